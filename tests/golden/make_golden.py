@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE T2S (imported from /root/reference through the
+`pytorch_transformers` -> `transformers` shim of SURVEY.md Appendix E) on seeded inputs and
+name-seeded weights, and writes small input/output fixtures to tests/golden/*.npz.
+
+Runs ONLY in the build container (needs /root/reference).  The fixtures are data (inputs and the
+reference's outputs); no reference source text is stored.  Re-run:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+ROW_STRIDE = 29
+
+
+def install_shims():
+    sys.path.insert(0, REF)
+    import transformers.models.bert.modeling_bert as mb
+    ptm = types.ModuleType("pytorch_transformers.modeling_bert")
+
+    class BertLayerNorm(nn.LayerNorm):
+        def __init__(self, hidden_size, eps=1e-12):
+            super().__init__(hidden_size, eps=eps)
+
+    class BertPreTrainedModel(mb.BertPreTrainedModel):
+        def init_weights(self):
+            if getattr(self, "_in_pi", False):
+                return mb.BertPreTrainedModel.init_weights(self)
+            self._in_pi = True
+            try:
+                self.post_init()
+            finally:
+                self._in_pi = False
+
+    ptm.BertLayerNorm, ptm.BertPreTrainedModel = BertLayerNorm, BertPreTrainedModel
+    ptm.BertEmbeddings, ptm.BertEncoder, ptm.BertConfig = mb.BertEmbeddings, mb.BertEncoder, mb.BertConfig
+    pt = types.ModuleType("pytorch_transformers")
+    pt.modeling_bert = ptm
+    sys.modules["pytorch_transformers"], sys.modules["pytorch_transformers.modeling_bert"] = pt, ptm
+    ed = types.ModuleType("editdistance")
+    ed.eval = lambda a, b: 0
+    sys.modules["editdistance"] = ed
+
+
+class AD(dict):
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def to_ad(x):
+    if isinstance(x, dict):
+        return AD({k: to_ad(v) for k, v in x.items()})
+    if isinstance(x, list):
+        return [to_ad(v) for v in x]
+    return x
+
+
+def build_reference(F_, P, V, text_vocab):
+    import yaml
+    from pythia.common.registry import registry
+
+    class W:
+        def write(self, *a, **k):
+            pass
+
+    registry.register("writer", W())
+    registry.register("config", to_ad({"datasets": "vtextgqa", "training_parameters": {"evalai_inference": False}}))
+    registry.register("vtextgqa_num_final_outputs", V + F_ * P)
+
+    class AP:
+        BOS_IDX = 1
+
+    registry.register("vtextgqa_answer_processor", AP())
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs/t2s_abinet.yml")))
+    mc = cfg["model_attributes"]["t2s"]
+    mc["grounding"].update(frame_num=F_, ocr_frame_num=P, max_ocr_num=F_ * P)
+    mc["classifier"]["ocr_max_num"] = F_ * P
+    mc["text_bert_init_from_bert_base"] = False
+    mc["text_bert"]["vocab_size"] = text_vocab
+    for k in ("text_bert", "translayers", "encoder", "mmt"):
+        mc[k]["hidden_dropout_prob"] = 0.0
+        mc[k]["attention_probs_dropout_prob"] = 0.0
+    mc["obj"]["dropout_prob"] = 0.0
+    mc["ocr"]["dropout_prob"] = 0.0
+    from pythia.models.t2s import T2S
+    m = T2S(to_ad(mc))
+    m.build()
+    return m
+
+
+def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs):
+    from vitxt_gqa_amd.schema import state_dict_schema
+    from vitxt_gqa_amd.init import make_state_dict, fingerprint
+    from vitxt_gqa_amd.synth import make_batch
+    from pythia.modules.losses import POSBCEWithMaskLoss, InfoNCE
+
+    m = build_reference(F_, P, V, text_vocab)
+    ref_sd = m.state_dict()
+    schema = state_dict_schema(V, text_vocab=text_vocab)
+    assert list(ref_sd.keys()) == list(schema.keys()), "schema key order mismatch"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(schema[k]), (k, v.shape, schema[k])
+    sd = make_state_dict(schema, seed=seed, attn_gain=attn_gain)
+    m.load_state_dict(sd)
+
+    batch = make_batch(B, F_, P, V=V, seed=seed, text_vocab=text_vocab)
+    sl = AD(batch)
+    sl.dataset_name, sl.dataset_type = "vtextgqa", "train"
+
+    # ---- noise: the two exponential draws the forward will consume under this seed (App. E)
+    noise_seed = 1000 + seed
+    torch.manual_seed(noise_seed)
+    E1 = torch.empty(B, 2, F_).exponential_()
+    E2 = torch.empty(B, 2, F_ * P).exponential_()
+
+    cap = {}
+    import pythia.models.t2s as t2s_mod
+    orig_ground = t2s_mod.Grounding_Module.forward
+
+    def ground_wrap(self, sample_list, fwd_results):
+        cap["txt_emb"] = fwd_results["txt_emb"].detach().clone()
+        cap["obj_in"] = fwd_results["obj_mmt_in"].detach().clone()
+        cap["ocr_in"] = fwd_results["ocr_mmt_in"].detach().clone()
+        r = orig_ground(self, sample_list, fwd_results)
+        for k in ("pos_obj_mask", "neg_obj_mask", "pos_ocr_mask", "neg_ocr_mask"):
+            cap[k] = fwd_results[k].detach().clone()
+        return r
+
+    orig_qtv = t2s_mod.QTV.forward
+
+    def qtv_wrap(self, fwd_results):
+        cap["txt_emb0"] = fwd_results["txt_emb"].detach().clone()
+        cap["obj_in0"] = fwd_results["obj_mmt_in"].detach().clone()
+        cap["ocr_in0"] = fwd_results["ocr_mmt_in"].detach().clone()
+        return orig_qtv(self, fwd_results)
+
+    t2s_mod.Grounding_Module.forward = ground_wrap
+    t2s_mod.QTV.forward = qtv_wrap
+    hooks = []
+    def h_frame(mod, i, o):
+        cap["frame_score"] = o.detach().clone()
+
+    def h_ocr(mod, i, o):
+        cap["ocr_score"] = o.detach().clone()
+        cap["new_ocr_mask"] = i[2].detach().clone()
+        cap["global_q"] = i[0].detach().clone()
+
+    mmt_outs, dec_embs = [], []
+
+    def h_mmt(mod, i, o):
+        mmt_outs.append([t.detach().clone() for t in o])
+
+    def h_dec(mod, i, o):
+        dec_embs.append(o.detach().clone())
+
+    hooks.append(m.Grounding_Module.frame_grounding_indicator.frame_pos_att.register_forward_hook(h_frame))
+    hooks.append(m.Grounding_Module.ocr_grounding_indicator.ocr_pos_att.register_forward_hook(h_ocr))
+    hooks.append(m.mmt.register_forward_hook(h_mmt))
+    hooks.append(m.mmt.prev_pred_embeddings.register_forward_hook(h_dec))
+
+    # ---- train-mode forward + losses + backward + clip + Adam (base_trainer.py:251-278)
+    m.train()
+    torch.manual_seed(noise_seed)
+    out = m.forward(sl)
+    bce = POSBCEWithMaskLoss()(sl, out)
+    nce = InfoNCE()(sl, out)
+    loss = 1.0 * bce + 1000.0 * nce
+    opt = torch.optim.Adam(m.get_optimizer_parameters(to_ad({"optimizer_attributes": {"params": {"lr": 1e-4}}})),
+                           lr=1e-4, eps=1e-8, weight_decay=0)
+    opt.zero_grad()
+    loss.backward()
+    gnames, gnorms = [], []
+    grads = {}
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            gnames.append(k)
+            gnorms.append(float(p.grad.double().norm()))
+    for k in ("mmt.encoder.layer.2.output.LayerNorm.weight", "ocr_ptr_net.query.bias",
+              "TransLayer.encoder.layer.0.attention.self.query.bias", "obj_feat_layer_norm.weight",
+              "text_bert.encoder.layer.0.attention.output.LayerNorm.bias",
+              "mmt.prev_pred_embeddings.emb_layer_norm.weight", "classifier.module.bias"):
+        grads[k] = dict(m.named_parameters())[k].grad.detach().clone()
+    grads["mmt.encoder.layer.0.attention.self.key.weight[:4]"] = \
+        dict(m.named_parameters())["mmt.encoder.layer.0.attention.self.key.weight"].grad[:4].detach().clone()
+    grads["linear_ocr_feat_to_mmt_in.weight[:2]"] = \
+        dict(m.named_parameters())["linear_ocr_feat_to_mmt_in.weight"].grad[:2].detach().clone()
+    total_norm = float(nn.utils.clip_grad_norm_(m.parameters(), 0.25))
+    opt.step()
+    after = {k: dict(m.named_parameters())[k].detach().clone()[:8]
+             for k in ("mmt.encoder.layer.2.output.LayerNorm.weight", "ocr_ptr_net.query.bias",
+                       "mmt.encoder.layer.1.intermediate.dense.bias")}
+
+    res = dict(
+        E1=E1, E2=E2,
+        ref_scores=out["ref_scores"], pos_scores=out["pos_scores"], neg_scores=out["neg_scores"],
+        ground_box=out["ground_box"], ground_frame=out["ground_frame"],
+        frame_topk=out["frame_topk"], ocr_topk=out["ocr_topk"],
+        loss_bce=bce, loss_nce=nce, loss_total=loss, grad_total_norm=torch.tensor(total_norm),
+        grad_norms=torch.tensor(gnorms, dtype=torch.float64),
+        ref_mmt_ocr=mmt_outs[0][0], ref_mmt_dec=mmt_outs[0][1],
+        pos_mmt_dec=mmt_outs[1][1], neg_mmt_dec=mmt_outs[2][1], dec_emb=dec_embs[0],
+    )
+    res.update(cap)
+    for k, v in grads.items():
+        res["grad:" + k] = v
+    for k, v in after.items():
+        res["after:" + k] = v
+
+    # ---- eval-mode greedy decode (t2s.py:315-354) with the SAME weights as train mode above?
+    # No: Adam already stepped.  Reload the pristine weights so the eval fixture is self-contained.
+    m.load_state_dict(sd)
+    m.eval()
+    mmt_outs.clear()
+    dec_embs.clear()
+    with torch.no_grad():
+        torch.manual_seed(noise_seed)
+        eo = m.forward(sl)
+    res["eval_pos_scores"] = eo["pos_scores"]
+    res["eval_ref_scores"] = eo["ref_scores"]
+    res["eval_neg_scores"] = eo["neg_scores"]
+    res["eval_argmax"] = eo["pos_scores"].argmax(-1)
+    for k in ("pos_obj_mask", "neg_obj_mask", "pos_ocr_mask", "neg_ocr_mask"):
+        res["eval_" + k] = cap[k]
+
+    for h in hooks:
+        h.remove()
+    t2s_mod.Grounding_Module.forward = orig_ground
+    t2s_mod.QTV.forward = orig_qtv
+
+    meta = dict(name=name, B=B, F=F_, P=P, V=V, text_vocab=text_vocab, seed=seed, attn_gain=attn_gain,
+                noise_seed=noise_seed, grad_names=gnames,
+                weight_fingerprint=fingerprint(sd, ["mmt.encoder.layer.0.attention.self.query.weight",
+                                                    "classifier.module.weight", "ocr_ptr_net.key.bias",
+                                                    "frame_embeddings.weight"]),
+                torch=torch.__version__, numpy=np.__version__)
+    meta["row_stride"] = ROW_STRIDE if not store_inputs else 1
+    if not store_inputs:
+        # slim fixture: keep every ROW_STRIDE-th row of the big [B, N, 768] intermediates
+        for k in ("ocr_in0", "ocr_in", "ref_mmt_ocr"):
+            res[k] = res[k][:, ::ROW_STRIDE].contiguous()
+        meta_stride = ROW_STRIDE
+    else:
+        meta_stride = 1
+    arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in res.items()}
+    if store_inputs:
+        for k, v in batch.items():
+            arrays["in:" + k] = v.numpy()
+    else:
+        meta["input_fingerprint"] = {k: float(v.double().sum()) for k, v in batch.items()}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(name, "loss", float(loss), "bce", float(bce), "nce", float(nce), "gnorm", total_norm,
+          "->", path, os.path.getsize(path) // 1024, "KiB")
+    return list(ref_sd.keys()), {k: list(v.shape) for k, v in ref_sd.items()}
+
+
+def main():
+    install_shims()
+    torch.set_num_threads(8)
+    # tiny: P >= ocr_topk, F >= frame_topk (Appendix E); peaky attention (attn_gain) so that the
+    # softmax is far from uniform and a wrong mask / wrong scale shows up
+    run_case("tiny_b2_f6_p8", B=2, F_=6, P=8, V=64, text_vocab=1000, seed=3, attn_gain=6.0, store_inputs=True)
+    # BASELINE.json configs[0]: batch=2, 20 frames x 30 OCR tokens per frame (N=600), reference init std
+    keys, shapes = run_case("cfg1_b2_f20_p30", B=2, F_=20, P=30, V=1000, text_vocab=30522, seed=11,
+                            attn_gain=1.0, store_inputs=False)
+    # checkpoint schema at the real vocabulary sizes (names/order/shapes, Appendix D)
+    from vitxt_gqa_amd.schema import state_dict_schema
+    json.dump({"keys": keys, "note": "reference T2S.state_dict() key order; shapes at V=1000, text_vocab=30522",
+               "shapes": shapes}, open(os.path.join(HERE, "state_dict_schema.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    main()

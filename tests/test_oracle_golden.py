@@ -1,0 +1,162 @@
+"""Pins the CPU oracle (oracle/t2s_oracle.py) against the golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  CPU-only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Fixture
+from oracle import t2s_oracle as O
+
+CASES = ["tiny_b2_f6_p8", "cfg1_b2_f20_p30"]
+
+
+def _close(a, b, atol, rtol=1e-4, what=""):
+    a, b = a.double(), b.double()
+    err = (a - b).abs().max().item()
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), "%s max abs err %.3e" % (what, err)
+
+
+@pytest.fixture(scope="module", params=CASES)
+def run(request):
+    fx = Fixture(request.param)
+    sd = fx.state_dict(torch.float64)
+    b = fx.batch()
+    s = {k: (v.double() if v.is_floating_point() else v) for k, v in b.items()}
+    for v in sd.values():
+        v.requires_grad_(True)
+    res = O.t2s_forward(sd, s, fx.cfg, training=True, expo_frame=fx["E1"].double(), expo_ocr=fx["E2"].double(),
+                        inject_masks={k: v.double() for k, v in fx.masks().items()}, keep=True)
+    return fx, sd, s, res
+
+
+def test_intermediates(run):
+    fx, sd, s, res = run
+    it = res["_inter"]
+    st = fx.meta["row_stride"]
+    _close(it["txt_emb0"], fx["txt_emb0"], 2e-5, what="text_bert")
+    _close(it["obj_in0"], fx["obj_in0"], 2e-5, what="obj_encoding")
+    _close(it["ocr_in0"][:, ::st], fx["ocr_in0"], 2e-5, what="ocr_encoding")
+    _close(it["txt_emb"], fx["txt_emb"], 5e-5, what="qtv txt")
+    _close(it["obj_in"], fx["obj_in"], 5e-5, what="qtv obj")
+    _close(it["ocr_in"][:, ::st], fx["ocr_in"], 5e-5, what="qtv ocr")
+
+
+def test_grounding_scores_and_selection(run):
+    """Scorer values match; the oracle's OWN selection (noise injected, lowest-index tie rule) equals the
+    reference's masks wherever the reference's choice is tie-free."""
+    fx, sd, s, res = run
+    with torch.no_grad():
+        it = res["_inter"]
+        g = O.grounding(sd, it["txt_emb"], O.get_mask(s["text_len"], 20).double(), it["obj_in"], s["frame_mask"],
+                        it["ocr_in"], s["frame_id"], s["temporal_id"], s["ocr_bbox_coordinates"],
+                        fx["E1"].double(), fx["E2"].double(), 5, 5, fx.F, fx.P)
+    _close(g["global_q"], fx["global_q"], 5e-5, what="global_q")
+    _close(g["frame_score"], fx["frame_score"], 1e-5, what="frame_score")
+    # pos frame top-k is tie-free whenever >=5 frames fall in the pos split
+    E1 = fx["E1"]
+    pos_cnt = ((-torch.log(E1[:, 0])) >= (-torch.log(E1[:, 1]))).sum(1)
+    for b in range(fx.B):
+        if pos_cnt[b] >= 5:
+            assert torch.equal(g["pos_obj_mask"][b].float(), fx["pos_obj_mask"][b].float())
+            assert torch.equal(g["ground_frame"][b], fx["ground_frame"][b])
+            assert torch.equal(g["new_ocr_mask"][b].float(), fx["new_ocr_mask"][b].float())
+    # mask cardinalities (Q10)
+    assert g["pos_obj_mask"].sum(1).tolist() == [5.0] * fx.B
+    assert g["pos_ocr_mask"].sum(1).tolist() == [5.0 * fx.F] * fx.B
+    assert (g["neg_ocr_mask"].sum(1) <= 25).all()
+    assert g["ground_box"].shape == (fx.B, 5 * fx.F, 4)
+    # spatial stage on the REFERENCE's grounded frames (decouples it from temporal tie-breaking)
+    with torch.no_grad():
+        newm = O.new_ocr_mask_from_frames(fx["ground_frame"], s["temporal_id"]).double()
+        assert torch.equal(newm.float(), fx["new_ocr_mask"].float())
+        o_score = O.attention_score(g["global_q"], it["ocr_in"], newm)
+        _close(o_score, fx["ocr_score"], 1e-5, what="ocr_score")
+        box, my_pos, my_neg = O.spatial_grounding(o_score, s["ocr_bbox_coordinates"], newm, fx["E2"].double(),
+                                                  5, fx.F, fx.P)
+    # pos OCR selection inside grounded frames with >=5 pos tokens is tie-free -> must match the reference
+    P = fx.P
+    ref_pos = fx["pos_ocr_mask"].view(fx.B, fx.F, P)
+    my_pos = my_pos.view(fx.B, fx.F, P)
+    E2 = fx["E2"]
+    pos_split = ((-torch.log(E2[:, 0])) >= (-torch.log(E2[:, 1]))).view(fx.B, fx.F, P)
+    nm = newm.view(fx.B, fx.F, P).bool()
+    checked = 0
+    for b in range(fx.B):
+        for f in range(fx.F):
+            if nm[b, f].all() and pos_split[b, f].sum() >= 5:
+                assert torch.equal(my_pos[b, f].float(), ref_pos[b, f].float())
+                checked += 1
+    assert checked > 0
+    # the neg OCR mask only ever selects inside grounded frames, at most 5 per frame
+    assert ((fx["neg_ocr_mask"].view(fx.B, fx.F, P).sum(-1)) <= 5).all()
+    assert (my_neg * (1 - newm)).sum() == 0
+
+
+def test_scores(run):
+    fx, sd, s, res = run
+    st = fx.meta["row_stride"]
+    for k in ("ref_scores", "pos_scores", "neg_scores"):
+        _close(res[k], fx[k], 2e-4, what=k)
+    assert torch.equal(res["frame_topk"], fx["frame_topk"]) and torch.equal(res["ocr_topk"], fx["ocr_topk"])
+
+
+def test_losses_and_grads(run):
+    fx, sd, s, res = run
+    loss, a, b = O.total_loss(res, s["targets"], s["train_loss_mask"])
+    _close(a, fx["loss_bce"], 1e-3, what="bce")
+    _close(b / 1000.0, fx["loss_nce"], 1e-5, what="nce")
+    names = fx.meta["grad_names"]
+    grads = torch.autograd.grad(loss, [sd[n] for n in names], allow_unused=True)
+    assert all(g is not None for g in grads)
+    live = set(names)
+    for n in sd:
+        assert (n in live) != O.is_dead(n), n          # dead-parameter list == reference's grad=None set
+    gn = torch.stack([g.norm() for g in grads])
+    ref = fx["grad_norms"]
+    # key-bias grads are mathematically 0 (softmax shift invariance): the reference's fp32 values there are
+    # rounding noise, hence the absolute floor relative to the total norm
+    floor = 1e-7 * fx["grad_total_norm"].item()
+    rel = ((gn - ref).abs() / (ref + floor / 2e-3)).max().item()
+    assert rel < 2e-3, "grad-norm rel err %.3e" % rel
+    gd = dict(zip(names, grads))
+    for k, v in fx.arr.items():
+        if not k.startswith("grad:"):
+            continue
+        n = k[5:]
+        if n.endswith("]"):
+            base, sl = n[:-1].split("[:")
+            g = gd[base][:int(sl)]
+        else:
+            g = gd[n]
+        scale = v.abs().max().item()
+        _close(g, v, atol=2e-3 * scale + 1e-7, rtol=2e-3, what=k)
+    total = torch.sqrt(sum((g ** 2).sum() for g in grads)).item()
+    assert abs(total - fx["grad_total_norm"].item()) / fx["grad_total_norm"].item() < 1e-3
+
+
+def test_adam_step():
+    fx = Fixture("tiny_b2_f6_p8")
+    sd = fx.state_dict(torch.float64)
+    s = {k: (v.double() if v.is_floating_point() else v) for k, v in fx.batch().items()}
+    for k, v in sd.items():
+        v.requires_grad_(not O.is_dead(k))
+    st = {}
+    loss, gnorm, a, b = O.train_step(sd, s, fx.cfg, st, 1, expo_frame=fx["E1"].double(), expo_ocr=fx["E2"].double(),
+                                     inject_masks={k: v.double() for k, v in fx.masks().items()})
+    assert abs(loss - fx["loss_total"].item()) / fx["loss_total"].item() < 1e-4
+    assert abs(gnorm - fx["grad_total_norm"].item()) / fx["grad_total_norm"].item() < 1e-3
+    for k, v in fx.arr.items():
+        if k.startswith("after:"):
+            _close(sd[k[6:]].detach()[:8], v, atol=2e-6, rtol=1e-5, what=k)
+
+
+def test_eval_greedy_decode():
+    fx = Fixture("tiny_b2_f6_p8")
+    sd = fx.state_dict(torch.float64)
+    s = {k: (v.double() if v.is_floating_point() else v) for k, v in fx.batch().items()}
+    with torch.no_grad():
+        res = O.t2s_forward(sd, s, fx.cfg, training=False, expo_frame=fx["E1"].double(), expo_ocr=fx["E2"].double(),
+                            inject_masks={k: v.double() for k, v in fx.masks("eval_").items()})
+    _close(res["pos_scores"], fx["eval_pos_scores"], 2e-4, what="eval pos")
+    _close(res["ref_scores"], fx["eval_ref_scores"], 2e-4, what="eval ref")
+    assert torch.equal(res["pos_scores"].argmax(-1), fx["eval_argmax"])     # pointer/copy indices bit-exact
