@@ -1,0 +1,195 @@
+"""GPU parity tests of the individual HIP kernels (called through the C ABI via vitxt_gqa_amd.ops)
+against plain fp32/fp64 torch restatements of the same op.  Run on the MI355X box: pytest -m gpu."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def dense_mask(valid, n_dec, L):
+    """[B, L, L] boolean visibility equal to the reference's extended mask (t2s.py:413-419, 609-618):
+    prefix keys by `valid`, decoder key j visible to decoder row i iff i >= j."""
+    B, L1 = valid.shape
+    assert L1 + n_dec == L
+    m = torch.zeros(B, L, L, dtype=torch.bool, device=valid.device)
+    m[:, :, :L1] = valid.bool().unsqueeze(1)
+    if n_dec:
+        m[:, L1:, L1:] = torch.tril(torch.ones(n_dec, n_dec, dtype=torch.bool, device=valid.device))
+    return m
+
+
+def ref_attention(qkv, mask, scale):
+    B, L, _ = qkv.shape
+    q, k, v = [t.view(B, L, 12, 64).permute(0, 2, 1, 3) for t in qkv.split(768, dim=-1)]
+    s = (q @ k.transpose(-1, -2)) * scale + (~mask).unsqueeze(1).to(q.dtype) * -10000.0
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B, L, 768)
+
+
+CASES = [  # B, L1 (prefix rows), n_dec, keep probability
+    (2, 20, 0, 0.6),
+    (2, 77, 0, 0.7),
+    (3, 200, 12, 0.7),
+    (2, 300, 12, 0.05),
+    (1, 515, 12, 1.0),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,L1,n_dec,keep", CASES)
+def test_attention_fwd_bwd(B, L1, n_dec, keep, dtype, tol):
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + L1)
+    L = L1 + n_dec
+    qkv = (torch.randn(B, L, 2304, generator=g) * 1.5).to(DEV)
+    valid = (torch.rand(B, L1, generator=g) < keep).to(DEV)
+    valid[:, 0] = True
+    dout = torch.randn(B, L, 768, generator=g).to(DEV)
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
+    # key list content
+    cnt = valid.sum(1).to(torch.int32)
+    assert torch.equal(keys.cnt, cnt)
+    for b in range(B):
+        exp = torch.nonzero(valid[b]).flatten().to(torch.int32)
+        assert torch.equal(keys.idx[b, :cnt[b]], exp)
+        if n_dec:
+            assert torch.equal(keys.idx[b, cnt[b]:cnt[b] + n_dec], torch.arange(L1, L, device=DEV, dtype=torch.int32))
+
+    x = qkv.to(dtype)
+    out, lse = ops.attn_fwd(x, keys)
+    xr = x.double().requires_grad_(True)
+    ref = ref_attention(xr, dense_mask(valid, n_dec, L), 0.125)
+    err = (out.double() - ref).abs().max().item()
+    assert err < tol, "fwd max err %.3e" % err
+    # log-sum-exp
+    q, k, _ = [t.view(B, L, 12, 64).permute(0, 2, 1, 3) for t in xr.detach().split(768, dim=-1)]
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    s = s.masked_fill(~dense_mask(valid, n_dec, L).unsqueeze(1), float("-inf"))
+    assert (lse.double() - torch.logsumexp(s, -1)).abs().max().item() < (1e-4 if dtype == torch.float32 else 2e-2)
+
+    dqkv = ops.attn_bwd(x, out, dout.to(dtype), lse, keys)
+    (gref,) = torch.autograd.grad(ref, xr, dout.to(dtype).double())
+    scale = gref.abs().max().item()
+    gerr = (dqkv.double() - gref).abs().max().item()
+    assert gerr < tol * max(1.0, scale) * (1 if dtype == torch.float32 else 2), "bwd max err %.3e (scale %.3e)" % (gerr, scale)
+    # masked keys get exactly zero dK / dV
+    kvalid = torch.cat([valid, torch.ones(B, n_dec, dtype=torch.bool, device=DEV)], 1)
+    assert dqkv[..., 768:][~kvalid].abs().max().item() == 0 if (~kvalid).any() else True
+
+
+def test_attention_spiky_rows_force_rescale():
+    """Online-softmax rescale path: one key far above the rest, placed in a late tile (guide rule 26)."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    B, L = 1, 400
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, L, 2304, generator=g).to(DEV)
+    qkv[:, 350, 768:1536] = qkv[:, 3, :768] * 6.0       # key 350 aligned with query 3 (all heads): score jumps late
+    keys = ops.compact_keys(torch.ones(B, L, dtype=torch.bool, device=DEV))
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 3e-2)):
+        x = qkv.to(dtype)
+        out, _ = ops.attn_fwd(x, keys)
+        ref = ref_attention(x.double(), torch.ones(B, L, L, dtype=torch.bool, device=DEV), 0.125)
+        assert (out.double() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("rows", [1, 7, 1000])
+def test_add_layernorm(rows, dtype, tol):
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 768, generator=g).to(DEV).to(dtype)
+    r = torch.randn(rows, 768, generator=g).to(DEV).to(dtype)
+    gam = (1 + 0.1 * torch.randn(768, generator=g)).to(DEV)
+    bet = (0.1 * torch.randn(768, generator=g)).to(DEV)
+    dy = torch.randn(rows, 768, generator=g).to(DEV).to(dtype)
+    xr, rr = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    z = xr + rr
+    ref = (z - z.mean(-1, keepdim=True)) / torch.sqrt(z.var(-1, unbiased=False, keepdim=True) + 1e-12) * gr + br
+    y, zz, st = ops.add_layernorm_fwd(x.clone(), r, gam, bet, inplace_z=False)
+    assert (y.double() - ref).abs().max().item() < tol
+    assert (zz.double() - z).abs().max().item() < tol
+    dz, dg, db = ops.add_layernorm_bwd(dy, zz, st, gam)
+    gx, gg, gb = torch.autograd.grad(ref, (xr, gr, br), dy.double())
+    assert (dz.double() - gx).abs().max().item() < tol * 5
+    assert (dg.double() - gg).abs().max().item() < tol * 5 * math.sqrt(rows)
+    assert (db.double() - gb).abs().max().item() < tol * 5 * math.sqrt(rows)
+    # without residual, in place
+    y2, z2, _ = ops.add_layernorm_fwd(x.clone(), None, gam, bet)
+    zr = x.double()
+    ref2 = (zr - zr.mean(-1, keepdim=True)) / torch.sqrt(zr.var(-1, unbiased=False, keepdim=True) + 1e-12) * gam.double() + bet.double()
+    assert (y2.double() - ref2).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_gelu(dtype, tol):
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    g = torch.Generator().manual_seed(1)
+    u = (torch.randn(333, 3072, generator=g) * 2).to(DEV).to(dtype)
+    dy = torch.randn(333, 3072, generator=g).to(DEV).to(dtype)
+    ur = u.double().requires_grad_(True)
+    ref = ur * 0.5 * (1 + torch.erf(ur / math.sqrt(2)))
+    y = ops.gelu_fwd(u)
+    assert (y.double() - ref).abs().max().item() < tol
+    du, db = ops.gelu_bwd(dy, u)
+    (gu,) = torch.autograd.grad(ref, ur, dy.double())
+    assert (du.double() - gu).abs().max().item() < tol * 4
+    assert (db.double() - gu.sum(0)).abs().max().item() < tol * 40
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 5e-2)])
+def test_bert_layer_fn(dtype, tol):
+    """Fused BertLayer autograd function vs the oracle's restatement of the third-party BERT block."""
+    _need_gpu()
+    from oracle import t2s_oracle as O
+    from vitxt_gqa_amd import functional as FN
+    from vitxt_gqa_amd import ops
+    from vitxt_gqa_amd.t2s import BertLayerParams
+    torch.manual_seed(0)
+    lp = BertLayerParams()
+    for p in lp.parameters():
+        p.data.normal_(0, 0.05)
+    lp.attention.output.LayerNorm.weight.data.add_(1.0)
+    lp.output.LayerNorm.weight.data.add_(1.0)
+    B, L1, n_dec = 2, 90, 12
+    L = L1 + n_dec
+    x = torch.randn(B, L, 768)
+    valid = torch.rand(B, L1) < 0.6
+    valid[:, 0] = True
+    dy = torch.randn(B, L, 768)
+    # oracle (fp64, CPU)
+    sd = {"l." + k: v.detach().double().requires_grad_(True) for k, v in lp.state_dict().items()}
+    xr = x.to(dtype).double().requires_grad_(True)
+    ext = (~dense_mask(valid, n_dec, L)).double().unsqueeze(1) * -10000.0
+    ref = O.bert_layer(sd, "l.", xr, ext)
+    names = list(sd)
+    grads = torch.autograd.grad(ref, [xr] + [sd[n] for n in names], dy.to(dtype).double())
+    # HIP path
+    lp = lp.to(DEV)
+    xg = x.to(DEV).to(dtype).requires_grad_(True)
+    keys = ops.compact_keys(valid.to(DEV), n_dec=n_dec, dec_row0=L1)
+    y = FN.bert_layer(xg, keys, lp, dtype)
+    assert (y.double().cpu() - ref).abs().max().item() < tol
+    y.backward(dy.to(DEV).to(dtype))
+    assert (xg.grad.double().cpu() - grads[0]).abs().max().item() < tol * max(1.0, grads[0].abs().max().item()) * 4
+    got = dict(lp.named_parameters())
+    for n, gr in zip(names, grads[1:]):
+        a = got[n[2:]].grad.double().cpu()
+        rel = (a - gr).norm().item() / max(gr.norm().item(), 1e-6 * gr.numel() ** 0.5)
+        if "key.bias" in n:        # mathematically zero gradient
+            assert a.abs().max().item() < 1e-2
+            continue
+        assert rel < (2e-4 if dtype == torch.float32 else 4e-2), "%s rel err %.3e" % (n, rel)

@@ -1,0 +1,560 @@
+// Flash-style self-attention backward for gfx950 (MI355X), head_dim 64.
+//
+// Gradient of the BertSelfAttention block the reference runs eagerly (see attn_fwd.hip for the call
+// sites).  P is recomputed from Q, K and the forward's log-sum-exp; nothing of size L x L is stored.
+//   delta = rowsum(dO * O);  P = exp(scale*S - LSE);  dS = P * (dO V^T - delta)
+//   dV = P^T dO;  dK = scale * dS^T Q;  dQ = scale * dS K
+// Two MFMA kernels, both deterministic (no atomics):
+//   * dK/dV: key-stationary.  A workgroup = 4 waves = 128 keys of the compacted key list of one
+//     (batch, head); each wave keeps dK^T and dV^T of its 32 keys in accumulators (key on the lane)
+//     while the workgroup sweeps 32-row query tiles staged in LDS.  S and dP are computed with the
+//     key on the MFMA lane, so their accumulators are directly the B operands of the dV^T / dK^T
+//     products; the A operands (dO^T, Q^T) are ds_read_b64_tr_b16 reads of the same LDS tiles.
+//   * dQ: query-stationary, same skeleton as the forward (query on the lane): S^T and dP^T from row
+//     reads of the K and V tiles, dQ^T += K^T dS^T with transposed reads of the K tile.
+// The fp32 variants keep the data flow on v_mfma_f32_32x32x2_f32.
+#include "attn_common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int TILE64 = 64 * 128;    // bytes of a 64-row bf16 tile
+constexpr int TILE32 = 32 * 128;    // bytes of a 32-row bf16 tile
+
+// ---------------------------------------------------------------------------------------------
+// delta[b, h, q] = sum_d dO[b, q, h, d] * O[b, q, h, d].  One wave per token row (768 elements).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta,
+                                                         int B, int H, int Lq, int64_t o_rs, int64_t o_bs) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * Lq) return;
+  const int b = (int)(row / Lq), q = (int)(row % Lq);
+  const T* op = o + (int64_t)b * o_bs + (int64_t)q * o_rs;
+  const T* dp = dout + (int64_t)b * o_bs + (int64_t)q * o_rs;
+  const int nchunk = H * 16;              // 4-element chunks per row
+  for (int c0 = 0; c0 < nchunk; c0 += 64) {
+    const int ci = c0 + lane;
+    float s = 0.f;
+    if (ci < nchunk) {
+      const f32x4 a = Vec4<T>::load(op + ci * 4), d = Vec4<T>::load(dp + ci * 4);
+      s = a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    if ((lane & 15) == 0 && ci < nchunk) delta[((int64_t)b * H + (ci >> 4)) * Lq + q] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dK / dV, bf16.
+template <bool USE_IDX>
+__global__ __launch_bounds__(256) void attn_dkdv_bf16_kernel(AttnParams p) {
+  // [buf][Q tile 4 KB | dO tile 4 KB | lse 32 f | delta 32 f]
+  constexpr int STAGE = 2 * TILE32 + 256;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
+  const int nk = n_prefix + p.n_dec;
+  const int kp0 = blockIdx.x * 128;
+  if (kp0 >= nk) return;                                   // uniform per workgroup
+  const int kpos = kp0 + wave * 32 + lr;                   // this lane's key position (column)
+  const bool kvalid = kpos < nk;
+  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
+  const int kclamp = kvalid ? kpos : nk - 1;
+  const int64_t krow = USE_IDX ? (int64_t)idx[kclamp] : (int64_t)kclamp;
+  const bf16_t* __restrict__ Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* __restrict__ DO = reinterpret_cast<const bf16_t*>(p.dout) + (int64_t)b * p.o_bs + h * 64;
+  const float* __restrict__ LSE = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  const float* __restrict__ DELTA = p.delta + ((int64_t)b * p.H + h) * p.Lq;
+
+  // K / V fragments of this wave's 32 keys: B operands, lane (key = lr, half lh) holds [key][16s+8lh..]
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs + 8 * lh;
+    const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
+      vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s);
+    }
+  }
+  const int kdec = kpos - n_prefix;        // decoder step of this key (negative: prefix key)
+  const float c = p.scale * LOG2E;
+  const int nqt = (p.Lq + 31) / 32;
+
+  // staging: thread -> (row sr, chunk sc) of the 32 x 64 Q and dO tiles
+  const int sr = tid >> 3, sc = tid & 7;
+  uint4 qreg, doreg;
+  float lreg = 0.f, dreg = 0.f;
+  auto stage_load = [&](int qt) {
+    const int r = qt * 32 + sr;
+    const bool ok = r < p.Lq;
+    const int rc = ok ? r : p.Lq - 1;
+    qreg = *reinterpret_cast<const uint4*>(Q + (int64_t)rc * p.q_rs + sc * 8);
+    doreg = *reinterpret_cast<const uint4*>(DO + (int64_t)rc * p.o_rs + sc * 8);
+    if (!ok) doreg = make_uint4(0, 0, 0, 0);
+    if (tid < 32) {
+      const int r2 = qt * 32 + tid;
+      lreg = r2 < p.Lq ? LSE[r2] * LOG2E : INFINITY;     // +inf => P = 0 for rows past Lq
+      dreg = r2 < p.Lq ? DELTA[r2] : 0.f;
+    }
+  };
+  auto stage_write = [&](int buf) {
+    char* base = smem + buf * STAGE;
+    *reinterpret_cast<uint4*>(base + tile_off(sr, sc)) = qreg;
+    *reinterpret_cast<uint4*>(base + TILE32 + tile_off(sr, sc)) = doreg;
+    if (tid < 32) {
+      reinterpret_cast<float*>(base + 2 * TILE32)[tid] = lreg;
+      reinterpret_cast<float*>(base + 2 * TILE32 + 128)[tid] = dreg;
+    }
+  };
+
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
+
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int buf = qt & 1;
+    if (qt + 1 < nqt) stage_load(qt + 1);
+    const char* qb = smem + buf * STAGE;
+    const char* dob = qb + TILE32;
+    const float* lse_s = reinterpret_cast<const float*>(qb + 2 * TILE32);
+    const float* del_s = lse_s + 32;
+
+    f32x16 sacc, dpacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sacc[i] = 0.f; dpacc[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sacc = mfma_bf16(lds_row_frag(qb, lr, s, lh), kf[s], sacc);        // S[q, key]
+      dpacc = mfma_bf16(lds_row_frag(dob, lr, s, lh), vf[s], dpacc);     // dP[q, key]
+    }
+    // rows of this lane's accumulator registers: q = acc_row(r, lh): 4 groups of 4 consecutive rows
+    const bool edge = (kp0 + 128 > n_prefix);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 8 * g + 4 * lh);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + 8 * g + 4 * lh);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * g + j;
+        float pv = exp2f(sacc[r] * c - l4[j]);
+        if (edge) {
+          const int qdec = qt * 32 + 8 * g + 4 * lh + j - p.dec_q0;
+          const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
+          pv = ok ? pv : 0.f;
+        }
+        sacc[r] = pv;
+        dpacc[r] = pv * (dpacc[r] - d4[j]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pf = acc_to_frag(sacc, s), dsf = acc_to_frag(dpacc, s);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dvacc[db] = mfma_bf16(lds_tr_frag(dob, 16 * s, db, lane), pf, dvacc[db]);   // dV^T[d, key] += dO^T[d, q] P[q, key]
+        dkacc[db] = mfma_bf16(lds_tr_frag(qb, 16 * s, db, lane), dsf, dkacc[db]);   // dK^T[d, key] += Q^T[d, q] dS[q, key]
+      }
+    }
+    if (qt + 1 < nqt) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (kvalid) {
+    bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs;
+    bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dv) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * lh;
+        bf16x4 k4 = {(bf16_t)(dkacc[db][4 * g] * p.scale), (bf16_t)(dkacc[db][4 * g + 1] * p.scale),
+                     (bf16_t)(dkacc[db][4 * g + 2] * p.scale), (bf16_t)(dkacc[db][4 * g + 3] * p.scale)};
+        bf16x4 v4 = {(bf16_t)dvacc[db][4 * g], (bf16_t)dvacc[db][4 * g + 1], (bf16_t)dvacc[db][4 * g + 2], (bf16_t)dvacc[db][4 * g + 3]};
+        *reinterpret_cast<bf16x4*>(dkp + d) = k4;
+        *reinterpret_cast<bf16x4*>(dvp + d) = v4;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dQ, bf16.
+template <bool USE_IDX>
+__global__ __launch_bounds__(256) void attn_dq_bf16_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE64];   // [buf][K, V]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = q0 + lr;
+  const bool qvalid = qrow < p.Lq;
+  const int qr = qvalid ? qrow : p.Lq - 1;
+  const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
+  const int nk = n_prefix + p.n_dec;
+  const int ntiles = (nk + BK - 1) / BK;
+  const bf16_t* __restrict__ K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.kv_bs + h * 64;
+  const bf16_t* __restrict__ V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.kv_bs + h * 64;
+  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
+
+  bf16x8 qf[4], dof[4];
+  {
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_bs + h * 64 + (int64_t)qr * p.q_rs + 8 * lh;
+    const bf16_t* dp = reinterpret_cast<const bf16_t*>(p.dout) + (int64_t)b * p.o_bs + h * 64 + (int64_t)qr * p.o_rs + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+      dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+    }
+  }
+  const float lse2 = qvalid ? p.lse[((int64_t)b * p.H + h) * p.Lq + qr] * LOG2E : INFINITY;
+  const float del = p.delta[((int64_t)b * p.H + h) * p.Lq + qr];
+  const float c = p.scale * LOG2E;
+  const int qdec = qrow - p.dec_q0;
+
+  const int sr = tid >> 3, sc = tid & 7;
+  uint4 kreg[2], vreg[2];
+  auto stage_load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int pos = t * BK + sr + 32 * i;
+      pos = pos < nk ? pos : nk - 1;
+      const int64_t row = USE_IDX ? (int64_t)idx[pos] : (int64_t)pos;
+      kreg[i] = *reinterpret_cast<const uint4*>(K + row * p.kv_rs + sc * 8);
+      vreg[i] = *reinterpret_cast<const uint4*>(V + row * p.kv_rs + sc * 8);
+    }
+  };
+  auto stage_write = [&](int buf) {
+    char* kb = smem + buf * 2 * TILE64;
+    char* vb = kb + TILE64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = sr + 32 * i;
+      *reinterpret_cast<uint4*>(kb + tile_off(r, sc)) = kreg[i];
+      *reinterpret_cast<uint4*>(vb + tile_off(r, sc)) = vreg[i];
+    }
+  };
+
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+  if (ntiles > 0) {
+    stage_load(0);
+    stage_write(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage_load(t + 1);
+    const char* kb = smem + buf * 2 * TILE64;
+    const char* vb = kb + TILE64;
+    f32x16 sacc[2], dpacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sacc[0][i] = 0.f; sacc[1][i] = 0.f; dpacc[0][i] = 0.f; dpacc[1][i] = 0.f; }
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc[kbk] = mfma_bf16(lds_row_frag(kb, kbk * 32 + lr, s, lh), qf[s], sacc[kbk]);      // S^T[key, q]
+        dpacc[kbk] = mfma_bf16(lds_row_frag(vb, kbk * 32 + lr, s, lh), dof[s], dpacc[kbk]);   // dP^T[key, q]
+      }
+    const bool edge = (t * BK + BK > n_prefix);
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = exp2f(sacc[kbk][r] * c - lse2);
+        if (edge) {
+          const int pos = t * BK + kbk * 32 + acc_row(r, lh);
+          const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
+          pv = ok ? pv : 0.f;
+        }
+        dpacc[kbk][r] = pv * (dpacc[kbk][r] - del);
+      }
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 dsf = acc_to_frag(dpacc[kbk], s);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          dqacc[db] = mfma_bf16(lds_tr_frag(kb, kbk * 32 + 16 * s, db, lane), dsf, dqacc[db]);   // dQ^T[d, q] += K^T[d, key] dS^T[key, q]
+      }
+    if (t + 1 < ntiles) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+
+  char* ob = smem + wave * (32 * 144);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 t4 = {(bf16_t)(dqacc[db][4 * g] * p.scale), (bf16_t)(dqacc[db][4 * g + 1] * p.scale),
+                   (bf16_t)(dqacc[db][4 * g + 2] * p.scale), (bf16_t)(dqacc[db][4 * g + 3] * p.scale)};
+      *reinterpret_cast<bf16x4*>(ob + lr * 144 + (db * 32 + 8 * g + 4 * lh) * 2) = t4;
+    }
+  __syncthreads();
+  bf16_t* __restrict__ DQ = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.q_bs + h * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = i * 64 + lane, r = id >> 3, cc = id & 7;
+    if (q0 + r < p.Lq)
+      *reinterpret_cast<uint4*>(DQ + (int64_t)(q0 + r) * p.q_rs + cc * 8) = *reinterpret_cast<const uint4*>(ob + r * 144 + cc * 16);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 variants (parity mode).  Tiles are staged as padded fp32 rows; every MFMA operand is a
+// single ds_read_b32 / register value of v_mfma_f32_32x32x2_f32.
+constexpr int F32_LD = 65;
+
+template <bool USE_IDX>
+__global__ __launch_bounds__(256) void attn_dkdv_f32_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 32 * F32_LD + 64];
+  float* qs = smem;
+  float* dos = smem + 32 * F32_LD;
+  float* lse_s = smem + 2 * 32 * F32_LD;
+  float* del_s = lse_s + 32;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
+  const int nk = n_prefix + p.n_dec;
+  const int kp0 = blockIdx.x * 128;
+  if (kp0 >= nk) return;
+  const int kpos = kp0 + wave * 32 + lr;
+  const bool kvalid = kpos < nk;
+  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
+  const int kclamp = kvalid ? kpos : nk - 1;
+  const int64_t krow = USE_IDX ? (int64_t)idx[kclamp] : (int64_t)kclamp;
+  const float* __restrict__ Q = reinterpret_cast<const float*>(p.q) + (int64_t)b * p.q_bs + h * 64;
+  const float* __restrict__ DO = reinterpret_cast<const float*>(p.dout) + (int64_t)b * p.o_bs + h * 64;
+  const float* __restrict__ LSE = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  const float* __restrict__ DELTA = p.delta + ((int64_t)b * p.H + h) * p.Lq;
+  // B operands: B[k = lh][key] = K[key][2t + lh]
+  float kf[32], vf[32];
+  {
+    const float* kp = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs + lh;
+    const float* vp = reinterpret_cast<const float*>(p.v) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs + lh;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) { kf[t] = kp[2 * t]; vf[t] = vp[2 * t]; }
+  }
+  const int kdec = kpos - n_prefix;
+  const float c = p.scale * LOG2E;
+  const int nqt = (p.Lq + 31) / 32;
+  const int sr = tid >> 3, sc = tid & 7;     // 32 rows x 8 chunks of 8 floats
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
+
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+    {
+      const int r = qt * 32 + sr;
+      const bool ok = r < p.Lq;
+      const int rc = ok ? r : p.Lq - 1;
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(Q + (int64_t)rc * p.q_rs + sc * 8 + 4 * j2);
+        f32x4 d4 = *reinterpret_cast<const f32x4*>(DO + (int64_t)rc * p.o_rs + sc * 8 + 4 * j2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          qs[sr * F32_LD + sc * 8 + 4 * j2 + j] = q4[j];
+          dos[sr * F32_LD + sc * 8 + 4 * j2 + j] = ok ? d4[j] : 0.f;
+        }
+      }
+      if (tid < 32) {
+        const int r2 = qt * 32 + tid;
+        lse_s[tid] = r2 < p.Lq ? LSE[r2] * LOG2E : INFINITY;
+        del_s[tid] = r2 < p.Lq ? DELTA[r2] : 0.f;
+      }
+    }
+    __syncthreads();
+    f32x16 sacc, dpacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sacc[i] = 0.f; dpacc[i] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qs[lr * F32_LD + 2 * t + lh], kf[t], sacc, 0, 0, 0);
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dos[lr * F32_LD + 2 * t + lh], vf[t], dpacc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = acc_row(r, lh);
+      float pv = exp2f(sacc[r] * c - lse_s[qi]);
+      const int qdec = qt * 32 + qi - p.dec_q0;
+      const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
+      pv = ok ? pv : 0.f;
+      sacc[r] = pv;
+      dpacc[r] = pv * (dpacc[r] - del_s[qi]);
+    }
+    // dV^T[d, key] += dO^T[d, q] P[q, key]:  A[i = d][k = lh] = dO[q = acc_row(r, lh)][d],  B = P register r
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = acc_row(r, lh);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(dos[qi * F32_LD + db * 32 + lr], sacc[r], dvacc[db], 0, 0, 0);
+        dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(qs[qi * F32_LD + db * 32 + lr], dpacc[r], dkacc[db], 0, 0, 0);
+      }
+    }
+  }
+  if (kvalid) {
+    float* dkp = reinterpret_cast<float*>(p.dk) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs;
+    float* dvp = reinterpret_cast<float*>(p.dv) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * lh;
+        f32x4 k4 = {dkacc[db][4 * g] * p.scale, dkacc[db][4 * g + 1] * p.scale, dkacc[db][4 * g + 2] * p.scale, dkacc[db][4 * g + 3] * p.scale};
+        f32x4 v4 = {dvacc[db][4 * g], dvacc[db][4 * g + 1], dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(dkp + d) = k4;
+        *reinterpret_cast<f32x4*>(dvp + d) = v4;
+      }
+  }
+}
+
+template <bool USE_IDX>
+__global__ __launch_bounds__(256) void attn_dq_f32_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * F32_LD];
+  float* ks = smem;
+  float* vs = smem + BK * F32_LD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = q0 + lr;
+  const bool qvalid = qrow < p.Lq;
+  const int qr = qvalid ? qrow : p.Lq - 1;
+  const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
+  const int nk = n_prefix + p.n_dec;
+  const int ntiles = (nk + BK - 1) / BK;
+  const float* __restrict__ K = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.kv_bs + h * 64;
+  const float* __restrict__ V = reinterpret_cast<const float*>(p.v) + (int64_t)b * p.kv_bs + h * 64;
+  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
+  float qf[32], dof[32];
+  {
+    const float* qp = reinterpret_cast<const float*>(p.q) + (int64_t)b * p.q_bs + h * 64 + (int64_t)qr * p.q_rs + lh;
+    const float* dp = reinterpret_cast<const float*>(p.dout) + (int64_t)b * p.o_bs + h * 64 + (int64_t)qr * p.o_rs + lh;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) { qf[t] = qp[2 * t]; dof[t] = dp[2 * t]; }
+  }
+  const float lse2 = qvalid ? p.lse[((int64_t)b * p.H + h) * p.Lq + qr] * LOG2E : INFINITY;
+  const float del = p.delta[((int64_t)b * p.H + h) * p.Lq + qr];
+  const float c = p.scale * LOG2E;
+  const int qdec = qrow - p.dec_q0;
+  const int sr = tid >> 4, sc = tid & 15;
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = sr + 16 * i;
+      int pos = t * BK + r;
+      pos = pos < nk ? pos : nk - 1;
+      const int64_t row = USE_IDX ? (int64_t)idx[pos] : (int64_t)pos;
+      const f32x4 kv4 = *reinterpret_cast<const f32x4*>(K + row * p.kv_rs + sc * 4);
+      const f32x4 vv4 = *reinterpret_cast<const f32x4*>(V + row * p.kv_rs + sc * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ks[r * F32_LD + sc * 4 + j] = kv4[j];
+        vs[r * F32_LD + sc * 4 + j] = vv4[j];
+      }
+    }
+    __syncthreads();
+    f32x16 sacc[2], dpacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sacc[0][i] = 0.f; sacc[1][i] = 0.f; dpacc[0][i] = 0.f; dpacc[1][i] = 0.f; }
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[(kbk * 32 + lr) * F32_LD + 2 * s + lh], qf[s], sacc[kbk], 0, 0, 0);
+        dpacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(kbk * 32 + lr) * F32_LD + 2 * s + lh], dof[s], dpacc[kbk], 0, 0, 0);
+      }
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pos = t * BK + kbk * 32 + acc_row(r, lh);
+        const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
+        const float pv = ok ? exp2f(sacc[kbk][r] * c - lse2) : 0.f;
+        dpacc[kbk][r] = pv * (dpacc[kbk][r] - del);
+      }
+#pragma unroll
+    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbk * 32 + acc_row(r, lh);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[key * F32_LD + db * 32 + lr], dpacc[kbk][r], dqacc[db], 0, 0, 0);
+      }
+  }
+  if (qvalid) {
+    float* DQ = reinterpret_cast<float*>(p.dq) + (int64_t)b * p.q_bs + h * 64 + (int64_t)qrow * p.q_rs;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 t4 = {dqacc[db][4 * g] * p.scale, dqacc[db][4 * g + 1] * p.scale, dqacc[db][4 * g + 2] * p.scale, dqacc[db][4 * g + 3] * p.scale};
+        *reinterpret_cast<f32x4*>(DQ + db * 32 + 8 * g + 4 * lh) = t4;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                            float* delta, void* dq, void* dk, void* dv, const int32_t* kv_idx, const int32_t* kv_cnt, int B,
+                            int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys, int64_t q_row_stride, int64_t q_batch_stride,
+                            int64_t kv_row_stride, int64_t kv_batch_stride, int64_t o_row_stride, int64_t o_batch_stride,
+                            float scale, int dtype, t2s_stream_t stream) {
+  T2S_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
+  T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "attn_bwd: bad dtype %d", dtype);
+  T2S_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && idx_cap > 0 && n_dec >= 0 && n_dec <= idx_cap, "attn_bwd: bad shape");
+  T2S_CHECK_ARG((kv_idx == nullptr) == (kv_cnt == nullptr), "attn_bwd: kv_idx and kv_cnt must both be given or both be NULL");
+  const int al = dtype == T2S_BF16 ? 8 : 4;
+  T2S_CHECK_ARG(q_row_stride % al == 0 && kv_row_stride % al == 0 && o_row_stride % al == 0 && q_batch_stride % al == 0 &&
+                    kv_batch_stride % al == 0 && o_batch_stride % al == 0, "attn_bwd: strides must be multiples of 16 bytes");
+  T2S_CHECK_ARG(B <= 65535 && H <= 65535, "attn_bwd: B/H exceed grid limits");
+  T2S_CHECK_ARG(max_keys > 0 && max_keys <= idx_cap, "attn_bwd: max_keys %d outside (0, idx_cap=%d]", max_keys, idx_cap);
+  AttnParams p = {};
+  p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta;
+  p.dq = dq; p.dk = dk; p.dv = dv; p.kv_idx = kv_idx; p.kv_cnt = kv_cnt;
+  p.B = B; p.H = H; p.Lq = Lq; p.idx_cap = idx_cap; p.n_dec = n_dec; p.dec_q0 = dec_q0;
+  p.q_rs = q_row_stride; p.q_bs = q_batch_stride; p.kv_rs = kv_row_stride; p.kv_bs = kv_batch_stride;
+  p.o_rs = o_row_stride; p.o_bs = o_batch_stride; p.scale = scale;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * Lq;
+  dim3 gd((unsigned)((rows + 3) / 4)), blk(256);
+  dim3 gkv((max_keys + 127) / 128, H, B), gq((Lq + 127) / 128, H, B);
+  if (dtype == T2S_BF16) {
+    hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, gd, blk, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, H, Lq, o_row_stride, o_batch_stride);
+    if (kv_idx) {
+      hipLaunchKernelGGL(attn_dkdv_bf16_kernel<true>, gkv, blk, 0, st, p);
+      hipLaunchKernelGGL(attn_dq_bf16_kernel<true>, gq, blk, 0, st, p);
+    } else {
+      hipLaunchKernelGGL(attn_dkdv_bf16_kernel<false>, gkv, blk, 0, st, p);
+      hipLaunchKernelGGL(attn_dq_bf16_kernel<false>, gq, blk, 0, st, p);
+    }
+  } else {
+    hipLaunchKernelGGL(attn_delta_kernel<float>, gd, blk, 0, st, (const float*)out, (const float*)dout, delta, B, H, Lq, o_row_stride, o_batch_stride);
+    if (kv_idx) {
+      hipLaunchKernelGGL(attn_dkdv_f32_kernel<true>, gkv, blk, 0, st, p);
+      hipLaunchKernelGGL(attn_dq_f32_kernel<true>, gq, blk, 0, st, p);
+    } else {
+      hipLaunchKernelGGL(attn_dkdv_f32_kernel<false>, gkv, blk, 0, st, p);
+      hipLaunchKernelGGL(attn_dq_f32_kernel<false>, gq, blk, 0, st, p);
+    }
+  }
+  T2S_CHECK_LAUNCH("attn_bwd");
+  return 0;
+}

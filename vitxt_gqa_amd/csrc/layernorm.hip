@@ -1,0 +1,170 @@
+// residual-add + LayerNorm over rows of 768 (BertSelfOutput / BertOutput / BertLayerNorm of the
+// third-party BERT block; also pythia/models/t2s.py:87-88 (obj_feat_layer_norm), :116-117
+// (ocr_feat/ocr_bbox_layer_norm), :685-687 (PrevPredEmbeddings)).  Biased variance, eps inside sqrt.
+//
+// HBM-bound: one wavefront per row, 12 elements per lane as three 4-element vectors (8-B loads in
+// bf16, 16-B in fp32, lane-contiguous => 512 B / 1 KiB coalesced per instruction), statistics by
+// 64-lane shuffle reduction (two-pass mean / centred variance in registers: the row is read once).
+// Algorithmic bytes per row: fwd read x,res + write y,z = 4*768*sizeof(T); bwd read dy,z + write dz.
+#include "common.h"
+
+namespace {
+
+constexpr int H = T2S_HIDDEN;           // 768 = 64 lanes * 3 vectors * 4
+constexpr int ROWS_PER_BLOCK = 4;       // 4 waves per workgroup
+constexpr int BWD_MAX_PARTS = 2048;
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                T* __restrict__ y, T* z_out, float* __restrict__ stats,
+                                                                int64_t rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xp = x + row * H;
+  f32x4 v[3];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    v[i] = Vec4<T>::load(xp + e);
+    if (res) {
+      const f32x4 r = Vec4<T>::load(res + row * H + e);
+      v[i] += r;
+    }
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  if (z_out) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Vec4<T>::store(z_out + row * H + (i * 64 + lane) * 4, v[i]);
+  }
+  const float mean = wave_sum(s) * (1.f / H);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = v[i][j] - mean;
+      sq += d * d;
+    }
+  const float rstd = 1.f / sqrtf(wave_sum(sq) * (1.f / H) + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + e);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + e);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+    Vec4<T>::store(y + row * H + e, o);
+  }
+  if (stats && lane == 0) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
+}
+
+// Backward: dz = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)).  Each workgroup walks rows with a
+// grid stride and keeps per-lane partial sums of dgamma/dbeta (12 columns per lane) in registers; the
+// 4 waves are combined through LDS and written as one [768] partial row per workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                                const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                T* __restrict__ dz, float* __restrict__ dgamma_part,
+                                                                float* __restrict__ dbeta_part, int64_t rows) {
+  __shared__ float red[2][4][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 g[3], dg[3], db[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    g[i] = *reinterpret_cast<const f32x4*>(gamma + (i * 64 + lane) * 4);
+    dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    f32x4 d[3], xh[3];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      d[i] = Vec4<T>::load(dy + row * H + e);
+      const f32x4 zz = Vec4<T>::load(z + row * H + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[i][j] = (zz[j] - mean) * rstd;
+        dg[i][j] += d[i][j] * xh[i][j];
+        db[i][j] += d[i][j];
+        const float t = d[i][j] * g[i][j];
+        d[i][j] = t;
+        s1 += t;
+        s2 += t * xh[i][j];
+      }
+    }
+    s1 = wave_sum(s1) * (1.f / H);
+    s2 = wave_sum(s2) * (1.f / H);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = rstd * (d[i][j] - s1 - xh[i][j] * s2);
+      Vec4<T>::store(dz + row * H + (i * 64 + lane) * 4, o);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[0][wave][(i * 64 + lane) * 4 + j] = dg[i][j];
+      red[1][wave][(i * 64 + lane) * 4 + j] = db[i][j];
+    }
+  __syncthreads();
+  for (int cix = threadIdx.x; cix < H; cix += 256) {
+    dgamma_part[(int64_t)blockIdx.x * H + cix] = red[0][0][cix] + red[0][1][cix] + red[0][2][cix] + red[0][3][cix];
+    dbeta_part[(int64_t)blockIdx.x * H + cix] = red[1][0][cix] + red[1][1][cix] + red[1][2][cix] + red[1][3][cix];
+  }
+}
+
+int bwd_parts(int64_t rows) {
+  int64_t n = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return (int)(n < BWD_MAX_PARTS ? (n < 1 ? 1 : n) : BWD_MAX_PARTS);
+}
+
+}  // namespace
+
+extern "C" int t2s_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z_out,
+                                     float* stats, int64_t rows, float eps, int dtype, t2s_stream_t stream) {
+  T2S_CHECK_ARG(x && gamma && beta && y, "add_layernorm_fwd: null pointer");
+  T2S_CHECK_ARG(rows > 0 && rows < ((int64_t)1 << 33), "add_layernorm_fwd: bad rows %lld", (long long)rows);
+  T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "add_layernorm_fwd: bad dtype %d", dtype);
+  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == T2S_BF16)
+    hipLaunchKernelGGL(add_layernorm_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)res, gamma, beta,
+                       (bf16_t*)y, (bf16_t*)z_out, stats, rows, eps);
+  else
+    hipLaunchKernelGGL(add_layernorm_fwd_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)res, gamma, beta,
+                       (float*)y, (float*)z_out, stats, rows, eps);
+  T2S_CHECK_LAUNCH("add_layernorm_fwd");
+  return 0;
+}
+
+extern "C" int t2s_layernorm_bwd_parts(int64_t rows) { return bwd_parts(rows); }
+
+extern "C" int t2s_add_layernorm_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* dz,
+                                     float* dgamma_part, float* dbeta_part, int64_t rows, int dtype, t2s_stream_t stream) {
+  T2S_CHECK_ARG(dy && z && stats && gamma && dz && dgamma_part && dbeta_part, "add_layernorm_bwd: null pointer");
+  T2S_CHECK_ARG(rows > 0, "add_layernorm_bwd: bad rows");
+  T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "add_layernorm_bwd: bad dtype %d", dtype);
+  dim3 grid(bwd_parts(rows)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == T2S_BF16)
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)z, stats, gamma,
+                       (bf16_t*)dz, dgamma_part, dbeta_part, rows);
+  else
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel<float>, grid, block, 0, st, (const float*)dy, (const float*)z, stats, gamma,
+                       (float*)dz, dgamma_part, dbeta_part, rows);
+  T2S_CHECK_LAUNCH("add_layernorm_bwd");
+  return 0;
+}

@@ -1,0 +1,141 @@
+"""Thin tensor-level wrappers over the C ABI (no autograd here; see functional.py).
+
+Every function validates shapes on the host before launching (an out-of-bounds kernel can take the
+whole GPU node down) and raises RuntimeError with the library's message on failure.
+"""
+import math
+
+import torch
+
+from . import hipext as X
+
+HID = 768
+HEADS = 12
+HEAD_DIM = 64
+
+
+def _rows768(t):
+    assert t.is_contiguous() and t.shape[-1] == HID, "expected contiguous [..., 768], got %s" % (tuple(t.shape),)
+    return t.numel() // HID
+
+
+class KeyList:
+    """Compacted visible-key list of a batch (replaces the [B,1,L,L] additive mask, t2s.py:413-419,609-618)."""
+
+    def __init__(self, idx, cnt, n_dec, dec_q0, cap_hint=None):
+        self.idx, self.cnt, self.n_dec, self.dec_q0 = idx, cnt, n_dec, dec_q0
+        # static upper bound on (#valid prefix keys + n_dec): lets the dK/dV grid skip empty key blocks
+        self.cap_hint = cap_hint if cap_hint is not None else idx.shape[1]
+
+
+def compact_keys(valid, n_dec=0, dec_row0=0, cap_hint=None):
+    """valid: [B, L] bool/uint8 over the prefix rows -> KeyList."""
+    assert valid.dim() == 2
+    B, L = valid.shape
+    v8 = valid.to(torch.uint8).contiguous()
+    cap = L + n_dec
+    idx = torch.empty(B, cap, dtype=torch.int32, device=valid.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=valid.device)
+    X.check(X.lib().t2s_compact_keys(X.ptr(v8), X.ptr(idx), X.ptr(cnt), B, L, cap, n_dec, dec_row0, X.stream()),
+            "t2s_compact_keys")
+    if cap_hint is not None:
+        cap_hint = min(cap, cap_hint)
+    return KeyList(idx, cnt, n_dec, dec_row0, cap_hint)
+
+
+def _attn_views(qkv):
+    """qkv: [B, L, 2304] fused projection -> (q, k, v) views, row stride 2304."""
+    assert qkv.dim() == 3 and qkv.shape[-1] == 3 * HID and qkv.is_contiguous()
+    return qkv[..., :HID], qkv[..., HID:2 * HID], qkv[..., 2 * HID:]
+
+
+def attn_fwd(qkv, keys, scale=1.0 / 8.0):
+    """Self-attention over a fused QKV buffer [B, L, 2304].  Returns (ctx [B, L, 768], lse [B, 12, L])."""
+    B, L, _ = qkv.shape
+    q, k, v = _attn_views(qkv)
+    out = torch.empty(B, L, HID, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, HEADS, L, dtype=torch.float32, device=qkv.device)
+    _check_keys(keys, B, L)
+    X.check(X.lib().t2s_attn_fwd(
+        X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(lse), X.ptr(keys.idx), X.ptr(keys.cnt),
+        B, HEADS, L, keys.idx.shape[1], keys.n_dec, keys.dec_q0,
+        qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
+        scale, X.dtype_code(qkv), X.stream()), "t2s_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0):
+    """Returns dqkv [B, L, 2304] (rows of keys outside the key list get exact zeros in the K/V thirds)."""
+    B, L, _ = qkv.shape
+    q, k, v = _attn_views(qkv)
+    assert out.is_contiguous() and dout.is_contiguous() and out.shape == (B, L, HID) and dout.shape == (B, L, HID)
+    assert lse.shape == (B, HEADS, L) and lse.is_contiguous()
+    _check_keys(keys, B, L)
+    dqkv = torch.zeros_like(qkv)
+    dq, dk, dv = _attn_views(dqkv)
+    delta = torch.empty_like(lse)
+    cap = keys.idx.shape[1]
+    X.check(X.lib().t2s_attn_bwd(
+        X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(dout), X.ptr(lse), X.ptr(delta),
+        X.ptr(dq), X.ptr(dk), X.ptr(dv), X.ptr(keys.idx), X.ptr(keys.cnt),
+        B, HEADS, L, cap, keys.n_dec, keys.dec_q0, keys.cap_hint,
+        qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
+        scale, X.dtype_code(qkv), X.stream()), "t2s_attn_bwd")
+    return dqkv
+
+
+def _check_keys(keys, B, L):
+    assert keys.idx.dtype == torch.int32 and keys.cnt.dtype == torch.int32
+    assert keys.idx.shape[0] == B and keys.cnt.shape == (B,) and keys.idx.is_contiguous()
+    assert 0 < keys.cap_hint <= keys.idx.shape[1]
+    assert 0 <= keys.n_dec <= keys.idx.shape[1]
+    assert keys.dec_q0 + keys.n_dec <= L or keys.n_dec == 0, "decoder rows must lie inside the sequence"
+
+
+def add_layernorm_fwd(x, res, gamma, beta, eps=1e-12, save=True, inplace_z=True):
+    """y = LN(x + res).  Returns (y, z, stats): z = x + res kept for backward (written over x when
+    inplace_z), stats [rows, 2] = (mean, rstd).  res may be None."""
+    rows = _rows768(x)
+    if res is not None:
+        assert res.shape == x.shape and res.is_contiguous() and res.dtype == x.dtype
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == HID
+    y = torch.empty_like(x)
+    z = (x if inplace_z else torch.empty_like(x)) if save else None
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save else None
+    X.check(X.lib().t2s_add_layernorm_fwd(X.ptr(x), X.ptr(res), X.ptr(gamma), X.ptr(beta), X.ptr(y), X.ptr(z),
+                                          X.ptr(stats), rows, eps, X.dtype_code(x), X.stream()), "t2s_add_layernorm_fwd")
+    return y, z, stats
+
+
+def add_layernorm_bwd(dy, z, stats, gamma):
+    """Returns (dz, dgamma, dbeta)."""
+    rows = _rows768(dy)
+    assert z.shape == dy.shape and z.is_contiguous() and z.dtype == dy.dtype and stats.shape == (rows, 2)
+    parts = X.lib().t2s_layernorm_bwd_parts(rows)
+    dz = torch.empty_like(dy)
+    dgp = torch.empty(parts, HID, dtype=torch.float32, device=dy.device)
+    dbp = torch.empty(parts, HID, dtype=torch.float32, device=dy.device)
+    X.check(X.lib().t2s_add_layernorm_bwd(X.ptr(dy), X.ptr(z), X.ptr(stats), X.ptr(gamma), X.ptr(dz), X.ptr(dgp), X.ptr(dbp),
+                                          rows, X.dtype_code(dy), X.stream()), "t2s_add_layernorm_bwd")
+    return dz, dgp.sum(0), dbp.sum(0)
+
+
+def gelu_fwd(u):
+    assert u.is_contiguous() and u.numel() % 4 == 0
+    y = torch.empty_like(u)
+    X.check(X.lib().t2s_gelu_fwd(X.ptr(u), X.ptr(y), u.numel(), X.dtype_code(u), X.stream()), "t2s_gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy, u):
+    """Returns (du, dbias [cols] fp32)."""
+    assert dy.is_contiguous() and u.is_contiguous() and dy.shape == u.shape and dy.dtype == u.dtype
+    cols = u.shape[-1]
+    rows = u.numel() // cols
+    assert cols % 4 == 0
+    parts = X.lib().t2s_gelu_bwd_parts(rows)
+    du = torch.empty_like(u)
+    dbp = torch.empty(parts, cols, dtype=torch.float32, device=u.device)
+    X.check(X.lib().t2s_gelu_bwd(X.ptr(dy), X.ptr(u), X.ptr(du), X.ptr(dbp), rows, cols, X.dtype_code(u), X.stream()),
+            "t2s_gelu_bwd")
+    return du, dbp.sum(0)

@@ -1,0 +1,459 @@
+"""MI355X-native T2S model behind the reference's model-registry surface.
+
+Drop-in counterpart of ``pythia/models/t2s.py`` (``@registry.register_model("t2s") class T2S(BaseModel)``,
+:21-376): same constructor/config, ``build()``, ``forward(sample_list) -> dict`` with the 7 keys of
+:165-173, ``get_optimizer_parameters(config)`` (:356-376) and the same ``state_dict()`` key schema
+(SURVEY.md Appendix D), so checkpoints are interchangeable.  The arithmetic runs on the HIP kernels
+of libt2s_hip.so (attention, LayerNorm, GELU, ...) plus library GEMMs; there is no CPU path.
+
+Differences that are deliberate and documented:
+  * the [B,1,L,L] additive masks are replaced by compacted key lists (exact: exp(-10000+..) == 0 in fp32);
+  * top-k / sort ties are broken lowest-index-first (the reference's ATen order is implementation
+    defined, Appendix A Q9); ``sample_list.grounding_noise`` / ``sample_list.grounding_masks`` allow
+    the gumbel draws or the masks themselves to be injected for parity tests;
+  * dead parameters (Q14) are kept in the state_dict but frozen, so DDP needs no unused-parameter scan.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import functional as FN
+from . import ops
+from .base_model import BaseModel
+from .registry import registry
+from .schema import is_dead_param
+
+HID = 768
+LN_EPS = 1e-12
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders named exactly like the reference's module tree
+# ------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    pass
+
+
+class BertLayerParams(nn.Module):
+    def __init__(self, hidden=HID, ffn=4 * HID):
+        super().__init__()
+        self.attention = _Holder()
+        att_self = _Holder()
+        att_self.query = nn.Linear(hidden, hidden)
+        att_self.key = nn.Linear(hidden, hidden)
+        att_self.value = nn.Linear(hidden, hidden)
+        self.attention.add_module("self", att_self)
+        self.attention.output = _Holder()
+        self.attention.output.dense = nn.Linear(hidden, hidden)
+        self.attention.output.LayerNorm = nn.LayerNorm(hidden, eps=LN_EPS)
+        self.intermediate = _Holder()
+        self.intermediate.dense = nn.Linear(hidden, ffn)
+        self.output = _Holder()
+        self.output.dense = nn.Linear(ffn, hidden)
+        self.output.LayerNorm = nn.LayerNorm(hidden, eps=LN_EPS)
+
+
+class BertEncoderParams(nn.Module):
+    def __init__(self, num_layers):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayerParams() for _ in range(num_layers)])
+
+
+def _bert_init(module):
+    """BertPreTrainedModel.init_weights (Appendix A, Q3): N(0, 0.02), bias 0, LayerNorm (1, 0)."""
+    for m in module.modules():
+        if isinstance(m, (nn.Linear, nn.Embedding)):
+            m.weight.data.normal_(mean=0.0, std=0.02)
+        if isinstance(m, nn.LayerNorm):
+            m.bias.data.zero_()
+            m.weight.data.fill_(1.0)
+        if isinstance(m, nn.Linear) and m.bias is not None:
+            m.bias.data.zero_()
+
+
+class TextBert(nn.Module):
+    """t2s.py:521-545 (BertEmbeddings + 3-layer BertEncoder over L=20)."""
+
+    def __init__(self, config):
+        super().__init__()
+        vocab = config.get("vocab_size", 30522)
+        self.embeddings = _Holder()
+        self.embeddings.word_embeddings = nn.Embedding(vocab, HID)
+        self.embeddings.position_embeddings = nn.Embedding(512, HID)
+        self.embeddings.token_type_embeddings = nn.Embedding(2, HID)
+        self.embeddings.LayerNorm = nn.LayerNorm(HID, eps=LN_EPS)
+        self.encoder = BertEncoderParams(config.get("num_hidden_layers", 12))
+        _bert_init(self)
+
+    def forward(self, txt_inds, txt_mask, dtype):
+        e = self.embeddings
+        L = txt_inds.size(1)
+        x = (e.word_embeddings(txt_inds) + e.position_embeddings.weight[:L].unsqueeze(0)
+             + e.token_type_embeddings.weight[0]).to(dtype)
+        x = FN.layer_norm(x, e.LayerNorm.weight, e.LayerNorm.bias)
+        keys = ops.compact_keys(txt_mask > 0)
+        return FN.bert_encoder(x, keys, self.encoder.layer, dtype)
+
+
+class QTV(nn.Module):
+    """t2s.py:378-432."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.encoder = BertEncoderParams(config.get("num_hidden_layers", 12))
+        _bert_init(self)
+
+    def forward(self, fwd, dtype):
+        txt, obj, ocr = fwd["txt_emb"], fwd["obj_mmt_in"], fwd["ocr_mmt_in"]
+        x = torch.cat([txt, obj, ocr], dim=1)
+        valid = torch.cat([fwd["txt_mask"] > 0, fwd["obj_mask"] > 0, fwd["ocr_mask"] > 0], dim=1)
+        out = FN.bert_encoder(x, ops.compact_keys(valid), self.encoder.layer, dtype)
+        T, Fn = txt.size(1), obj.size(1)
+        fwd["txt_emb"] = txt + torch.tanh(out[:, :T])
+        fwd["obj_mmt_in"] = obj + torch.tanh(out[:, T:T + Fn])
+        fwd["ocr_mmt_in"] = ocr + torch.tanh(out[:, T + Fn:])
+
+
+class _AttentionScoreParams(nn.Module):
+    """AttentionScore (spatio_temporal_grounding.py:6-23): linear_q / linear_k exist but are unused."""
+
+    def __init__(self, hidden):
+        super().__init__()
+        self.linear_q = nn.Linear(hidden, hidden)
+        self.linear_k = nn.Linear(hidden, hidden)
+
+
+def attention_score(q, k, attn_mask):
+    """spatio_temporal_grounding.py:15-23 (Q7)."""
+    a = torch.bmm(q, k.transpose(-2, -1)).squeeze(1)
+    a = torch.softmax(a, dim=-1) * attn_mask
+    a = a / (a.sum(dim=-1, keepdim=True) + 1e-12)
+    return torch.where(attn_mask == 0, torch.full_like(a, -10000.0), a)
+
+
+def _gumbel_split(score, expo):
+    """2-way hard gumbel-softmax over identical pos/neg scores (Q8): argmax of noise, tie -> pos."""
+    g = -torch.log(expo)
+    pos = (g[:, 0] >= g[:, 1]).to(score.dtype)
+    # the reference adds the SAME score to both rows; in floating point (s+g0) >= (s+g1) can differ from
+    # g0 >= g1 only through rounding of the sum, so evaluate exactly what the reference evaluates:
+    y = torch.stack([score, score], dim=1) + g
+    pos = (y.argmax(dim=1) == 0).to(score.dtype)
+    return pos, 1.0 - pos
+
+
+def _topk_lowest_index(score, k, largest):
+    key = -score if largest else score
+    return torch.sort(key, dim=-1, stable=True).indices[..., :k]
+
+
+class Grounding_Module(nn.Module):
+    """t2s.py:434-518 + spatio_temporal_grounding.py (forward only: nothing here receives gradients)."""
+
+    def __init__(self, grounding_config, bert_config):
+        super().__init__()
+        g = grounding_config
+        self.frame_topk, self.ocr_topk = g.frame_topk, g.ocr_topk
+        self.frame_num, self.frame_ocr_num, self.hidden_size = g.frame_num, g.ocr_frame_num, g.hidden_size
+        h = self.hidden_size
+        self.q_linear = nn.Linear(h, h)
+        self.frame_attn = nn.Linear(h * 2, 1)
+        self.self_attn = nn.Linear(h, 1)
+        self.frame_grounding_indicator = _Holder()
+        self.frame_grounding_indicator.frame_pos_att = _AttentionScoreParams(h)
+        self.frame_grounding_indicator.frame_neg_att = _AttentionScoreParams(h)
+        self.ocr_grounding_indicator = _Holder()
+        self.ocr_grounding_indicator.ocr_pos_att = _AttentionScoreParams(h)
+        self.ocr_grounding_indicator.ocr_neg_att = _AttentionScoreParams(h)
+        self.encoder = BertEncoderParams(bert_config.get("num_hidden_layers", 12))     # dead (Q14)
+
+    @torch.no_grad()
+    def forward(self, sample_list, fwd):
+        ocr_feat, frame_feat = fwd["ocr_mmt_in"].float(), fwd["obj_mmt_in"].float()
+        frame_mask = fwd["obj_mask"].float()
+        q_feat, q_mask = fwd["txt_emb"].float(), fwd["txt_mask"].float()
+        B, N, _ = ocr_feat.shape
+        Fn = frame_feat.size(1)
+        noise = sample_list.get("grounding_noise", None)
+        if noise is None:
+            e1 = torch.empty(B, 2, Fn, device=ocr_feat.device).exponential_()
+            e2 = torch.empty(B, 2, N, device=ocr_feat.device).exponential_()
+        else:
+            e1, e2 = noise[0].to(ocr_feat.device).float(), noise[1].to(ocr_feat.device).float()
+
+        # question pooling, t2s.py:453-459,472-473 (Q6)
+        qp = F.linear(q_feat, self.q_linear.weight, self.q_linear.bias)
+        a = torch.softmax(F.linear(qp, self.self_attn.weight, self.self_attn.bias).squeeze(-1), dim=-1) * q_mask
+        a = a / (a.sum(1, keepdim=True) + 1e-12)
+        gq = torch.bmm(a.unsqueeze(1), qp)
+
+        # stage 1: temporal grounding (spatio_temporal_grounding.py:34-68)
+        f_score = attention_score(gq, frame_feat, frame_mask)
+        pos_m, neg_m = _gumbel_split(f_score, e1)
+        pos_m, neg_m = pos_m * frame_mask, neg_m * frame_mask
+        pos_s = torch.where(pos_m == 0, torch.full_like(f_score, -10000.0), f_score * pos_m)
+        neg_s = torch.where(neg_m == 0, torch.full_like(f_score, -10000.0), f_score * neg_m)
+        k = self.frame_topk
+        pos_top = torch.zeros_like(f_score).scatter_(1, _topk_lowest_index(pos_s, k, True), 1.0)
+        neg_top = torch.zeros_like(f_score).scatter_(1, _topk_lowest_index(neg_s, k, False), 1.0)
+        pos_f = torch.sort(torch.sort(pos_top, dim=1, descending=True, stable=True).indices[:, :k], dim=1).values
+        ground_frame = torch.gather(sample_list.frame_id, 1, pos_f)
+        ground_frame_mask, neg_frame_mask = pos_top * frame_mask, neg_top * frame_mask
+
+        # stage 2: spatial grounding (t2s.py:486-494, spatio_temporal_grounding.py:79-142)
+        gfix = torch.where(ground_frame == 0, torch.ones_like(ground_frame), ground_frame)
+        new_mask = torch.eq(sample_list.temporal_id.unsqueeze(1), gfix.unsqueeze(-1)).any(dim=1).float()
+        o_score = attention_score(gq, ocr_feat, new_mask)
+        opos_m, oneg_m = _gumbel_split(o_score, e2)
+        opos_m, oneg_m = opos_m * new_mask, oneg_m * new_mask
+        opos_s = torch.where(opos_m == 0, torch.full_like(o_score, -10000.0), o_score * opos_m)
+        oneg_s = torch.where(oneg_m == 0, torch.full_like(o_score, -10000.0), o_score * oneg_m)
+        P, ot = self.frame_ocr_num, self.ocr_topk
+        assert N == self.frame_num * P, "OCR slots must equal frame_num * ocr_frame_num"
+        opos_top = torch.zeros(B, self.frame_num, P, device=o_score.device).scatter_(
+            2, _topk_lowest_index(opos_s.view(B, self.frame_num, P), ot, True), 1.0).view(B, -1)
+        oneg_top = torch.zeros(B, self.frame_num, P, device=o_score.device).scatter_(
+            2, _topk_lowest_index(oneg_s.view(B, self.frame_num, P), ot, False), 1.0).view(B, -1) * new_mask
+        # ground_ocr_box = masked_select(bbox, pos mask) -> [B, frame_num*ocr_topk, 4]: ascending slot order
+        sel = torch.sort(torch.sort(opos_top, dim=1, descending=True, stable=True).indices[:, :self.frame_num * ot], dim=1).values
+        ground_box = torch.gather(sample_list.ocr_bbox_coordinates, 1, sel.unsqueeze(-1).expand(-1, -1, 4))
+
+        masks = dict(pos_obj_mask=ground_frame_mask, neg_obj_mask=neg_frame_mask,
+                     pos_ocr_mask=opos_top, neg_ocr_mask=oneg_top)
+        inject = sample_list.get("grounding_masks", None)
+        if inject is not None:
+            masks.update({k_: v.to(ocr_feat.device).float() for k_, v in inject.items() if k_ in masks})
+            if "ground_frame" in inject:
+                ground_frame = inject["ground_frame"].to(ocr_feat.device)
+            if "ground_box" in inject:
+                ground_box = inject["ground_box"].to(ocr_feat.device)
+        fwd["ground_frame"] = ground_frame
+        fwd["ground_bbox"] = ground_box
+        fwd["frame_topk"] = torch.tensor(self.frame_topk, device=frame_feat.device)
+        fwd["ocr_topk"] = torch.tensor(self.ocr_topk, device=ocr_feat.device)
+        fwd["frame_score"], fwd["ocr_score"], fwd["new_ocr_mask"], fwd["global_q"] = f_score, o_score, new_mask, gq
+        fwd.update(masks)
+        # features are NOT gated, only masks differ (t2s.py:510-518)
+        for p in ("pos", "neg"):
+            fwd[p + "_obj_mmt_in"] = fwd["obj_mmt_in"]
+            fwd[p + "_ocr_mmt_in"] = fwd["ocr_mmt_in"]
+
+
+class PrevPredEmbeddings(nn.Module):
+    """t2s.py:673-723."""
+
+    def __init__(self):
+        super().__init__()
+        self.position_embeddings = nn.Embedding(100, HID)
+        self.token_type_embeddings = nn.Embedding(5, HID)
+        self.ans_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
+        self.ocr_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
+        self.emb_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
+
+    def forward(self, ans_emb, ocr_emb, prev_inds, dtype):
+        # LayerNorm is row-wise, so LN(table)[gather] == LN(table[gather]): only the 12 gathered rows per
+        # sample are normalised instead of the whole [V, 768] table + [B, N, 768] OCR tensor (t2s.py:702-709).
+        B, D = prev_inds.shape
+        V = ans_emb.size(0)
+        is_ocr = prev_inds.ge(V)
+        ans_rows = ans_emb[prev_inds.clamp(max=V - 1)].to(dtype)                                  # [B, D, 768]
+        ocr_idx = (prev_inds - V).clamp(min=0)
+        ocr_rows = torch.gather(ocr_emb, 1, ocr_idx.unsqueeze(-1).expand(-1, -1, HID))
+        ans_n = FN.layer_norm(ans_rows, self.ans_layer_norm.weight, self.ans_layer_norm.bias)
+        ocr_n = FN.layer_norm(ocr_rows, self.ocr_layer_norm.weight, self.ocr_layer_norm.bias)
+        raw = torch.where(is_ocr.unsqueeze(-1), ocr_n, ans_n)
+        emb = (self.position_embeddings.weight[:D].unsqueeze(0) + self.token_type_embeddings(is_ocr.long())).to(dtype)
+        emb = FN.layer_norm(emb, self.emb_layer_norm.weight, self.emb_layer_norm.bias)
+        return raw + emb
+
+
+class MMT(nn.Module):
+    """t2s.py:548-633."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.prev_pred_embeddings = PrevPredEmbeddings()
+        self.encoder = BertEncoderParams(config.get("num_hidden_layers", 12))
+        _bert_init(self)
+
+    def forward(self, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, fixed_ans_emb, prev_inds, dtype,
+                max_keys=None):
+        dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype)
+        x = torch.cat([txt_emb, obj_emb, ocr_emb, dec_emb], dim=1)
+        T, Fn, N, D = txt_emb.size(1), obj_emb.size(1), ocr_emb.size(1), dec_emb.size(1)
+        L1 = T + Fn + N
+        valid = torch.cat([txt_mask > 0, obj_mask > 0, ocr_mask > 0], dim=1)
+        # decoder keys: step j visible to decoder row i iff i >= j; prefix rows never see them (t2s.py:574-618)
+        keys = ops.compact_keys(valid, n_dec=D, dec_row0=L1, cap_hint=max_keys)
+        out = FN.bert_encoder(x, keys, self.encoder.layer, dtype)
+        return out[:, T + Fn:L1], out[:, L1:]
+
+
+class OcrPtrNet(nn.Module):
+    """t2s.py:636-670 (Q12: the RAW 0/1 mask is added to the scores)."""
+
+    def __init__(self, hidden_size, query_key_size=None):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.query_key_size = query_key_size or hidden_size
+        self.query = nn.Linear(hidden_size, self.query_key_size)
+        self.key = nn.Linear(hidden_size, self.query_key_size)
+
+    def forward(self, query_inputs, key_inputs, attention_mask, dtype):
+        assert attention_mask.dim() == 2
+        q = F.linear(query_inputs, self.query.weight.to(dtype), self.query.bias.to(dtype))
+        k = F.linear(key_inputs, self.key.weight.to(dtype), self.key.bias.to(dtype))
+        scores = torch.matmul(q, k.transpose(-1, -2)).float() / math.sqrt(self.query_key_size)
+        return scores + attention_mask.float().unsqueeze(1)
+
+
+class _Classifier(nn.Module):
+    """ClassifierLayer(type="linear") = nn.Linear(768, V) under ``.module`` (layers.py:91-108)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.module = nn.Linear(in_dim, out_dim)
+
+
+# ------------------------------------------------------------------------------------------------
+@registry.register_model("t2s")
+class T2S(BaseModel):
+    def __init__(self, config):
+        super().__init__(config)
+        self.compute_dtype = torch.bfloat16
+        cfgreg = registry.get("config")
+        self._datasets = (cfgreg["datasets"] if cfgreg is not None and "datasets" in cfgreg else "vtextgqa").split(",")
+
+    # -- construction (t2s.py:31-151) -------------------------------------------------------------
+    def build(self):
+        c = self.config
+        self.finetune_modules = []
+        self.text_bert = TextBert(c.text_bert)
+        if c.get("text_bert_init_from_bert_base", False):
+            # the reference loads ../../huggingface/bert-base-uncased (t2s.py:47-56): load those three layers
+            # through load_state_dict; the smaller learning rate is kept
+            self.finetune_modules.append({"module": self.text_bert, "lr_scale": c.lr_scale_text_bert})
+        self.text_bert_out_linear = nn.Identity()
+        self.frame_embeddings = nn.Embedding(4000, 50)
+        self.linear_obj_feat_to_mmt_in = nn.Linear(c.obj.mmt_in_dim, HID)
+        self.obj_feat_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
+        self.obj_frame_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
+        self.linear_obj_frame_to_mmt_in = nn.Linear(50, HID)
+        self.obj_drop_p = c.obj.dropout_prob
+        self.linear_ocr_feat_to_mmt_in = nn.Linear(c.ocr.mmt_in_dim, HID)
+        self.linear_ocr_bbox_to_mmt_in = nn.Linear(4, HID)
+        self.temporal_position_embeddings = nn.Embedding(4000, 50)
+        self.track_position_embeddings = nn.Embedding(4000, 50)
+        self.ocr_feat_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
+        self.ocr_bbox_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
+        self.ocr_drop_p = c.ocr.dropout_prob
+        self.TransLayer = QTV(c.translayers)
+        self.Grounding_Module = Grounding_Module(c.grounding, c.encoder)
+        self.mmt = MMT(c.mmt)
+        self.finetune_modules.append({"module": self.mmt, "lr_scale": c.lr_scale_mmt})
+        self.ocr_ptr_net = OcrPtrNet(**c.classifier.ocr_ptr_net)
+        num_choices = registry.get(self._datasets[0] + "_num_final_outputs")
+        if num_choices is None:
+            raise RuntimeError("registry key '%s_num_final_outputs' is not set (t2s.py:138)" % self._datasets[0])
+        num_choices -= c.classifier.ocr_max_num
+        self.classifier = _Classifier(HID, num_choices)
+        self.answer_processor = registry.get(self._datasets[0] + "_answer_processor")
+        for n, p in self.named_parameters():
+            if is_dead_param(n):
+                p.requires_grad_(False)
+        return self
+
+    def set_compute_dtype(self, dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    # -- forward (t2s.py:153-354) ------------------------------------------------------------------
+    def forward(self, sample_list):
+        dt = self.compute_dtype
+        fwd = {}
+        self._forward_txt_encoding(sample_list, fwd, dt)
+        self._forward_obj_encoding(sample_list, fwd, dt)
+        self._forward_ocr_encoding(sample_list, fwd, dt)
+        self.TransLayer(fwd, dt)
+        self.Grounding_Module(sample_list, fwd)
+        self._forward_mmt_and_output(sample_list, fwd, dt)
+        self._last_fwd = fwd
+        return {"ref_scores": fwd["ref_scores"], "pos_scores": fwd["pos_scores"], "neg_scores": fwd["neg_scores"],
+                "ground_box": fwd["ground_bbox"], "ground_frame": fwd["ground_frame"],
+                "frame_topk": fwd["frame_topk"], "ocr_topk": fwd["ocr_topk"]}
+
+    def _drop(self, x, p):
+        return F.dropout(x, p, self.training) if (self.training and p > 0) else x
+
+    def _forward_txt_encoding(self, s, fwd, dt):
+        T = s.text.size(1)
+        fwd["txt_mask"] = (torch.arange(T, device=s.text.device).unsqueeze(0) < s.text_len.unsqueeze(-1)).float()
+        fwd["txt_emb"] = self.text_bert(s.text, fwd["txt_mask"], dt)
+
+    def _forward_obj_encoding(self, s, fwd, dt):
+        assert s.video_feat.size(-1) == 1024
+        x = torch.cat([F.normalize(s.video_feat.float(), dim=-1), self.frame_embeddings(s.frame_id)], dim=-1).to(dt)
+        y = F.linear(x, self.linear_obj_feat_to_mmt_in.weight.to(dt), self.linear_obj_feat_to_mmt_in.bias.to(dt))
+        y = FN.layer_norm(y, self.obj_feat_layer_norm.weight, self.obj_feat_layer_norm.bias)
+        fwd["obj_mmt_in"] = self._drop(y, self.obj_drop_p)
+        fwd["obj_mask"] = s.frame_mask
+
+    def _forward_ocr_encoding(self, s, fwd, dt):
+        assert s.context_feature_0.size(-1) == 300 and s.context_feature_1.size(-1) == 604
+        x = torch.cat([F.normalize(s.context_feature_0.float(), dim=-1), F.normalize(s.context_feature_1.float(), dim=-1),
+                       self.temporal_position_embeddings(s.temporal_id), self.track_position_embeddings(s.track_id)],
+                      dim=-1).to(dt)
+        a = F.linear(x, self.linear_ocr_feat_to_mmt_in.weight.to(dt), self.linear_ocr_feat_to_mmt_in.bias.to(dt))
+        a = FN.layer_norm(a, self.ocr_feat_layer_norm.weight, self.ocr_feat_layer_norm.bias)
+        b = F.linear(s.ocr_bbox_coordinates.to(dt), self.linear_ocr_bbox_to_mmt_in.weight.to(dt),
+                     self.linear_ocr_bbox_to_mmt_in.bias.to(dt))
+        b = FN.layer_norm(b, self.ocr_bbox_layer_norm.weight, self.ocr_bbox_layer_norm.bias)
+        fwd["ocr_mmt_in"] = self._drop(a + b, self.ocr_drop_p)
+        fwd["ocr_mask"] = s.ocr_mask
+
+    def _forward_output(self, ocr_out, dec_out, mask, dt):
+        fixed = F.linear(dec_out, self.classifier.module.weight.to(dt), self.classifier.module.bias.to(dt)).float()
+        return torch.cat([fixed, self.ocr_ptr_net(dec_out, ocr_out, mask, dt)], dim=-1)
+
+    def _three_pass(self, fwd, prev_inds, dt):
+        g = self.Grounding_Module
+        T, Fn, N = fwd["txt_emb"].size(1), fwd["obj_mmt_in"].size(1), fwd["ocr_mmt_in"].size(1)
+        D = prev_inds.size(1)
+        # static bounds on the number of visible keys of the pos / neg passes (Q10)
+        bounds = {"ref": None,
+                  "pos": T + g.frame_topk + g.ocr_topk * g.frame_num + D,
+                  "neg": T + g.frame_topk + g.ocr_topk * g.frame_topk + D}
+        for name, om, cm in (("ref", fwd["obj_mask"], fwd["ocr_mask"]),
+                             ("pos", fwd["pos_obj_mask"], fwd["pos_ocr_mask"]),
+                             ("neg", fwd["neg_obj_mask"], fwd["neg_ocr_mask"])):
+            ocr_out, dec_out = self.mmt(fwd["txt_emb"], fwd["txt_mask"], fwd["obj_mmt_in"], om, fwd["ocr_mmt_in"], cm,
+                                        self.classifier.module.weight, prev_inds, dt, max_keys=bounds[name])
+            fwd[name + "_scores"] = self._forward_output(ocr_out, dec_out, cm, dt)
+
+    def _forward_mmt_and_output(self, s, fwd, dt):
+        if self.training:
+            fwd["prev_inds"] = s.train_prev_inds.clone()
+            self._three_pass(fwd, fwd["prev_inds"], dt)
+        else:
+            D = s.train_prev_inds.size(1)
+            fwd["prev_inds"] = torch.zeros_like(s.train_prev_inds)
+            fwd["prev_inds"][:, 0] = self.answer_processor.BOS_IDX
+            for _ in range(D):
+                self._three_pass(fwd, fwd["prev_inds"], dt)
+                fwd["prev_inds"][:, 1:] = fwd["pos_scores"].argmax(dim=-1)[:, :-1]
+
+    # -- optimizer hook (t2s.py:356-376) -------------------------------------------------------------
+    def get_optimizer_parameters(self, config):
+        groups = []
+        base_lr = config.optimizer_attributes.params.lr
+        finetune = set()
+        for m in self.finetune_modules:
+            ps = [p for p in m["module"].parameters() if p.requires_grad]
+            groups.append({"params": ps, "lr": base_lr * m["lr_scale"]})
+            finetune.update(ps)
+        remaining = [p for p in self.parameters() if p.requires_grad and p not in finetune]
+        groups.insert(0, {"params": remaining})
+        return groups
