@@ -82,18 +82,23 @@ int t2s_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
 
 /* ---- residual + LayerNorm (BertSelfOutput / BertOutput / BertLayerNorm; also
  * t2s.py:87-88,116-117,685-687): z = x + res (res may be NULL); y = (z-mean)/sqrt(var+eps)*g+b,
- * biased variance, eps inside the sqrt.  rows x 768.  z_out (may alias x, may be NULL) keeps
- * the pre-norm sum for backward; stats: [rows, 2] fp32 (mean, rstd), may be NULL. */
+ * biased variance, eps inside the sqrt.  rows x 768.
+ * x has x_dtype (a GEMM output); res, y, z_out have stream_dtype (the residual stream: fp32 in
+ * both compute modes, so bf16 rounding never touches the running hidden state).  y_lo (may be
+ * NULL) receives a bf16 copy of y for the next GEMM; y may be NULL when only y_lo is wanted.  z_out (may be NULL; may alias x when the
+ * two dtypes are equal) keeps the pre-norm sum for backward; stats: [rows, 2] fp32 (mean, rstd),
+ * may be NULL.  Supported (x, stream): (f32,f32), (bf16,f32), (bf16,bf16). */
 int t2s_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
-                          void* y, void* z_out, float* stats, int64_t rows, float eps, int dtype,
-                          t2s_stream_t stream);
+                          void* y, void* y_lo, void* z_out, float* stats, int64_t rows, float eps,
+                          int x_dtype, int stream_dtype, t2s_stream_t stream);
 
 /* dz = LN backward wrt z (= grad of both x and res); dgamma_part/dbeta_part: [n_part, 768] fp32
- * partial sums (n_part = t2s_layernorm_bwd_parts(rows)); the caller reduces over dim 0. */
+ * partial sums (n_part = t2s_layernorm_bwd_parts(rows)); the caller reduces over dim 0.
+ * Supported (dy, z, dz) dtypes: (f32,f32,f32), (f32,f32,bf16), (bf16,f32,bf16), (bf16,bf16,bf16). */
 int t2s_layernorm_bwd_parts(int64_t rows);
 int t2s_add_layernorm_bwd(const void* dy, const void* z, const float* stats, const float* gamma,
-                          void* dz, float* dgamma_part, float* dbeta_part, int64_t rows, int dtype,
-                          t2s_stream_t stream);
+                          void* dz, float* dgamma_part, float* dbeta_part, int64_t rows,
+                          int dy_dtype, int z_dtype, int dz_dtype, t2s_stream_t stream);
 
 /* ---- GELU (erf form) of BertIntermediate: y = gelu(u); backward du = dy * gelu'(u) with
  * per-column partial sums of du (bias gradient): dbias_part [n_part, cols] fp32,

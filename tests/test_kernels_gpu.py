@@ -103,34 +103,48 @@ def test_attention_spiky_rows_force_rescale():
         assert (out.double() - ref).abs().max().item() < tol
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("xdt,sdt,tol", [(torch.float32, torch.float32, 2e-5), (torch.bfloat16, torch.float32, 2e-5),
+                                         (torch.bfloat16, torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("rows", [1, 7, 1000])
-def test_add_layernorm(rows, dtype, tol):
+def test_add_layernorm(rows, xdt, sdt, tol):
+    """x: GEMM-output dtype, residual stream (res / y / z) dtype sdt; checks y, y_lo, z, stats and backward."""
     _need_gpu()
     from vitxt_gqa_amd import ops
     g = torch.Generator().manual_seed(rows)
-    x = torch.randn(rows, 768, generator=g).to(DEV).to(dtype)
-    r = torch.randn(rows, 768, generator=g).to(DEV).to(dtype)
+    x = torch.randn(rows, 768, generator=g).to(DEV).to(xdt)
+    r = torch.randn(rows, 768, generator=g).to(DEV).to(sdt)
     gam = (1 + 0.1 * torch.randn(768, generator=g)).to(DEV)
     bet = (0.1 * torch.randn(768, generator=g)).to(DEV)
-    dy = torch.randn(rows, 768, generator=g).to(DEV).to(dtype)
+    dy = torch.randn(rows, 768, generator=g).to(DEV)
     xr, rr = x.double().requires_grad_(True), r.double().requires_grad_(True)
     gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
     z = xr + rr
     ref = (z - z.mean(-1, keepdim=True)) / torch.sqrt(z.var(-1, unbiased=False, keepdim=True) + 1e-12) * gr + br
-    y, zz, st = ops.add_layernorm_fwd(x.clone(), r, gam, bet, inplace_z=False)
+    y, y_lo, zz, st = ops.add_layernorm_fwd(x.clone(), r, gam, bet, inplace_z=False, stream_dtype=sdt, want_lo=True)
+    assert y.dtype == sdt and zz.dtype == sdt and y_lo.dtype == torch.bfloat16
     assert (y.double() - ref).abs().max().item() < tol
+    assert (y_lo.double() - ref).abs().max().item() < 2e-2
     assert (zz.double() - z).abs().max().item() < tol
-    dz, dg, db = ops.add_layernorm_bwd(dy, zz, st, gam)
-    gx, gg, gb = torch.autograd.grad(ref, (xr, gr, br), dy.double())
-    assert (dz.double() - gx).abs().max().item() < tol * 5
-    assert (dg.double() - gg).abs().max().item() < tol * 5 * math.sqrt(rows)
-    assert (db.double() - gb).abs().max().item() < tol * 5 * math.sqrt(rows)
-    # without residual, in place
-    y2, z2, _ = ops.add_layernorm_fwd(x.clone(), None, gam, bet)
+    assert (st[:, 0].double() - z.mean(-1)).abs().max().item() < 1e-5
+    for ddt, odt in ((torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)):
+        if sdt == torch.bfloat16 and not (ddt == torch.bfloat16 and odt == torch.bfloat16):
+            continue
+        if sdt == torch.float32 and ddt == torch.bfloat16 and odt == torch.float32:
+            continue
+        d = dy.to(ddt)
+        dz, dg, db = ops.add_layernorm_bwd(d, zz, st, gam, out_dtype=odt)
+        gx, gg, gb = torch.autograd.grad(ref, (xr, gr, br), d.double(), retain_graph=True)
+        t2 = tol if odt == torch.float32 else 2e-2
+        assert (dz.double() - gx).abs().max().item() < t2 * 5
+        assert (dg.double() - gg).abs().max().item() < max(tol, 1e-4) * 5 * math.sqrt(rows)
+        assert (db.double() - gb).abs().max().item() < max(tol, 1e-4) * 5 * math.sqrt(rows)
+    # without residual; in place when dtypes match; y_lo only
+    y2, _, z2, _ = ops.add_layernorm_fwd(x.clone(), None, gam, bet, stream_dtype=sdt)
     zr = x.double()
     ref2 = (zr - zr.mean(-1, keepdim=True)) / torch.sqrt(zr.var(-1, unbiased=False, keepdim=True) + 1e-12) * gam.double() + bet.double()
     assert (y2.double() - ref2).abs().max().item() < tol
+    y3, y3_lo, _, _ = ops.add_layernorm_fwd(x.clone(), None, gam, bet, save=False, stream_dtype=sdt, want_lo=True, want_y=False)
+    assert y3 is None and (y3_lo.double() - ref2).abs().max().item() < 2e-2
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
@@ -179,17 +193,18 @@ def test_bert_layer_fn(dtype, tol):
     grads = torch.autograd.grad(ref, [xr] + [sd[n] for n in names], dy.to(dtype).double())
     # HIP path
     lp = lp.to(DEV)
-    xg = x.to(DEV).to(dtype).requires_grad_(True)
+    xg = x.to(DEV).to(dtype).float().requires_grad_(True)        # fp32 residual stream holding operand-exact values
     keys = ops.compact_keys(valid.to(DEV), n_dec=n_dec, dec_row0=L1)
-    y = FN.bert_layer(xg, keys, lp, dtype)
+    y, y_lo = FN.bert_layer(xg, None, keys, lp, dtype)
+    assert y.dtype == torch.float32 and y_lo.dtype == dtype
     assert (y.double().cpu() - ref).abs().max().item() < tol
-    y.backward(dy.to(DEV).to(dtype))
+    y.backward(dy.to(DEV).to(dtype).float())
     assert (xg.grad.double().cpu() - grads[0]).abs().max().item() < tol * max(1.0, grads[0].abs().max().item()) * 4
     got = dict(lp.named_parameters())
     for n, gr in zip(names, grads[1:]):
         a = got[n[2:]].grad.double().cpu()
         rel = (a - gr).norm().item() / max(gr.norm().item(), 1e-6 * gr.numel() ** 0.5)
-        if "key.bias" in n:        # mathematically zero gradient
-            assert a.abs().max().item() < 1e-2
+        if "key.bias" in n:        # mathematically zero gradient: only rounding noise of the dK column sums
+            assert a.abs().max().item() < (1e-3 if dtype == torch.float32 else 0.5)
             continue
         assert rel < (2e-4 if dtype == torch.float32 else 4e-2), "%s rel err %.3e" % (n, rel)

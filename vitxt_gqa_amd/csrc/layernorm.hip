@@ -2,10 +2,15 @@
 // third-party BERT block; also pythia/models/t2s.py:87-88 (obj_feat_layer_norm), :116-117
 // (ocr_feat/ocr_bbox_layer_norm), :685-687 (PrevPredEmbeddings)).  Biased variance, eps inside sqrt.
 //
+// Mixed precision: the branch input x (a GEMM output) and the residual stream (res, y, z) have
+// separate storage types.  In the bf16 compute mode the residual stream stays fp32 (x: bf16,
+// res/y/z: fp32) and a second bf16 copy of y (y_lo) is emitted for the next GEMM, so rounding to
+// bf16 happens only at GEMM/attention operands, never on the running hidden state.
+//
 // HBM-bound: one wavefront per row, 12 elements per lane as three 4-element vectors (8-B loads in
 // bf16, 16-B in fp32, lane-contiguous => 512 B / 1 KiB coalesced per instruction), statistics by
 // 64-lane shuffle reduction (two-pass mean / centred variance in registers: the row is read once).
-// Algorithmic bytes per row: fwd read x,res + write y,z = 4*768*sizeof(T); bwd read dy,z + write dz.
+// Algorithmic bytes per row: fwd = 768 * (read x, res + write y, z [+ y_lo]); bwd = 768 * (dy + z + dz).
 #include "common.h"
 
 namespace {
@@ -14,30 +19,29 @@ constexpr int H = T2S_HIDDEN;           // 768 = 64 lanes * 3 vectors * 4
 constexpr int ROWS_PER_BLOCK = 4;       // 4 waves per workgroup
 constexpr int BWD_MAX_PARTS = 2048;
 
-template <typename T>
-__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+template <typename TX, typename TS>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const TX* __restrict__ x, const TS* __restrict__ res,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                T* __restrict__ y, T* z_out, float* __restrict__ stats,
-                                                                int64_t rows, float eps) {
+                                                                TS* __restrict__ y, bf16_t* __restrict__ y_lo, TS* z_out,
+                                                                float* __restrict__ stats, int64_t rows, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const T* xp = x + row * H;
   f32x4 v[3];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int e = (i * 64 + lane) * 4;
-    v[i] = Vec4<T>::load(xp + e);
+    v[i] = Vec4<TX>::load(x + row * H + e);
     if (res) {
-      const f32x4 r = Vec4<T>::load(res + row * H + e);
+      const f32x4 r = Vec4<TS>::load(res + row * H + e);
       v[i] += r;
     }
     s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
   }
   if (z_out) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) Vec4<T>::store(z_out + row * H + (i * 64 + lane) * 4, v[i]);
+    for (int i = 0; i < 3; ++i) Vec4<TS>::store(z_out + row * H + (i * 64 + lane) * 4, v[i]);
   }
   const float mean = wave_sum(s) * (1.f / H);
   float sq = 0.f;
@@ -57,7 +61,8 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T* __restr
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-    Vec4<T>::store(y + row * H + e, o);
+    if (y) Vec4<TS>::store(y + row * H + e, o);
+    if (y_lo) Vec4<bf16_t>::store(y_lo + row * H + e, o);
   }
   if (stats && lane == 0) {
     stats[row * 2] = mean;
@@ -68,10 +73,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T* __restr
 // Backward: dz = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)).  Each workgroup walks rows with a
 // grid stride and keeps per-lane partial sums of dgamma/dbeta (12 columns per lane) in registers; the
 // 4 waves are combined through LDS and written as one [768] partial row per workgroup.
-template <typename T>
-__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+template <typename TDY, typename TZ, typename TDZ>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const TDY* __restrict__ dy, const TZ* __restrict__ z,
                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                                T* __restrict__ dz, float* __restrict__ dgamma_part,
+                                                                TDZ* __restrict__ dz, float* __restrict__ dgamma_part,
                                                                 float* __restrict__ dbeta_part, int64_t rows) {
   __shared__ float red[2][4][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -89,8 +94,8 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T* __restr
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int e = (i * 64 + lane) * 4;
-      d[i] = Vec4<T>::load(dy + row * H + e);
-      const f32x4 zz = Vec4<T>::load(z + row * H + e);
+      d[i] = Vec4<TDY>::load(dy + row * H + e);
+      const f32x4 zz = Vec4<TZ>::load(z + row * H + e);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         xh[i][j] = (zz[j] - mean) * rstd;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T* __restr
       f32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = rstd * (d[i][j] - s1 - xh[i][j] * s2);
-      Vec4<T>::store(dz + row * H + (i * 64 + lane) * 4, o);
+      Vec4<TDZ>::store(dz + row * H + (i * 64 + lane) * 4, o);
     }
   }
 #pragma unroll
@@ -131,21 +136,28 @@ int bwd_parts(int64_t rows) {
   return (int)(n < BWD_MAX_PARTS ? (n < 1 ? 1 : n) : BWD_MAX_PARTS);
 }
 
+bool is_dt(int d) { return d == T2S_F32 || d == T2S_BF16; }
+
 }  // namespace
 
-extern "C" int t2s_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* z_out,
-                                     float* stats, int64_t rows, float eps, int dtype, t2s_stream_t stream) {
-  T2S_CHECK_ARG(x && gamma && beta && y, "add_layernorm_fwd: null pointer");
+extern "C" int t2s_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* y_lo,
+                                     void* z_out, float* stats, int64_t rows, float eps, int x_dtype, int stream_dtype,
+                                     t2s_stream_t stream) {
+  T2S_CHECK_ARG(x && gamma && beta && (y || y_lo), "add_layernorm_fwd: null pointer");
   T2S_CHECK_ARG(rows > 0 && rows < ((int64_t)1 << 33), "add_layernorm_fwd: bad rows %lld", (long long)rows);
-  T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "add_layernorm_fwd: bad dtype %d", dtype);
+  T2S_CHECK_ARG(is_dt(x_dtype) && is_dt(stream_dtype), "add_layernorm_fwd: bad dtype %d/%d", x_dtype, stream_dtype);
+  T2S_CHECK_ARG(!(x_dtype == T2S_F32 && stream_dtype == T2S_BF16), "add_layernorm_fwd: fp32 branch with bf16 stream is not supported");
   dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == T2S_BF16)
-    hipLaunchKernelGGL(add_layernorm_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)res, gamma, beta,
-                       (bf16_t*)y, (bf16_t*)z_out, stats, rows, eps);
+  if (x_dtype == T2S_BF16 && stream_dtype == T2S_BF16)
+    hipLaunchKernelGGL((add_layernorm_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)res, gamma, beta,
+                       (bf16_t*)y, (bf16_t*)y_lo, (bf16_t*)z_out, stats, rows, eps);
+  else if (x_dtype == T2S_BF16)
+    hipLaunchKernelGGL((add_layernorm_fwd_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)x, (const float*)res, gamma, beta,
+                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps);
   else
-    hipLaunchKernelGGL(add_layernorm_fwd_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)res, gamma, beta,
-                       (float*)y, (float*)z_out, stats, rows, eps);
+    hipLaunchKernelGGL((add_layernorm_fwd_kernel<float, float>), grid, block, 0, st, (const float*)x, (const float*)res, gamma, beta,
+                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps);
   T2S_CHECK_LAUNCH("add_layernorm_fwd");
   return 0;
 }
@@ -153,18 +165,27 @@ extern "C" int t2s_add_layernorm_fwd(const void* x, const void* res, const float
 extern "C" int t2s_layernorm_bwd_parts(int64_t rows) { return bwd_parts(rows); }
 
 extern "C" int t2s_add_layernorm_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* dz,
-                                     float* dgamma_part, float* dbeta_part, int64_t rows, int dtype, t2s_stream_t stream) {
+                                     float* dgamma_part, float* dbeta_part, int64_t rows, int dy_dtype, int z_dtype, int dz_dtype,
+                                     t2s_stream_t stream) {
   T2S_CHECK_ARG(dy && z && stats && gamma && dz && dgamma_part && dbeta_part, "add_layernorm_bwd: null pointer");
   T2S_CHECK_ARG(rows > 0, "add_layernorm_bwd: bad rows");
-  T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "add_layernorm_bwd: bad dtype %d", dtype);
+  T2S_CHECK_ARG(is_dt(dy_dtype) && is_dt(z_dtype) && is_dt(dz_dtype), "add_layernorm_bwd: bad dtype");
   dim3 grid(bwd_parts(rows)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == T2S_BF16)
-    hipLaunchKernelGGL(add_layernorm_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)z, stats, gamma,
-                       (bf16_t*)dz, dgamma_part, dbeta_part, rows);
-  else
-    hipLaunchKernelGGL(add_layernorm_bwd_kernel<float>, grid, block, 0, st, (const float*)dy, (const float*)z, stats, gamma,
-                       (float*)dz, dgamma_part, dbeta_part, rows);
+  const int combo = dy_dtype * 4 + z_dtype * 2 + dz_dtype;
+#define LN_BWD(TDY, TZ, TDZ)                                                                                                   \
+  hipLaunchKernelGGL((add_layernorm_bwd_kernel<TDY, TZ, TDZ>), grid, block, 0, st, (const TDY*)dy, (const TZ*)z, stats, gamma, \
+                     (TDZ*)dz, dgamma_part, dbeta_part, rows)
+  switch (combo) {
+    case 0: LN_BWD(float, float, float); break;
+    case 1: LN_BWD(float, float, bf16_t); break;
+    case 5: LN_BWD(bf16_t, float, bf16_t); break;
+    case 7: LN_BWD(bf16_t, bf16_t, bf16_t); break;
+    default:
+      t2s_set_error("add_layernorm_bwd: unsupported dtype combination dy=%d z=%d dz=%d", dy_dtype, z_dtype, dz_dtype);
+      return 1;
+  }
+#undef LN_BWD
   T2S_CHECK_LAUNCH("add_layernorm_bwd");
   return 0;
 }

@@ -1,16 +1,23 @@
 """Autograd functions of the T2S hot path, built on the HIP kernels (ops.py) plus library GEMMs.
 
+Precision policy.  ``dtype`` is the GEMM / attention OPERAND type (bf16 for throughput, fp32 for the
+parity mode).  The residual stream (layer inputs/outputs, pre-LayerNorm sums) is always fp32: the
+LayerNorm kernel reads the bf16 GEMM output plus the fp32 residual and emits the fp32 stream value
+together with a bf16 copy for the next GEMM.  bf16 rounding therefore only ever touches matmul
+operands, which is what keeps bf16 logits within 1e-2 of the fp32 reference after 8 layers.
+
 One fused ``torch.autograd.Function`` per BERT layer (third-party BertLayer used by TextBert / QTV /
 MMT, call sites pythia/models/t2s.py:423-427,538-542,622-626) with a hand-written backward, so that
-only the tensors a flash-style backward needs are kept: layer input, fused QKV, attention output,
-log-sum-exp, the two pre-LayerNorm sums (+ statistics) and the FFN pre-activation.  LayerNorm outputs
-and GELU outputs are recomputed in backward (HBM-cheap) instead of stored.
+only what a flash-style backward needs is kept: the operand copy of the layer input, fused QKV,
+attention output, log-sum-exp, the two pre-LayerNorm sums (+ statistics) and the FFN pre-activation.
+LayerNorm outputs and GELU outputs are recomputed in backward (HBM-cheap) instead of stored.
 """
 import torch
 
 from . import ops
 
 HID = ops.HID
+F32 = torch.float32
 
 
 def _mm_bias(x2, w, b):
@@ -19,34 +26,44 @@ def _mm_bias(x2, w, b):
 
 
 class BertLayerFn(torch.autograd.Function):
-    """y = BertLayer(x; keys).  Weights arrive already in the compute dtype (bf16 or fp32); LayerNorm
-    affine parameters stay fp32."""
+    """(y, y_lo) = BertLayer(x; keys).  x / y: fp32 residual stream; x_lo / y_lo: operand-dtype copies
+    (y_lo is y itself in fp32 mode).  Weights arrive in the operand dtype; LayerNorm affine stays fp32."""
 
     @staticmethod
-    def forward(ctx, x, keys, w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2):
+    def forward(ctx, x, x_lo, keys, w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2):
         B, L, _ = x.shape
-        x2 = x.reshape(B * L, HID)
-        qkv = _mm_bias(x2, w_qkv, b_qkv).view(B, L, 3 * HID)
+        dt = w_qkv.dtype
+        lo = dt != F32
+        x2 = x.contiguous().view(B * L, HID)
+        xl = (x_lo if x_lo is not None else x.to(dt)).contiguous().view(B * L, HID)
+        qkv = _mm_bias(xl, w_qkv, b_qkv).view(B, L, 3 * HID)
         att, lse = ops.attn_fwd(qkv, keys)
         a = _mm_bias(att.view(B * L, HID), w_ao, b_ao)
-        y1, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1)                 # z1 overwrites a
-        u = _mm_bias(y1, w_i, b_i)
+        y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo)
+        del a
+        u = _mm_bias(y1_lo if lo else y1, w_i, b_i)
+        del y1_lo
         gact = ops.gelu_fwd(u)
         o = _mm_bias(gact, w_o, b_o)
         del gact
-        y2, z2, st2 = ops.add_layernorm_fwd(o, y1, g2, be2)                 # z2 overwrites o
+        y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, y1, g2, be2, stream_dtype=F32, want_lo=lo)
         ctx.keys = keys
-        ctx.save_for_backward(x2, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2)
-        return y2.view(B, L, HID)
+        ctx.save_for_backward(xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2)
+        y2 = y2.view(B, L, HID)
+        y2_lo = y2_lo.view(B, L, HID) if lo else y2.detach()
+        ctx.mark_non_differentiable(y2_lo)
+        return y2, y2_lo
 
     @staticmethod
-    def backward(ctx, dy):
-        x2, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2 = ctx.saved_tensors
+    def backward(ctx, dy, _dy_lo):
+        xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2 = ctx.saved_tensors
         keys = ctx.keys
         B, L, _ = qkv.shape
+        dt = w_qkv.dtype
+        lo = dt != F32
         dy = dy.contiguous().view(B * L, HID)
         # ---- output LayerNorm + FFN
-        dz2, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2)
+        dz2, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt)
         gact = ops.gelu_fwd(u)
         dw_o = dz2.t() @ gact
         db_o = dz2.sum(0)
@@ -54,60 +71,64 @@ class BertLayerFn(torch.autograd.Function):
         del gact
         du, db_i = ops.gelu_bwd(dgact, u)
         del dgact
-        y1, _, _ = ops.add_layernorm_fwd(z1, None, g1, be1, save=False)      # recompute LN1 output
-        dw_i = du.t() @ y1
+        y1, y1_lo, _, _ = ops.add_layernorm_fwd(z1, None, g1, be1, save=False, stream_dtype=F32, want_lo=lo, want_y=not lo)
+        dw_i = du.t() @ (y1_lo if lo else y1)                                # recomputed LN1 output
         dy1 = torch.addmm(dz2, du, w_i)                                      # + residual branch of LN2
-        del du, y1, dz2
+        del du, y1, y1_lo, dz2
         # ---- attention output LayerNorm + projection
-        dz1, dg1, dbe1 = ops.add_layernorm_bwd(dy1, z1, st1, g1)
+        dz1, dg1, dbe1 = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt)
         del dy1
-        att2 = att.view(B * L, HID)
-        dw_ao = dz1.t() @ att2
+        dw_ao = dz1.t() @ att.view(B * L, HID)
         db_ao = dz1.sum(0)
         datt = (dz1 @ w_ao).view(B, L, HID)
         # ---- attention
         dqkv = ops.attn_bwd(qkv, att, datt, lse, keys).view(B * L, 3 * HID)
         del datt
-        dw_qkv = dqkv.t() @ x2
+        dw_qkv = dqkv.t() @ xl
         db_qkv = dqkv.sum(0)
         dx = torch.addmm(dz1, dqkv, w_qkv)                                   # + residual branch of LN1
-        return (dx.view(B, L, HID), None, dw_qkv, db_qkv.to(dw_qkv.dtype), dw_ao, db_ao.to(dw_ao.dtype), dg1, dbe1,
-                dw_i, db_i.to(dw_i.dtype), dw_o, db_o.to(dw_o.dtype), dg2, dbe2)
+        return (dx.view(B, L, HID), None, None, dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1,
+                dw_i, db_i.to(dt), dw_o, db_o, dg2, dbe2)
 
 
 class LayerNormFn(torch.autograd.Function):
-    """y = LN(x + res) over rows of 768 (res optional).  Used outside the BERT layers:
-    t2s.py:87-88,116-117 (embedding LayerNorms), :685-687 (PrevPredEmbeddings), BertEmbeddings."""
+    """y = LN(x + res) over rows of 768 (res optional); x may be a bf16 GEMM output, y/res are fp32.
+    Used outside the BERT layers: t2s.py:87-88,116-117 (embedding LayerNorms), :685-687
+    (PrevPredEmbeddings), BertEmbeddings."""
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta):
         shape = x.shape
         x2 = x.contiguous().view(-1, HID)
         r2 = res.contiguous().view(-1, HID) if res is not None else None
-        y, z, st = ops.add_layernorm_fwd(x2, r2, gamma, beta, inplace_z=False)
+        y, _, z, st = ops.add_layernorm_fwd(x2, r2, gamma, beta, inplace_z=False, stream_dtype=F32)
         ctx.save_for_backward(z, st, gamma)
         ctx.has_res = res is not None
+        ctx.x_dtype = x.dtype
         return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
         z, st, gamma = ctx.saved_tensors
-        dz, dg, db = ops.add_layernorm_bwd(dy.contiguous().view(-1, HID), z, st, gamma)
+        dy2 = dy.contiguous().view(-1, HID)
+        dz, dg, db = ops.add_layernorm_bwd(dy2.float() if dy2.dtype != F32 else dy2, z, st, gamma, out_dtype=F32)
         dz = dz.view(dy.shape)
-        return dz, (dz if ctx.has_res else None), dg, db
+        return dz.to(ctx.x_dtype), (dz if ctx.has_res else None), dg, db
 
 
 def layer_norm(x, gamma, beta, res=None):
+    """-> fp32."""
     return LayerNormFn.apply(x, res, gamma, beta)
 
 
-def bert_layer(x, keys, lp, dtype):
-    """lp: a module holding one layer's parameters under the reference's names (see t2s.BertLayerParams)."""
+def bert_layer(x, x_lo, keys, lp, dtype):
+    """lp: a module holding one layer's parameters under the reference's names (see t2s.BertLayerParams).
+    Returns (y fp32, y_lo operand dtype)."""
     att = lp.attention
     w_qkv = torch.cat([att.self.query.weight, att.self.key.weight, att.self.value.weight], 0).to(dtype)
     b_qkv = torch.cat([att.self.query.bias, att.self.key.bias, att.self.value.bias], 0).to(dtype)
     return BertLayerFn.apply(
-        x, keys, w_qkv, b_qkv,
+        x, x_lo, keys, w_qkv, b_qkv,
         att.output.dense.weight.to(dtype), att.output.dense.bias.to(dtype),
         att.output.LayerNorm.weight, att.output.LayerNorm.bias,
         lp.intermediate.dense.weight.to(dtype), lp.intermediate.dense.bias.to(dtype),
@@ -116,6 +137,8 @@ def bert_layer(x, keys, lp, dtype):
 
 
 def bert_encoder(x, keys, layers, dtype):
+    """x: fp32 [B, L, 768] -> fp32."""
+    x_lo = None
     for lp in layers:
-        x = bert_layer(x, keys, lp, dtype)
+        x, x_lo = bert_layer(x, x_lo, keys, lp, dtype)
     return x

@@ -92,31 +92,39 @@ def _check_keys(keys, B, L):
     assert keys.dec_q0 + keys.n_dec <= L or keys.n_dec == 0, "decoder rows must lie inside the sequence"
 
 
-def add_layernorm_fwd(x, res, gamma, beta, eps=1e-12, save=True, inplace_z=True):
-    """y = LN(x + res).  Returns (y, z, stats): z = x + res kept for backward (written over x when
-    inplace_z), stats [rows, 2] = (mean, rstd).  res may be None."""
+def add_layernorm_fwd(x, res, gamma, beta, eps=1e-12, save=True, inplace_z=True, stream_dtype=None, want_lo=False,
+                      want_y=True):
+    """y = LN(x + res).  x: GEMM-output dtype; res / y / z: residual-stream dtype (``stream_dtype``, default
+    x.dtype).  Returns (y, y_lo, z, stats): y_lo = bf16 copy of y (if want_lo), z = x + res kept for backward
+    (written over x when the dtypes match and inplace_z), stats [rows, 2] = (mean, rstd).  res may be None."""
     rows = _rows768(x)
+    sdt = stream_dtype or x.dtype
     if res is not None:
-        assert res.shape == x.shape and res.is_contiguous() and res.dtype == x.dtype
+        assert res.shape == x.shape and res.is_contiguous() and res.dtype == sdt
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == HID
-    y = torch.empty_like(x)
-    z = (x if inplace_z else torch.empty_like(x)) if save else None
+    y = torch.empty(x.shape, dtype=sdt, device=x.device) if want_y else None
+    y_lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lo else None
+    z = None
+    if save:
+        z = x if (inplace_z and sdt == x.dtype) else torch.empty(x.shape, dtype=sdt, device=x.device)
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save else None
-    X.check(X.lib().t2s_add_layernorm_fwd(X.ptr(x), X.ptr(res), X.ptr(gamma), X.ptr(beta), X.ptr(y), X.ptr(z),
-                                          X.ptr(stats), rows, eps, X.dtype_code(x), X.stream()), "t2s_add_layernorm_fwd")
-    return y, z, stats
+    X.check(X.lib().t2s_add_layernorm_fwd(X.ptr(x), X.ptr(res), X.ptr(gamma), X.ptr(beta), X.ptr(y), X.ptr(y_lo), X.ptr(z),
+                                          X.ptr(stats), rows, eps, X.dtype_code(x), X.T2S_F32 if sdt == torch.float32 else X.T2S_BF16, X.stream()),
+            "t2s_add_layernorm_fwd")
+    return y, y_lo, z, stats
 
 
-def add_layernorm_bwd(dy, z, stats, gamma):
-    """Returns (dz, dgamma, dbeta)."""
+def add_layernorm_bwd(dy, z, stats, gamma, out_dtype=None):
+    """Returns (dz [out_dtype, default dy.dtype], dgamma, dbeta)."""
     rows = _rows768(dy)
-    assert z.shape == dy.shape and z.is_contiguous() and z.dtype == dy.dtype and stats.shape == (rows, 2)
+    assert z.shape == dy.shape and z.is_contiguous() and stats.shape == (rows, 2)
     parts = X.lib().t2s_layernorm_bwd_parts(rows)
-    dz = torch.empty_like(dy)
+    dz = torch.empty(dy.shape, dtype=out_dtype or dy.dtype, device=dy.device)
     dgp = torch.empty(parts, HID, dtype=torch.float32, device=dy.device)
     dbp = torch.empty(parts, HID, dtype=torch.float32, device=dy.device)
     X.check(X.lib().t2s_add_layernorm_bwd(X.ptr(dy), X.ptr(z), X.ptr(stats), X.ptr(gamma), X.ptr(dz), X.ptr(dgp), X.ptr(dbp),
-                                          rows, X.dtype_code(dy), X.stream()), "t2s_add_layernorm_bwd")
+                                          rows, X.dtype_code(dy), X.dtype_code(z), X.dtype_code(dz), X.stream()),
+            "t2s_add_layernorm_bwd")
     return dz, dgp.sum(0), dbp.sum(0)
 
 

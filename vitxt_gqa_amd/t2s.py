@@ -91,7 +91,7 @@ class TextBert(nn.Module):
         e = self.embeddings
         L = txt_inds.size(1)
         x = (e.word_embeddings(txt_inds) + e.position_embeddings.weight[:L].unsqueeze(0)
-             + e.token_type_embeddings.weight[0]).to(dtype)
+             + e.token_type_embeddings.weight[0])
         x = FN.layer_norm(x, e.LayerNorm.weight, e.LayerNorm.bias)
         keys = ops.compact_keys(txt_mask > 0)
         return FN.bert_encoder(x, keys, self.encoder.layer, dtype)
@@ -258,13 +258,13 @@ class PrevPredEmbeddings(nn.Module):
         B, D = prev_inds.shape
         V = ans_emb.size(0)
         is_ocr = prev_inds.ge(V)
-        ans_rows = ans_emb[prev_inds.clamp(max=V - 1)].to(dtype)                                  # [B, D, 768]
+        ans_rows = ans_emb[prev_inds.clamp(max=V - 1)]                                            # [B, D, 768] fp32
         ocr_idx = (prev_inds - V).clamp(min=0)
         ocr_rows = torch.gather(ocr_emb, 1, ocr_idx.unsqueeze(-1).expand(-1, -1, HID))
         ans_n = FN.layer_norm(ans_rows, self.ans_layer_norm.weight, self.ans_layer_norm.bias)
         ocr_n = FN.layer_norm(ocr_rows, self.ocr_layer_norm.weight, self.ocr_layer_norm.bias)
         raw = torch.where(is_ocr.unsqueeze(-1), ocr_n, ans_n)
-        emb = (self.position_embeddings.weight[:D].unsqueeze(0) + self.token_type_embeddings(is_ocr.long())).to(dtype)
+        emb = self.position_embeddings.weight[:D].unsqueeze(0) + self.token_type_embeddings(is_ocr.long())
         emb = FN.layer_norm(emb, self.emb_layer_norm.weight, self.emb_layer_norm.bias)
         return raw + emb
 
@@ -303,9 +303,10 @@ class OcrPtrNet(nn.Module):
 
     def forward(self, query_inputs, key_inputs, attention_mask, dtype):
         assert attention_mask.dim() == 2
-        q = F.linear(query_inputs, self.query.weight.to(dtype), self.query.bias.to(dtype))
-        k = F.linear(key_inputs, self.key.weight.to(dtype), self.key.bias.to(dtype))
-        scores = torch.matmul(q, k.transpose(-1, -2)).float() / math.sqrt(self.query_key_size)
+        # 12 query rows per sample: fp32 GEMM (tiny); N key rows per sample: operand-dtype GEMM
+        q = F.linear(query_inputs, self.query.weight, self.query.bias)
+        k = F.linear(key_inputs.to(dtype), self.key.weight.to(dtype), self.key.bias.to(dtype))
+        scores = torch.matmul(q, k.float().transpose(-1, -2)) / math.sqrt(self.query_key_size)
         return scores + attention_mask.float().unsqueeze(1)
 
 
@@ -408,14 +409,14 @@ class T2S(BaseModel):
                       dim=-1).to(dt)
         a = F.linear(x, self.linear_ocr_feat_to_mmt_in.weight.to(dt), self.linear_ocr_feat_to_mmt_in.bias.to(dt))
         a = FN.layer_norm(a, self.ocr_feat_layer_norm.weight, self.ocr_feat_layer_norm.bias)
-        b = F.linear(s.ocr_bbox_coordinates.to(dt), self.linear_ocr_bbox_to_mmt_in.weight.to(dt),
-                     self.linear_ocr_bbox_to_mmt_in.bias.to(dt))
+        b = F.linear(s.ocr_bbox_coordinates.float(), self.linear_ocr_bbox_to_mmt_in.weight,
+                     self.linear_ocr_bbox_to_mmt_in.bias)                      # K = 4: fp32
         b = FN.layer_norm(b, self.ocr_bbox_layer_norm.weight, self.ocr_bbox_layer_norm.bias)
         fwd["ocr_mmt_in"] = self._drop(a + b, self.ocr_drop_p)
         fwd["ocr_mask"] = s.ocr_mask
 
     def _forward_output(self, ocr_out, dec_out, mask, dt):
-        fixed = F.linear(dec_out, self.classifier.module.weight.to(dt), self.classifier.module.bias.to(dt)).float()
+        fixed = F.linear(dec_out, self.classifier.module.weight, self.classifier.module.bias)      # fp32, 12 rows/sample
         return torch.cat([fixed, self.ocr_ptr_net(dec_out, ocr_out, mask, dt)], dim=-1)
 
     def _three_pass(self, fwd, prev_inds, dt):
