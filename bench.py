@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Headline benchmark: T2S-QA train-step samples/sec on synthetic 100-frame x 100-OCR x 20-q-token batches.
+
+    python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run)
+
+A step = forward (TextBert, embeds, QTV, grounding, 3 x MMT + heads) + pos_bce_loss + 1000*InfoNCE +
+backward + global-norm clip 0.25 + Adam, batch 64 per GPU (BASELINE.json configs[2]; weak scaling:
+per-GPU batch fixed, questions sharded across ranks, one RCCL gradient all-reduce per step).
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (attention forward
+kernel, HIP-event timed inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle restatement
+of the reference timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+T_Q, DEC = 20, 12
+HID, FFN = 768, 3072
+
+
+def flops_per_sample_fwd(F, P, V):
+    """FLOP model of BASELINE.md section 4."""
+    N = F * P
+    L1, L2 = T_Q + F + N, T_Q + F + N + DEC
+    layer = lambda L: 24 * L * HID * HID + 4 * L * L * HID
+    attn = 4 * HID * (3 * T_Q ** 2 + 2 * L1 ** 2 + 9 * L2 ** 2)
+    total = (3 * layer(T_Q) + 2 * layer(L1) + 9 * layer(L2) + 2 * HID * (1074 * F + 1008 * N)
+             + 3 * (24 * HID * V + 24 * HID * HID + 2 * N * HID * HID + 24 * N * HID))
+    return total, attn
+
+
+class AttnFwdTimer:
+    """Wraps ops.attn_fwd with HIP events on the launch stream (torch's current stream is the stream the
+    kernel is enqueued on); accumulates algorithmic (dense-mask) FLOPs and device time per launch."""
+
+    def __init__(self):
+        from vitxt_gqa_amd import ops
+        self.ops, self.orig = ops, ops.attn_fwd
+        self.events, self.enabled = [], False
+
+    def __enter__(self):
+        def timed(qkv, keys, scale=0.125):
+            if not self.enabled:
+                return self.orig(qkv, keys, scale)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig(qkv, keys, scale)
+            e1.record()
+            B, L, _ = qkv.shape
+            self.events.append((e0, e1, 4.0 * B * 12 * L * L * 64))
+            return r
+        self.ops.attn_fwd = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.attn_fwd = self.orig
+
+    def summary(self, min_flops=1e9):
+        big = [(a.elapsed_time(b) * 1e-3, f) for a, b, f in self.events if f >= min_flops]
+        if not big:
+            return None
+        t, f = sum(x for x, _ in big), sum(y for _, y in big)
+        return dict(launches=len(big), avg_ms=1e3 * t / len(big), tflops=f / t / 1e12)
+
+
+class _Budget(Exception):
+    pass
+
+
+def cpu_baseline(V, seed=0, budget_s=150):
+    """Reference semantics (CPU oracle) timed on the host cores on a bounded sample of the workload, scaled to
+    the full 100x100 shape by the FLOP model.  Runs BEFORE the GPU is touched, under a hard wall-clock budget."""
+    import signal
+    from oracle import t2s_oracle as O
+    from vitxt_gqa_amd.init import make_state_dict
+    from vitxt_gqa_amd.schema import state_dict_schema
+    from vitxt_gqa_amd.synth import make_batch, make_noise
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 64))
+    torch.set_num_threads(cores)
+    Fs, Bs = 100, 1
+    f_full, _ = flops_per_sample_fwd(100, 100, V)
+    sd = make_state_dict(state_dict_schema(V), seed=seed)
+    for k, v in sd.items():
+        v.requires_grad_(not O.is_dead(k))
+    result = {"value": None, "unit": "samples/s", "cores": cores, "kind": "port", "sample": "not measured (budget exceeded)"}
+
+    def on_alarm(signum, frame):
+        raise _Budget()
+
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(int(budget_s))
+    try:
+        for Ps, min_steps in ((5, 1), (20, 2)):
+            batch = make_batch(Bs, Fs, Ps, V=V, seed=seed)
+            e1, e2 = make_noise(Bs, Fs, Ps, seed)
+            cfg = dict(frame_topk=5, ocr_topk=5, frame_num=Fs, ocr_frame_num=Ps)
+            st = {}
+            t0 = time.time()
+            O.train_step(sd, batch, cfg, st, 1, expo_frame=e1, expo_ocr=e2)        # warm-up
+            warm = time.time() - t0
+            t0 = time.time()
+            n = 0
+            while n < min_steps or (time.time() - t0 < 8 and n < 6):
+                O.train_step(sd, batch, cfg, st, n + 2, expo_frame=e1, expo_ocr=e2)
+                n += 1
+            dt = (time.time() - t0) / n
+            f_s, _ = flops_per_sample_fwd(Fs, Ps, V)
+            sps = Bs / dt
+            result.update(value=sps * f_s / f_full, measured_samples_per_s_at_sample_shape=sps,
+                          sample="oracle (plain-torch CPU restatement of the reference) full train step, fp32, %d threads, "
+                                 "B=%d x %d frames x %d OCR/frame (L=%d): %.2f s/step over %d steps = %.3f samples/s "
+                                 "measured; scaled by the FLOP model (x%.4f) to the 100x100 workload"
+                                 % (cores, Bs, Fs, Ps, T_Q + Fs + Fs * Ps + DEC, dt, n, sps, f_s / f_full))
+            f_next, _ = flops_per_sample_fwd(Fs, 20, V)
+            if Ps == 5 and dt * f_next / f_s > 12:       # the larger sample would not fit the budget
+                break
+    except _Budget:
+        result["sample"] += " [stopped by the %ds wall-clock budget]" % budget_s
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config: 64)")
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--ocr", type=int, default=100, help="OCR tokens per frame")
+    ap.add_argument("--vocab", type=int, default=5000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]: forward-only throughput")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_res = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_res = cpu_baseline(args.vocab)          # host-only; runs before any GPU call
+        print("[bench] cpu_baseline:", json.dumps(cpu_res), file=sys.stderr, flush=True)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from vitxt_gqa_amd import training_config
+    from vitxt_gqa_amd.ddp import GradBuckets
+    from vitxt_gqa_amd.optim import build_optimizer, clip_gradients, lr_lambda_update
+    from vitxt_gqa_amd.synth import make_batch, make_noise
+    from vitxt_gqa_amd.testing import make_model, to_device
+
+    B, F, P, V = args.batch, args.frames, args.ocr, args.vocab
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = make_model(F, P, V, seed=0, dtype=dtype).to(dev)        # identical weights on every rank (name-seeded)
+    model.train(not args.forward_only)
+    cfg = training_config()
+    opt = build_optimizer(model, cfg)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda it: lr_lambda_update(it, cfg))
+    buckets = GradBuckets(model.parameters())
+    # each rank draws its own shard of questions (weak scaling: B per GPU)
+    batch = to_device(make_batch(B, F, P, V=V, seed=100 + rank), dev)
+    batch.grounding_noise = tuple(t.to(dev) for t in make_noise(B, F, P, seed=100 + rank))
+
+    def step():
+        if args.forward_only:
+            with torch.no_grad():
+                return model.forward(batch)
+        out = model(batch)
+        loss = sum(l.mean() for l in out["losses"].values())
+        buckets.reset()
+        loss.backward()
+        buckets.finish()
+        clip_gradients(model, cfg)
+        opt.step()
+        sched.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with AttnFwdTimer() as timer:
+        for _ in range(args.warmup):
+            step()
+        sync()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    f_total, f_attn = flops_per_sample_fwd(F, P, V)
+    mult = 1.0 if args.forward_only else 3.0
+    sps = world * B * args.steps / elapsed
+    att = timer.summary()
+    res = {
+        "metric": ("forward-only" if args.forward_only else "train-step") + " samples/sec (T2S, %d-frame x %d-OCR synthetic)" % (F, P),
+        "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "T2S-QA %s, batch %d/GPU, %d frames x %d OCR/frame x 20 q-tokens, 12 decode steps, V=%d "
+                               "(BASELINE.json configs[%d])" % ("forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam, pos-BCE + 1000*InfoNCE)",
+                                                               B, F, P, V, 1 if args.forward_only else 2),
+                   "global_batch": world * B, "seq_len": T_Q + F + F * P + DEC, "parallelism": "dp%d" % world,
+                   "precision": "bf16 MFMA operands, fp32 accumulate / residual stream / master weights" if args.dtype == "bf16" else "fp32"},
+        "model_flops_per_sample": mult * f_total,
+        "model_tflops": sps * mult * f_total / 1e12 / world,
+        "attention_gemm_fraction_of_flops": f_attn / f_total,
+        "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+    }
+    if not args.forward_only:
+        res["loss"] = float(last.detach())
+    if att:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("attn_fwd_bf16_kernel")
+        res["roofline"] = {"kernel": "attn_fwd_bf16_kernel (all launches with >= 1 GFLOP in the timed region)",
+                           "bound": "mfma", "achieved": att["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": att["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+                           "launches": att["launches"], "avg_launch_ms": att["avg_ms"],
+                           "note": "algorithmic = dense-mask attention-GEMM FLOPs 4*B*12*L^2*64 per launch; masked keys are "
+                                   "skipped by key compaction, so executed FLOPs are lower (DESIGN.md)"}
+    if cpu_res is not None:
+        res["cpu_baseline"] = cpu_res
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

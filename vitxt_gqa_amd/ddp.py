@@ -1,0 +1,90 @@
+"""Data parallelism for the T2S train step: one process per GPU, questions sharded across ranks, ONE
+exchange step per iteration = gradient all-reduce (mean) over RCCL/xGMI, bucketed and overlapped
+with backward.
+
+Replaces the reference's ``nn.DataParallel`` default / opt-in ``DistributedDataParallel(...,
+find_unused_parameters=True)`` (``pythia/trainers/base_trainer.py:51-71,121-137``): the 58 parameters
+that never receive a gradient are frozen at build time, so no unused-parameter
+scan is needed and every bucket's readiness is known statically.
+
+Gradients live as views into a few large flat fp32 buckets (few, large collectives: a ring all-reduce
+over point-to-point xGMI links is per-link bound, so per-collective latency is what to amortise).
+A bucket is all-reduced (async, on RCCL's own stream) as soon as the last of its gradients has been
+accumulated; ``finish()`` waits for the outstanding collectives before clipping / the optimizer.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous-chunk sharding of ``DistributedSampler`` (``pythia/datasets/samplers.py:42-60``):
+    pad to a multiple of world_size by wrapping, rank r takes [r*n, (r+1)*n)."""
+    per = (n_items + world_size - 1) // world_size
+    idx = list(range(n_items))
+    idx += idx[: per * world_size - n_items]
+    return idx[rank * per:(rank + 1) * per]
+
+
+class GradBuckets:
+    def __init__(self, params, bucket_bytes=256 << 20, group=None, average=True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.average = average
+        params = [p for p in params if p.requires_grad]
+        # gradients become ready roughly in reverse construction order
+        params = list(reversed(params))
+        self.buckets = []          # (flat tensor, [params])
+        cur, cur_n = [], 0
+        cap = max(1, bucket_bytes // 4)
+        for p in params:
+            if cur and cur_n + p.numel() > cap:
+                self._close(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self._close(cur)
+        self._pending = [0] * len(self.buckets)
+        self._handles = []
+        self._hooks = []
+        for bi, (_, ps) in enumerate(self.buckets):
+            for p in ps:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self.reset()
+
+    def _close(self, ps):
+        flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
+        off = 0
+        for p in ps:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.buckets.append((flat, ps))
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0 and self.world > 1:
+                flat = self.buckets[bi][0]
+                if self.average:
+                    flat.div_(self.world)
+                self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return hook
+
+    def reset(self):
+        """Zero the buckets (keeps .grad views alive; use instead of optimizer.zero_grad())."""
+        for bi, (flat, ps) in enumerate(self.buckets):
+            flat.zero_()
+            self._pending[bi] = len(ps)
+            for p in ps:                      # restore views if something replaced .grad
+                if p.grad is None or p.grad.data_ptr() < flat.data_ptr() or p.grad.data_ptr() >= flat.data_ptr() + flat.numel() * 4:
+                    raise RuntimeError("a bucketed .grad view was replaced; call GradBuckets.reset() instead of zero_grad(set_to_none=True)")
+        self._handles = []
+
+    def finish(self):
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
