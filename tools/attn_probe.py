@@ -6,7 +6,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vitxt_gqa_amd import ops  # noqa: E402
 
 

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 // ---------------------------------------------------------------------------------------------
 // dK / dV, bf16.
 template <bool USE_IDX>
-__global__ __launch_bounds__(256) void attn_dkdv_bf16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   // [buf][Q tile 4 KB | dO tile 4 KB | lse 32 f | delta 32 f]
   constexpr int STAGE = 2 * TILE32 + 256;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -88,41 +88,48 @@ __global__ __launch_bounds__(256) void attn_dkdv_bf16_kernel(AttnParams p) {
 
   // staging: thread -> (row sr, chunk sc) of the 32 x 64 Q and dO tiles
   const int sr = tid >> 3, sc = tid & 7;
+  // plain named registers + unconditional (clamped) loads: keeps the staging out of scratch memory
   uint4 qreg, doreg;
   float lreg = 0.f, dreg = 0.f;
-  auto stage_load = [&](int qt) {
-    const int r = qt * 32 + sr;
-    const bool ok = r < p.Lq;
-    const int rc = ok ? r : p.Lq - 1;
-    qreg = *reinterpret_cast<const uint4*>(Q + (int64_t)rc * p.q_rs + sc * 8);
-    doreg = *reinterpret_cast<const uint4*>(DO + (int64_t)rc * p.o_rs + sc * 8);
-    if (!ok) doreg = make_uint4(0, 0, 0, 0);
-    if (tid < 32) {
-      const int r2 = qt * 32 + tid;
-      lreg = r2 < p.Lq ? LSE[r2] * LOG2E : INFINITY;     // +inf => P = 0 for rows past Lq
-      dreg = r2 < p.Lq ? DELTA[r2] : 0.f;
-    }
-  };
-  auto stage_write = [&](int buf) {
-    char* base = smem + buf * STAGE;
-    *reinterpret_cast<uint4*>(base + tile_off(sr, sc)) = qreg;
-    *reinterpret_cast<uint4*>(base + TILE32 + tile_off(sr, sc)) = doreg;
-    if (tid < 32) {
-      reinterpret_cast<float*>(base + 2 * TILE32)[tid] = lreg;
-      reinterpret_cast<float*>(base + 2 * TILE32 + 128)[tid] = dreg;
-    }
-  };
+  const int lrow = tid & 31;               // lse / delta row staged by this thread (all threads load; 32 write)
+#define STAGE_LOAD(qt_)                                                                         \
+  {                                                                                             \
+    const int r_ = (qt_) * 32 + sr;                                                             \
+    const bool ok_ = r_ < p.Lq;                                                                 \
+    const int rc_ = ok_ ? r_ : p.Lq - 1;                                                        \
+    qreg = *reinterpret_cast<const uint4*>(Q + (int64_t)rc_ * p.q_rs + sc * 8);                 \
+    doreg = *reinterpret_cast<const uint4*>(DO + (int64_t)rc_ * p.o_rs + sc * 8);               \
+    if (!ok_) doreg = make_uint4(0, 0, 0, 0);                                                   \
+    const int r2_ = (qt_) * 32 + lrow;                                                          \
+    const int r2c_ = r2_ < p.Lq ? r2_ : p.Lq - 1;                                               \
+    const float l_ = LSE[r2c_] * LOG2E, d_ = DELTA[r2c_];                                       \
+    lreg = r2_ < p.Lq ? l_ : INFINITY; /* +inf => P = 0 for rows past Lq */                     \
+    dreg = r2_ < p.Lq ? d_ : 0.f;                                                               \
+  }
+#define STAGE_WRITE(buf_)                                                                       \
+  {                                                                                             \
+    char* base_ = smem + (buf_) * STAGE;                                                        \
+    *reinterpret_cast<uint4*>(base_ + tile_off(sr, sc)) = qreg;                                 \
+    *reinterpret_cast<uint4*>(base_ + TILE32 + tile_off(sr, sc)) = doreg;                       \
+    if (tid < 32) {                                                                             \
+      reinterpret_cast<float*>(base_ + 2 * TILE32)[tid] = lreg;                                 \
+      reinterpret_cast<float*>(base_ + 2 * TILE32 + 128)[tid] = dreg;                           \
+    }                                                                                           \
+  }
 
   f32x16 dkacc[2], dvacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
 
-  stage_load(0);
-  stage_write(0);
+  STAGE_LOAD(0);
+  STAGE_WRITE(0);
   __syncthreads();
   for (int qt = 0; qt < nqt; ++qt) {
     const int buf = qt & 1;
-    if (qt + 1 < nqt) stage_load(qt + 1);
+    {
+      const int qn = qt + 1 < nqt ? qt + 1 : qt;          // last iteration re-loads its own tile (harmless)
+      STAGE_LOAD(qn);
+    }
     const char* qb = smem + buf * STAGE;
     const char* dob = qb + TILE32;
     const float* lse_s = reinterpret_cast<const float*>(qb + 2 * TILE32);
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_bf16_kernel(AttnParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = 4 * g + j;
-        float pv = exp2f(sacc[r] * c - l4[j]);
+        float pv = fast_exp2(sacc[r] * c - l4[j]);
         if (edge) {
           const int qdec = qt * 32 + 8 * g + 4 * lh + j - p.dec_q0;
           const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
@@ -164,9 +171,11 @@ __global__ __launch_bounds__(256) void attn_dkdv_bf16_kernel(AttnParams p) {
         dkacc[db] = mfma_bf16(lds_tr_frag(qb, 16 * s, db, lane), dsf, dkacc[db]);   // dK^T[d, key] += Q^T[d, q] dS[q, key]
       }
     }
-    if (qt + 1 < nqt) stage_write(buf ^ 1);
+    STAGE_WRITE(buf ^ 1);
     __syncthreads();
   }
+#undef STAGE_LOAD
+#undef STAGE_WRITE
 
   if (kvalid) {
     bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs;
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_bf16_kernel(AttnParams p) {
 // ---------------------------------------------------------------------------------------------
 // dQ, bf16.
 template <bool USE_IDX>
-__global__ __launch_bounds__(256) void attn_dq_bf16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE64];   // [buf][K, V]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -219,39 +228,42 @@ __global__ __launch_bounds__(256) void attn_dq_bf16_kernel(AttnParams p) {
   const int qdec = qrow - p.dec_q0;
 
   const int sr = tid >> 3, sc = tid & 7;
-  uint4 kreg[2], vreg[2];
-  auto stage_load = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int pos = t * BK + sr + 32 * i;
-      pos = pos < nk ? pos : nk - 1;
-      const int64_t row = USE_IDX ? (int64_t)idx[pos] : (int64_t)pos;
-      kreg[i] = *reinterpret_cast<const uint4*>(K + row * p.kv_rs + sc * 8);
-      vreg[i] = *reinterpret_cast<const uint4*>(V + row * p.kv_rs + sc * 8);
-    }
-  };
-  auto stage_write = [&](int buf) {
-    char* kb = smem + buf * 2 * TILE64;
-    char* vb = kb + TILE64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = sr + 32 * i;
-      *reinterpret_cast<uint4*>(kb + tile_off(r, sc)) = kreg[i];
-      *reinterpret_cast<uint4*>(vb + tile_off(r, sc)) = vreg[i];
-    }
-  };
+  uint4 kr0, kr1, vr0, vr1;
+#define STAGE_LOAD(t_)                                                                              \
+  {                                                                                                 \
+    int p0_ = (t_) * BK + sr, p1_ = p0_ + 32;                                                       \
+    p0_ = p0_ < nk ? p0_ : nk - 1;                                                                  \
+    p1_ = p1_ < nk ? p1_ : nk - 1;                                                                  \
+    const int64_t r0_ = USE_IDX ? (int64_t)idx[p0_] : (int64_t)p0_;                                 \
+    const int64_t r1_ = USE_IDX ? (int64_t)idx[p1_] : (int64_t)p1_;                                 \
+    kr0 = *reinterpret_cast<const uint4*>(K + r0_ * p.kv_rs + sc * 8);                              \
+    vr0 = *reinterpret_cast<const uint4*>(V + r0_ * p.kv_rs + sc * 8);                              \
+    kr1 = *reinterpret_cast<const uint4*>(K + r1_ * p.kv_rs + sc * 8);                              \
+    vr1 = *reinterpret_cast<const uint4*>(V + r1_ * p.kv_rs + sc * 8);                              \
+  }
+#define STAGE_WRITE(buf_)                                                                           \
+  {                                                                                                 \
+    char* kb_ = smem + (buf_) * 2 * TILE64;                                                         \
+    *reinterpret_cast<uint4*>(kb_ + tile_off(sr, sc)) = kr0;                                        \
+    *reinterpret_cast<uint4*>(kb_ + TILE64 + tile_off(sr, sc)) = vr0;                               \
+    *reinterpret_cast<uint4*>(kb_ + tile_off(sr + 32, sc)) = kr1;                                   \
+    *reinterpret_cast<uint4*>(kb_ + TILE64 + tile_off(sr + 32, sc)) = vr1;                          \
+  }
 
   f32x16 dqacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
   if (ntiles > 0) {
-    stage_load(0);
-    stage_write(0);
+    STAGE_LOAD(0);
+    STAGE_WRITE(0);
   }
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntiles) stage_load(t + 1);
+    {
+      const int tn = t + 1 < ntiles ? t + 1 : t;
+      STAGE_LOAD(tn);
+    }
     const char* kb = smem + buf * 2 * TILE64;
     const char* vb = kb + TILE64;
     f32x16 sacc[2], dpacc[2];
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_dq_bf16_kernel(AttnParams p) {
     for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float pv = exp2f(sacc[kbk][r] * c - lse2);
+        float pv = fast_exp2(sacc[kbk][r] * c - lse2);
         if (edge) {
           const int pos = t * BK + kbk * 32 + acc_row(r, lh);
           const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
@@ -286,9 +298,11 @@ __global__ __launch_bounds__(256) void attn_dq_bf16_kernel(AttnParams p) {
         for (int db = 0; db < 2; ++db)
           dqacc[db] = mfma_bf16(lds_tr_frag(kb, kbk * 32 + 16 * s, db, lane), dsf, dqacc[db]);   // dQ^T[d, q] += K^T[d, key] dS^T[key, q]
       }
-    if (t + 1 < ntiles) stage_write(buf ^ 1);
+    STAGE_WRITE(buf ^ 1);
     __syncthreads();
   }
+#undef STAGE_LOAD
+#undef STAGE_WRITE
 
   char* ob = smem + wave * (32 * 144);
 #pragma unroll
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_dq_bf16_kernel(AttnParams p) {
 constexpr int F32_LD = 65;
 
 template <bool USE_IDX>
-__global__ __launch_bounds__(256) void attn_dkdv_f32_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_dkdv_f32_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 32 * F32_LD + 64];
   float* qs = smem;
   float* dos = smem + 32 * F32_LD;
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_f32_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = acc_row(r, lh);
-      float pv = exp2f(sacc[r] * c - lse_s[qi]);
+      float pv = fast_exp2(sacc[r] * c - lse_s[qi]);
       const int qdec = qt * 32 + qi - p.dec_q0;
       const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
       pv = ok ? pv : 0.f;
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_dkdv_f32_kernel(AttnParams p) {
 }
 
 template <bool USE_IDX>
-__global__ __launch_bounds__(256) void attn_dq_f32_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_dq_f32_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * F32_LD];
   float* ks = smem;
   float* vs = smem + BK * F32_LD;
@@ -485,7 +499,7 @@ __global__ __launch_bounds__(256) void attn_dq_f32_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const int pos = t * BK + kbk * 32 + acc_row(r, lh);
         const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
-        const float pv = ok ? exp2f(sacc[kbk][r] * c - lse2) : 0.f;
+        const float pv = ok ? fast_exp2(sacc[kbk][r] * c - lse2) : 0.f;
         dpacc[kbk][r] = pv * (dpacc[kbk][r] - del);
       }
 #pragma unroll

@@ -72,3 +72,6 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 #define LOG2E 1.4426950408889634f
+
+// raw v_exp_f32 (one instruction; results below 2^-126 flush to 0, which is what a softmax wants)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

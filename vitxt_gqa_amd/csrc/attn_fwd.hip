@@ -25,7 +25,7 @@ constexpr int BK = 64;    // keys per tile
 constexpr int TILE_BYTES = BK * 128;
 
 template <bool USE_IDX>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];   // [buf][K,V]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -48,29 +48,30 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
   }
 
-  // staging: thread -> (row sr / sr+32, 16-B chunk sc) of the K and V tiles
+  // staging: thread -> (row sr / sr+32, 16-B chunk sc) of the K and V tiles.  Plain named registers and
+  // unconditional (clamped) loads: arrays captured by a lambda or loads under a branch end up in scratch.
   const int sr = tid >> 3, sc = tid & 7;
-  uint4 kreg[2], vreg[2];
-  auto stage_load = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int pos = t * BK + sr + 32 * i;
-      pos = pos < nk ? pos : nk - 1;
-      const int64_t row = USE_IDX ? (int64_t)idx[pos] : (int64_t)pos;
-      kreg[i] = *reinterpret_cast<const uint4*>(K + row * p.kv_rs + sc * 8);
-      vreg[i] = *reinterpret_cast<const uint4*>(V + row * p.kv_rs + sc * 8);
-    }
-  };
-  auto stage_write = [&](int buf) {
-    char* kb = smem + buf * 2 * TILE_BYTES;
-    char* vb = kb + TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = sr + 32 * i;
-      *reinterpret_cast<uint4*>(kb + tile_off(r, sc)) = kreg[i];
-      *reinterpret_cast<uint4*>(vb + tile_off(r, sc)) = vreg[i];
-    }
-  };
+  uint4 kr0, kr1, vr0, vr1;
+#define STAGE_LOAD(t_)                                                                              \
+  {                                                                                                 \
+    int p0_ = (t_) * BK + sr, p1_ = p0_ + 32;                                                       \
+    p0_ = p0_ < nk ? p0_ : nk - 1;                                                                  \
+    p1_ = p1_ < nk ? p1_ : nk - 1;                                                                  \
+    const int64_t r0_ = USE_IDX ? (int64_t)idx[p0_] : (int64_t)p0_;                                 \
+    const int64_t r1_ = USE_IDX ? (int64_t)idx[p1_] : (int64_t)p1_;                                 \
+    kr0 = *reinterpret_cast<const uint4*>(K + r0_ * p.kv_rs + sc * 8);                              \
+    vr0 = *reinterpret_cast<const uint4*>(V + r0_ * p.kv_rs + sc * 8);                              \
+    kr1 = *reinterpret_cast<const uint4*>(K + r1_ * p.kv_rs + sc * 8);                              \
+    vr1 = *reinterpret_cast<const uint4*>(V + r1_ * p.kv_rs + sc * 8);                              \
+  }
+#define STAGE_WRITE(buf_)                                                                           \
+  {                                                                                                 \
+    char* kb_ = smem + (buf_) * 2 * TILE_BYTES;                                                     \
+    *reinterpret_cast<uint4*>(kb_ + tile_off(sr, sc)) = kr0;                                        \
+    *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + tile_off(sr, sc)) = vr0;                           \
+    *reinterpret_cast<uint4*>(kb_ + tile_off(sr + 32, sc)) = kr1;                                   \
+    *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + tile_off(sr + 32, sc)) = vr1;                      \
+  }
 
   f32x16 oacc[2];
 #pragma unroll
@@ -80,14 +81,17 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
   const int qdec = qrow - p.dec_q0;    // decoder step of this query row (negative: not a decoder row)
 
   if (ntiles > 0) {
-    stage_load(0);
-    stage_write(0);
+    STAGE_LOAD(0);
+    STAGE_WRITE(0);
   }
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntiles) stage_load(t + 1);
+    {
+      const int tn = t + 1 < ntiles ? t + 1 : t;      // last iteration re-loads its own tile (harmless)
+      STAGE_LOAD(tn);
+    }
     const char* kb = smem + buf * 2 * TILE_BYTES;
     const char* vb = kb + TILE_BYTES;
 
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f((m_run - m_use) * c);
+    const float alpha = fast_exp2((m_run - m_use) * c);
     m_run = m_new;
     const float mc = m_use * c;
     float lsum = 0.f;
@@ -130,13 +134,16 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
     for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(sacc[kbk][r] * c - mc);
+        const float pv = fast_exp2(sacc[kbk][r] * c - mc);
         sacc[kbk][r] = pv;
         lsum += pv;
       }
     l_run = l_run * alpha + lsum;
+    // the running max rarely moves after the first tiles: skip the O rescale when no row of the wave changed
+    if (!__all(alpha == 1.f)) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+      for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+    }
 
     // ---- O^T[d, q] += V^T[d, key] P^T[key, q]
 #pragma unroll
@@ -149,9 +156,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
           oacc[db] = mfma_bf16(lds_tr_frag(vb, kbk * 32 + 16 * s, db, lane), pf, oacc[db]);
       }
 
-    if (t + 1 < ntiles) stage_write(buf ^ 1);
+    STAGE_WRITE(buf ^ 1);
     __syncthreads();
   }
+#undef STAGE_LOAD
+#undef STAGE_WRITE
 
   // ---- epilogue: normalise, stage O through LDS (per-wave 32 x 64 tile, 144-B rows), store rows
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnParams p) {
 constexpr int F32_LD = 65;   // padded fp32 LDS row (conflict-free column reads)
 
 template <bool USE_IDX>
-__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * F32_LD];
   float* ks = smem;
   float* vs = smem + BK * F32_LD;
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f((m_run - m_use) * c);
+    const float alpha = fast_exp2((m_run - m_use) * c);
     m_run = m_new;
     const float mc = m_use * c;
     float lsum = 0.f;
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(AttnParams p) {
     for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(sacc[kbk][r] * c - mc);
+        const float pv = fast_exp2(sacc[kbk][r] * c - mc);
         sacc[kbk][r] = pv;
         lsum += pv;
       }
