@@ -49,152 +49,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 }
 
 // ---------------------------------------------------------------------------------------------
-// dK / dV, bf16.
-template <bool USE_IDX>
-__global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
-  // [buf][Q tile 4 KB | dO tile 4 KB | lse 32 f | delta 32 f]
-  constexpr int STAGE = 2 * TILE32 + 256;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
-  const int nk = n_prefix + p.n_dec;
-  const int kp0 = blockIdx.x * 128;
-  if (kp0 >= nk) return;                                   // uniform per workgroup
-  const int kpos = kp0 + wave * 32 + lr;                   // this lane's key position (column)
-  const bool kvalid = kpos < nk;
-  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
-  const int kclamp = kvalid ? kpos : nk - 1;
-  const int64_t krow = USE_IDX ? (int64_t)idx[kclamp] : (int64_t)kclamp;
-  const bf16_t* __restrict__ Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* __restrict__ DO = reinterpret_cast<const bf16_t*>(p.dout) + (int64_t)b * p.o_bs + h * 64;
-  const float* __restrict__ LSE = p.lse + ((int64_t)b * p.H + h) * p.Lq;
-  const float* __restrict__ DELTA = p.delta + ((int64_t)b * p.H + h) * p.Lq;
-
-  // K / V fragments of this wave's 32 keys: B operands, lane (key = lr, half lh) holds [key][16s+8lh..]
-  bf16x8 kf[4], vf[4];
-  {
-    const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs + 8 * lh;
-    const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs + 8 * lh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
-      vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s);
-    }
-  }
-  const int kdec = kpos - n_prefix;        // decoder step of this key (negative: prefix key)
-  const float c = p.scale * LOG2E;
-  const int nqt = (p.Lq + 31) / 32;
-
-  // staging: thread -> (row sr, chunk sc) of the 32 x 64 Q and dO tiles
-  const int sr = tid >> 3, sc = tid & 7;
-  // plain named registers + unconditional (clamped) loads: keeps the staging out of scratch memory
-  uint4 qreg, doreg;
-  float lreg = 0.f, dreg = 0.f;
-  const int lrow = tid & 31;               // lse / delta row staged by this thread (all threads load; 32 write)
-#define STAGE_LOAD(qt_)                                                                         \
-  {                                                                                             \
-    const int r_ = (qt_) * 32 + sr;                                                             \
-    const bool ok_ = r_ < p.Lq;                                                                 \
-    const int rc_ = ok_ ? r_ : p.Lq - 1;                                                        \
-    qreg = *reinterpret_cast<const uint4*>(Q + (int64_t)rc_ * p.q_rs + sc * 8);                 \
-    doreg = *reinterpret_cast<const uint4*>(DO + (int64_t)rc_ * p.o_rs + sc * 8);               \
-    if (!ok_) doreg = make_uint4(0, 0, 0, 0);                                                   \
-    const int r2_ = (qt_) * 32 + lrow;                                                          \
-    const int r2c_ = r2_ < p.Lq ? r2_ : p.Lq - 1;                                               \
-    const float l_ = LSE[r2c_] * LOG2E, d_ = DELTA[r2c_];                                       \
-    lreg = r2_ < p.Lq ? l_ : INFINITY; /* +inf => P = 0 for rows past Lq */                     \
-    dreg = r2_ < p.Lq ? d_ : 0.f;                                                               \
-  }
-#define STAGE_WRITE(buf_)                                                                       \
-  {                                                                                             \
-    char* base_ = smem + (buf_) * STAGE;                                                        \
-    *reinterpret_cast<uint4*>(base_ + tile_off(sr, sc)) = qreg;                                 \
-    *reinterpret_cast<uint4*>(base_ + TILE32 + tile_off(sr, sc)) = doreg;                       \
-    if (tid < 32) {                                                                             \
-      reinterpret_cast<float*>(base_ + 2 * TILE32)[tid] = lreg;                                 \
-      reinterpret_cast<float*>(base_ + 2 * TILE32 + 128)[tid] = dreg;                           \
-    }                                                                                           \
-  }
-
-  f32x16 dkacc[2], dvacc[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
-
-  STAGE_LOAD(0);
-  STAGE_WRITE(0);
-  __syncthreads();
-  for (int qt = 0; qt < nqt; ++qt) {
-    const int buf = qt & 1;
-    {
-      const int qn = qt + 1 < nqt ? qt + 1 : qt;          // last iteration re-loads its own tile (harmless)
-      STAGE_LOAD(qn);
-    }
-    const char* qb = smem + buf * STAGE;
-    const char* dob = qb + TILE32;
-    const float* lse_s = reinterpret_cast<const float*>(qb + 2 * TILE32);
-    const float* del_s = lse_s + 32;
-
-    f32x16 sacc, dpacc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sacc[i] = 0.f; dpacc[i] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      sacc = mfma_bf16(lds_row_frag(qb, lr, s, lh), kf[s], sacc);        // S[q, key]
-      dpacc = mfma_bf16(lds_row_frag(dob, lr, s, lh), vf[s], dpacc);     // dP[q, key]
-    }
-    // rows of this lane's accumulator registers: q = acc_row(r, lh): 4 groups of 4 consecutive rows
-    const bool edge = (kp0 + 128 > n_prefix);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 8 * g + 4 * lh);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + 8 * g + 4 * lh);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = 4 * g + j;
-        float pv = fast_exp2(sacc[r] * c - l4[j]);
-        if (edge) {
-          const int qdec = qt * 32 + 8 * g + 4 * lh + j - p.dec_q0;
-          const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
-          pv = ok ? pv : 0.f;
-        }
-        sacc[r] = pv;
-        dpacc[r] = pv * (dpacc[r] - d4[j]);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 pf = acc_to_frag(sacc, s), dsf = acc_to_frag(dpacc, s);
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        dvacc[db] = mfma_bf16(lds_tr_frag(dob, 16 * s, db, lane), pf, dvacc[db]);   // dV^T[d, key] += dO^T[d, q] P[q, key]
-        dkacc[db] = mfma_bf16(lds_tr_frag(qb, 16 * s, db, lane), dsf, dkacc[db]);   // dK^T[d, key] += Q^T[d, q] dS[q, key]
-      }
-    }
-    STAGE_WRITE(buf ^ 1);
-    __syncthreads();
-  }
-#undef STAGE_LOAD
-#undef STAGE_WRITE
-
-  if (kvalid) {
-    bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs;
-    bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dv) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * lh;
-        bf16x4 k4 = {(bf16_t)(dkacc[db][4 * g] * p.scale), (bf16_t)(dkacc[db][4 * g + 1] * p.scale),
-                     (bf16_t)(dkacc[db][4 * g + 2] * p.scale), (bf16_t)(dkacc[db][4 * g + 3] * p.scale)};
-        bf16x4 v4 = {(bf16_t)dvacc[db][4 * g], (bf16_t)dvacc[db][4 * g + 1], (bf16_t)dvacc[db][4 * g + 2], (bf16_t)dvacc[db][4 * g + 3]};
-        *reinterpret_cast<bf16x4*>(dkp + d) = k4;
-        *reinterpret_cast<bf16x4*>(dvp + d) = v4;
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // dQ, bf16.
 template <bool USE_IDX>
 __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
@@ -552,13 +406,9 @@ extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const v
   dim3 gkv((max_keys + 127) / 128, H, B), gq((Lq + 127) / 128, H, B);
   if (dtype == T2S_BF16) {
     hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, gd, blk, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, H, Lq, o_row_stride, o_batch_stride);
-    if (kv_idx) {
-      hipLaunchKernelGGL(attn_dkdv_bf16_kernel<true>, gkv, blk, 0, st, p);
-      hipLaunchKernelGGL(attn_dq_bf16_kernel<true>, gq, blk, 0, st, p);
-    } else {
-      hipLaunchKernelGGL(attn_dkdv_bf16_kernel<false>, gkv, blk, 0, st, p);
-      hipLaunchKernelGGL(attn_dq_bf16_kernel<false>, gq, blk, 0, st, p);
-    }
+    launch_attn_dkdv_bf16(p, max_keys, st);
+    if (kv_idx) hipLaunchKernelGGL(attn_dq_bf16_kernel<true>, gq, blk, 0, st, p);
+    else hipLaunchKernelGGL(attn_dq_bf16_kernel<false>, gq, blk, 0, st, p);
   } else {
     hipLaunchKernelGGL(attn_delta_kernel<float>, gd, blk, 0, st, (const float*)out, (const float*)dout, delta, B, H, Lq, o_row_stride, o_batch_stride);
     if (kv_idx) {

@@ -71,6 +71,11 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// bf16 forward kernel lives in attn_fwd_bf16.hip
+void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st);
+// bf16 dK/dV kernel lives in attn_dkdv_bf16.hip
+void launch_attn_dkdv_bf16(const AttnParams& p, int max_keys, hipStream_t st);
+
 #define LOG2E 1.4426950408889634f
 
 // raw v_exp_f32 (one instruction; results below 2^-126 flush to 0, which is what a softmax wants)

@@ -1,0 +1,178 @@
+// dK / dV kernel of the bf16 flash-attention backward for gfx950 (design notes: attn_bwd.hip).
+//
+// Key-stationary: a workgroup = 4 waves = 128 keys of the compacted key list of one (batch, head);
+// each wave keeps dK^T and dV^T of its 32 keys in accumulators (key on the MFMA lane) and holds its K / V
+// rows as B-operand fragments in registers.  The workgroup sweeps the queries in tiles of 64 rows (two
+// 32-row sub-blocks per barrier: half the barriers per MFMA, and two independent exp / dS chains for the
+// scheduler to place beside the MFMAs) staged in LDS as Q and dO images plus LSE / delta vectors.
+//   S = Q K^T, dP = dO V^T            (A = row reads of the LDS tiles, B = register fragments)
+//   P = exp2(c S - LSE log2e), dS = P (dP - delta)
+//   dV^T += dO^T P, dK^T += Q^T dS    (A = ds_read_b64_tr_b16 reads of the same tiles, B = P / dS accumulators)
+#include "attn_common.h"
+
+namespace {
+
+constexpr int QROWS = 64;                         // query rows per iteration
+constexpr int TILE = QROWS * 128;                 // bytes of a 64-row bf16 tile
+constexpr int STAGE = 2 * TILE + 2 * QROWS * 4;   // Q | dO | lse | delta
+
+template <bool USE_IDX>
+__global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
+  const int nk = n_prefix + p.n_dec;
+  const int kp0 = blockIdx.x * 128;
+  if (kp0 >= nk) return;                                   // uniform per workgroup
+  const int kpos = kp0 + wave * 32 + lr;                   // this lane's key position (column)
+  const bool kvalid = kpos < nk;
+  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
+  const int kclamp = kvalid ? kpos : nk - 1;
+  const int64_t krow = USE_IDX ? (int64_t)idx[kclamp] : (int64_t)kclamp;
+  const bf16_t* __restrict__ Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* __restrict__ DO = reinterpret_cast<const bf16_t*>(p.dout) + (int64_t)b * p.o_bs + h * 64;
+  const float* __restrict__ LSE = p.lse + ((int64_t)b * p.H + h) * p.Lq;
+  const float* __restrict__ DELTA = p.delta + ((int64_t)b * p.H + h) * p.Lq;
+
+  // K / V fragments of this wave's 32 keys: B operands, lane (key = lr, half lh) holds [key][16s+8lh..]
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs + 8 * lh;
+    const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
+      vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s);
+    }
+  }
+  const int kdec = kpos - n_prefix;        // decoder step of this key (negative: prefix key)
+  const float c = p.scale * LOG2E;
+  const int nqt = (p.Lq + QROWS - 1) / QROWS;
+  const bool edge = (kp0 + 128 > n_prefix);
+
+  // staging: thread -> rows sr / sr+32, 16-B chunk sc of the Q and dO tiles; plain named registers and
+  // unconditional clamped loads (keeps the staging out of scratch memory)
+  const int sr = tid >> 3, sc = tid & 7;
+  const int lrow = tid & 63;
+  uint4 q0r, q1r, d0r, d1r;
+  float lreg, dreg;
+#define STAGE_LOAD(qt_)                                                                         \
+  {                                                                                             \
+    const int r0_ = (qt_) * QROWS + sr, r1_ = r0_ + 32;                                         \
+    const int c0_ = r0_ < p.Lq ? r0_ : p.Lq - 1, c1_ = r1_ < p.Lq ? r1_ : p.Lq - 1;             \
+    q0r = *reinterpret_cast<const uint4*>(Q + (int64_t)c0_ * p.q_rs + sc * 8);                  \
+    d0r = *reinterpret_cast<const uint4*>(DO + (int64_t)c0_ * p.o_rs + sc * 8);                 \
+    q1r = *reinterpret_cast<const uint4*>(Q + (int64_t)c1_ * p.q_rs + sc * 8);                  \
+    d1r = *reinterpret_cast<const uint4*>(DO + (int64_t)c1_ * p.o_rs + sc * 8);                 \
+    if (r0_ >= p.Lq) d0r = make_uint4(0, 0, 0, 0);                                              \
+    if (r1_ >= p.Lq) d1r = make_uint4(0, 0, 0, 0);                                              \
+    const int r2_ = (qt_) * QROWS + lrow;                                                       \
+    const int r2c_ = r2_ < p.Lq ? r2_ : p.Lq - 1;                                               \
+    const float l_ = LSE[r2c_] * LOG2E, dl_ = DELTA[r2c_];                                      \
+    lreg = r2_ < p.Lq ? l_ : INFINITY; /* +inf => P = 0 for rows past Lq */                     \
+    dreg = r2_ < p.Lq ? dl_ : 0.f;                                                              \
+  }
+#define STAGE_WRITE(buf_)                                                                       \
+  {                                                                                             \
+    char* base_ = smem + (buf_) * STAGE;                                                        \
+    *reinterpret_cast<uint4*>(base_ + tile_off(sr, sc)) = q0r;                                  \
+    *reinterpret_cast<uint4*>(base_ + TILE + tile_off(sr, sc)) = d0r;                           \
+    *reinterpret_cast<uint4*>(base_ + tile_off(sr + 32, sc)) = q1r;                             \
+    *reinterpret_cast<uint4*>(base_ + TILE + tile_off(sr + 32, sc)) = d1r;                      \
+    if (tid < QROWS) {                                                                          \
+      reinterpret_cast<float*>(base_ + 2 * TILE)[tid] = lreg;                                   \
+      reinterpret_cast<float*>(base_ + 2 * TILE + QROWS * 4)[tid] = dreg;                       \
+    }                                                                                           \
+  }
+
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
+
+  STAGE_LOAD(0);
+  STAGE_WRITE(0);
+  __syncthreads();
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int buf = qt & 1;
+    {
+      const int qn = qt + 1 < nqt ? qt + 1 : qt;          // last iteration re-loads its own tile (harmless)
+      STAGE_LOAD(qn);
+    }
+    const char* qb = smem + buf * STAGE;
+    const char* dob = qb + TILE;
+    const float* lse_s = reinterpret_cast<const float*>(qb + 2 * TILE);
+    const float* del_s = lse_s + QROWS;
+
+    f32x16 sacc[2], dpacc[2];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sacc[sb][i] = 0.f; dpacc[sb][i] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc[sb] = mfma_bf16(lds_row_frag(qb, sb * 32 + lr, s, lh), kf[s], sacc[sb]);        // S[q, key]
+        dpacc[sb] = mfma_bf16(lds_row_frag(dob, sb * 32 + lr, s, lh), vf[s], dpacc[sb]);     // dP[q, key]
+      }
+    }
+    // rows of this lane's accumulator registers: q = acc_row(r, lh): 4 groups of 4 consecutive rows
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + sb * 32 + 8 * g + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + sb * 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          float pv = fast_exp2(sacc[sb][r] * c - l4[j]);
+          if (edge) {
+            const int qdec = qt * QROWS + sb * 32 + 8 * g + 4 * lh + j - p.dec_q0;
+            const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
+            pv = ok ? pv : 0.f;
+          }
+          sacc[sb][r] = pv;
+          dpacc[sb][r] = pv * (dpacc[sb][r] - d4[j]);
+        }
+      }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = acc_to_frag(sacc[sb], s), dsf = acc_to_frag(dpacc[sb], s);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dvacc[db] = mfma_bf16(lds_tr_frag(dob, sb * 32 + 16 * s, db, lane), pf, dvacc[db]);   // dV^T[d,key] += dO^T[d,q] P[q,key]
+          dkacc[db] = mfma_bf16(lds_tr_frag(qb, sb * 32 + 16 * s, db, lane), dsf, dkacc[db]);   // dK^T[d,key] += Q^T[d,q] dS[q,key]
+        }
+      }
+    STAGE_WRITE(buf ^ 1);
+    __syncthreads();
+  }
+#undef STAGE_LOAD
+#undef STAGE_WRITE
+
+  if (kvalid) {
+    bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs;
+    bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dv) + (int64_t)b * p.kv_bs + h * 64 + krow * p.kv_rs;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * lh;
+        bf16x4 k4 = {(bf16_t)(dkacc[db][4 * g] * p.scale), (bf16_t)(dkacc[db][4 * g + 1] * p.scale),
+                     (bf16_t)(dkacc[db][4 * g + 2] * p.scale), (bf16_t)(dkacc[db][4 * g + 3] * p.scale)};
+        bf16x4 v4 = {(bf16_t)dvacc[db][4 * g], (bf16_t)dvacc[db][4 * g + 1], (bf16_t)dvacc[db][4 * g + 2], (bf16_t)dvacc[db][4 * g + 3]};
+        *reinterpret_cast<bf16x4*>(dkp + d) = k4;
+        *reinterpret_cast<bf16x4*>(dvp + d) = v4;
+      }
+  }
+}
+
+}  // namespace
+
+void launch_attn_dkdv_bf16(const AttnParams& p, int max_keys, hipStream_t st) {
+  dim3 grid((max_keys + 127) / 128, p.H, p.B), block(256);
+  if (p.kv_idx) hipLaunchKernelGGL(attn_dkdv_bf16_kernel<true>, grid, block, 0, st, p);
+  else hipLaunchKernelGGL(attn_dkdv_bf16_kernel<false>, grid, block, 0, st, p);
+}

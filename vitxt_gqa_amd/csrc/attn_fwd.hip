@@ -22,172 +22,6 @@ namespace {
 
 constexpr int BQ = 128;   // query rows per workgroup
 constexpr int BK = 64;    // keys per tile
-constexpr int TILE_BYTES = BK * 128;
-
-template <bool USE_IDX>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];   // [buf][K,V]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * BQ + wave * 32;
-  const int qrow = q0 + lr;
-  const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
-  const int nk = n_prefix + p.n_dec;
-  const int ntiles = (nk + BK - 1) / BK;
-  const bf16_t* __restrict__ Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_bs + h * 64;
-  const bf16_t* __restrict__ K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.kv_bs + h * 64;
-  const bf16_t* __restrict__ V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.kv_bs + h * 64;
-  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
-
-  // Q fragments: B operand of S^T = K Q^T; lane (q = lr, half lh) holds Q[q][16s + 8lh .. +7]
-  bf16x8 qf[4];
-  {
-    const int qr = qrow < p.Lq ? qrow : p.Lq - 1;
-    const bf16_t* qp = Q + (int64_t)qr * p.q_rs + 8 * lh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-  }
-
-  // staging: thread -> (row sr / sr+32, 16-B chunk sc) of the K and V tiles.  Plain named registers and
-  // unconditional (clamped) loads: arrays captured by a lambda or loads under a branch end up in scratch.
-  const int sr = tid >> 3, sc = tid & 7;
-  uint4 kr0, kr1, vr0, vr1;
-#define STAGE_LOAD(t_)                                                                              \
-  {                                                                                                 \
-    int p0_ = (t_) * BK + sr, p1_ = p0_ + 32;                                                       \
-    p0_ = p0_ < nk ? p0_ : nk - 1;                                                                  \
-    p1_ = p1_ < nk ? p1_ : nk - 1;                                                                  \
-    const int64_t r0_ = USE_IDX ? (int64_t)idx[p0_] : (int64_t)p0_;                                 \
-    const int64_t r1_ = USE_IDX ? (int64_t)idx[p1_] : (int64_t)p1_;                                 \
-    kr0 = *reinterpret_cast<const uint4*>(K + r0_ * p.kv_rs + sc * 8);                              \
-    vr0 = *reinterpret_cast<const uint4*>(V + r0_ * p.kv_rs + sc * 8);                              \
-    kr1 = *reinterpret_cast<const uint4*>(K + r1_ * p.kv_rs + sc * 8);                              \
-    vr1 = *reinterpret_cast<const uint4*>(V + r1_ * p.kv_rs + sc * 8);                              \
-  }
-#define STAGE_WRITE(buf_)                                                                           \
-  {                                                                                                 \
-    char* kb_ = smem + (buf_) * 2 * TILE_BYTES;                                                     \
-    *reinterpret_cast<uint4*>(kb_ + tile_off(sr, sc)) = kr0;                                        \
-    *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + tile_off(sr, sc)) = vr0;                           \
-    *reinterpret_cast<uint4*>(kb_ + tile_off(sr + 32, sc)) = kr1;                                   \
-    *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + tile_off(sr + 32, sc)) = vr1;                      \
-  }
-
-  f32x16 oacc[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
-  const float c = p.scale * LOG2E;
-  const int qdec = qrow - p.dec_q0;    // decoder step of this query row (negative: not a decoder row)
-
-  if (ntiles > 0) {
-    STAGE_LOAD(0);
-    STAGE_WRITE(0);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    {
-      const int tn = t + 1 < ntiles ? t + 1 : t;      // last iteration re-loads its own tile (harmless)
-      STAGE_LOAD(tn);
-    }
-    const char* kb = smem + buf * 2 * TILE_BYTES;
-    const char* vb = kb + TILE_BYTES;
-
-    f32x16 sacc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sacc[0][i] = 0.f; sacc[1][i] = 0.f; }
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) sacc[kbk] = mfma_bf16(lds_row_frag(kb, kbk * 32 + lr, s, lh), qf[s], sacc[kbk]);
-
-    // ---- online softmax over the 64 keys of this tile (this lane: 32 of them, partner lane^32 the rest)
-    const bool edge = (t * BK + BK > n_prefix);
-    float mx = -INFINITY;
-    if (edge) {
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int pos = t * BK + kbk * 32 + acc_row(r, lh);
-          const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
-          const float sv = ok ? sacc[kbk][r] : -INFINITY;
-          sacc[kbk][r] = sv;
-          mx = fmaxf(mx, sv);
-        }
-    } else {
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kbk][r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = fast_exp2((m_run - m_use) * c);
-    m_run = m_new;
-    const float mc = m_use * c;
-    float lsum = 0.f;
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = fast_exp2(sacc[kbk][r] * c - mc);
-        sacc[kbk][r] = pv;
-        lsum += pv;
-      }
-    l_run = l_run * alpha + lsum;
-    // the running max rarely moves after the first tiles: skip the O rescale when no row of the wave changed
-    if (!__all(alpha == 1.f)) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
-    }
-
-    // ---- O^T[d, q] += V^T[d, key] P^T[key, q]
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = acc_to_frag(sacc[kbk], s);
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-          oacc[db] = mfma_bf16(lds_tr_frag(vb, kbk * 32 + 16 * s, db, lane), pf, oacc[db]);
-      }
-
-    STAGE_WRITE(buf ^ 1);
-    __syncthreads();
-  }
-#undef STAGE_LOAD
-#undef STAGE_WRITE
-
-  // ---- epilogue: normalise, stage O through LDS (per-wave 32 x 64 tile, 144-B rows), store rows
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-  char* ob = smem + wave * (32 * 144);
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 t4 = {(bf16_t)(oacc[db][4 * g] * inv), (bf16_t)(oacc[db][4 * g + 1] * inv),
-                   (bf16_t)(oacc[db][4 * g + 2] * inv), (bf16_t)(oacc[db][4 * g + 3] * inv)};
-      const int d = db * 32 + 8 * g + 4 * lh;
-      *reinterpret_cast<bf16x4*>(ob + lr * 144 + d * 2) = t4;
-    }
-  __syncthreads();
-  bf16_t* __restrict__ O = reinterpret_cast<bf16_t*>(p.out) + (int64_t)b * p.o_bs + h * 64;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int id = i * 64 + lane, r = id >> 3, cc = id & 7;
-    if (q0 + r < p.Lq)
-      *reinterpret_cast<uint4*>(O + (int64_t)(q0 + r) * p.o_rs + cc * 8) = *reinterpret_cast<const uint4*>(ob + r * 144 + cc * 16);
-  }
-  if (lh == 0 && qrow < p.Lq) {
-    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-    p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_use * p.scale + logf(l_tot);
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // fp32 variant: same data flow on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains).  Used by the
@@ -384,8 +218,7 @@ extern "C" int t2s_attn_fwd(const void* q, const void* k, const void* v, void* o
   dim3 grid((Lq + BQ - 1) / BQ, H, B), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == T2S_BF16) {
-    if (kv_idx) hipLaunchKernelGGL(attn_fwd_bf16_kernel<true>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<false>, grid, block, 0, st, p);
+    launch_attn_fwd_bf16(p, st);
   } else {
     if (kv_idx) hipLaunchKernelGGL(attn_fwd_f32_kernel<true>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_f32_kernel<false>, grid, block, 0, st, p);
