@@ -108,6 +108,43 @@ int t2s_gelu_bwd_parts(int64_t rows);
 int t2s_gelu_bwd(const void* dy, const void* u, void* du, float* dbias_part, int64_t rows, int cols,
                  int dtype, t2s_stream_t stream);
 
+/* ---- OCR pointer-network scores (OcrPtrNet.forward t2s.py:648-670 + the concat of
+ * T2S._forward_output :279-286): out[b, j, col0 + n] = q[b,j] . k[b,n] * scale + mask01[b,n]
+ * (the RAW 0/1 mask is added).  q: [B, D, 768] fp32 (D <= 16 decoding steps), k: [B, N, 768] in
+ * k_dtype, mask: [B, N] fp32, out: fp32 rows of out_row_stride elements (the [B, D, V+N] logits
+ * buffer, col0 = V).  exact_fp32 != 0 selects the fp32-MFMA path (parity mode, fp32 keys). */
+int t2s_ptr_scores(const float* q, const void* k, const float* mask, float* out, int B, int D, int N,
+                   int64_t out_row_stride, int col0, float scale, int k_dtype, int exact_fp32,
+                   t2s_stream_t stream);
+
+/* ---- grounding scorers and selection (forward only: no gradient reaches them).
+ * t2s_question_pool: Grounding_Module._calculate_self_attn t2s.py:453-459 on the already projected
+ *   question qp = q_linear(txt_emb) [B, T, 768] fp32: att = softmax(qp.w + bias) over all T, * qmask,
+ *   / (sum + 1e-12); out[b] = sum_t att[t] qp[b, t]  -> [B, 768].
+ * t2s_attention_score: AttentionScore.forward spatio_temporal_grounding.py:15-23:
+ *   score = softmax_M(q . k^T) * mask / (sum + 1e-12), -10000 where mask == 0.  k: [B, M, 768]. */
+int t2s_question_pool(const float* qp, const float* w, const float* bias, const float* qmask, float* out,
+                      int B, int T, t2s_stream_t stream);
+int t2s_attention_score(const float* q, const void* k, const float* mask, float* score, int B, int M,
+                        int k_dtype, t2s_stream_t stream);
+
+/* t2s_ground_select: Temporal_Grounding_Indicator.forward (spatio_temporal_grounding.py:34-68),
+ * Grounding_Module.forward t2s.py:486-494 and Spatial_Grounding_Indicator.forward (:79-142) in one
+ * call.  Inputs: frame_score [B, F] (t2s_attention_score over the frames), frame_mask [B, F] fp32,
+ * expo_frame [B, 2, F] / expo_ocr [B, 2, F*P]: the exponential draws of the two gumbel_softmax
+ * calls (injected by the caller; noise = -log(expo)), frame_id [B, F] / temporal_id [B, F*P] int64,
+ * q_global [B, 768], ocr_feat [B, F*P, 768] (ocr_dtype), bbox [B, F*P, 4].
+ * Outputs: pos/neg_obj_mask [B, F], ground_frame [B, frame_topk] int64 (frame ids, ascending frame
+ * index), new_ocr_mask / ocr_score / pos_ocr_mask / neg_ocr_mask [B, F*P], ground_box
+ * [B, F*ocr_topk, 4].  Ties among equal scores go to the LOWEST index (the reference's ATen order is
+ * implementation defined). */
+int t2s_ground_select(const float* frame_score, const float* frame_mask, const float* expo_frame,
+                      const int64_t* frame_id, const float* q_global, const void* ocr_feat, int ocr_dtype,
+                      const float* expo_ocr, const int64_t* temporal_id, const float* bbox,
+                      float* pos_obj_mask, float* neg_obj_mask, int64_t* ground_frame, float* new_ocr_mask,
+                      float* ocr_score, float* pos_ocr_mask, float* neg_ocr_mask, float* ground_box,
+                      int B, int F, int P, int frame_topk, int ocr_topk, t2s_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

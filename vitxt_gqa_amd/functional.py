@@ -121,6 +121,39 @@ def layer_norm(x, gamma, beta, res=None):
     return LayerNormFn.apply(x, res, gamma, beta)
 
 
+class PtrLogitsFn(torch.autograd.Function):
+    """logits = cat([fixed, q.k^T/sqrt(768) + mask01], -1)  (T2S._forward_output t2s.py:279-286 with
+    OcrPtrNet.forward :648-670).  fixed: [B, D, V] fp32 classifier scores; q: [B, D, 768] fp32; k: [B, N, 768]
+    operand dtype; mask01: [B, N] fp32.  The pointer scores are written by the HIP kernel straight into the
+    concatenated buffer."""
+
+    @staticmethod
+    def forward(ctx, fixed, q, k, mask01):
+        B, D, V = fixed.shape
+        N = k.shape[1]
+        logits = torch.empty(B, D, V + N, dtype=torch.float32, device=fixed.device)
+        logits[:, :, :V] = fixed
+        ops.ptr_scores(q.contiguous(), k.contiguous(), mask01, logits, V, exact_fp32=(k.dtype == F32))
+        ctx.save_for_backward(q, k)
+        ctx.V = V
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        q, k = ctx.saved_tensors
+        V = ctx.V
+        scale = 1.0 / (HID ** 0.5)
+        ds = dlogits[:, :, V:]                                            # [B, D, N] fp32
+        dsl = (ds * scale).to(k.dtype)
+        dq = torch.bmm(dsl, k).float()                                    # [B, D, 768]
+        dk = torch.bmm(dsl.transpose(1, 2), q.to(k.dtype))                # [B, N, 768]
+        return dlogits[:, :, :V], dq, dk, None
+
+
+def ptr_logits(fixed, q, k, mask01):
+    return PtrLogitsFn.apply(fixed, q, k, mask01)
+
+
 def bert_layer(x, x_lo, keys, lp, dtype):
     """lp: a module holding one layer's parameters under the reference's names (see t2s.BertLayerParams).
     Returns (y fp32, y_lo operand dtype)."""

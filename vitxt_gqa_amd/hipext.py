@@ -28,6 +28,10 @@ _SIGS = {
     "t2s_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "t2s_gelu_bwd_parts": (c_int, [c_int64]),
     "t2s_gelu_bwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
+    "t2s_ptr_scores": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64, c_int, c_float, c_int, c_int, c_void_p]),
+    "t2s_question_pool": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "t2s_attention_score": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
+    "t2s_ground_select": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
 }
 
 _lib = None

@@ -147,3 +147,64 @@ def gelu_bwd(dy, u):
     X.check(X.lib().t2s_gelu_bwd(X.ptr(dy), X.ptr(u), X.ptr(du), X.ptr(dbp), rows, cols, X.dtype_code(u), X.stream()),
             "t2s_gelu_bwd")
     return du, dbp.sum(0)
+
+
+def ptr_scores(q, k, mask01, out, col0, exact_fp32=False):
+    """out[b, j, col0 + n] = q[b,j].k[b,n]/sqrt(768) + mask01[b,n] written in place into the logits buffer
+    out [B, D, V+N] fp32.  q: [B, D, 768] fp32; k: [B, N, 768] bf16/fp32; mask01: [B, N] fp32."""
+    B, D, _ = q.shape
+    N = k.shape[1]
+    assert q.dtype == torch.float32 and q.is_contiguous() and q.shape[2] == HID
+    assert k.is_contiguous() and k.shape == (B, N, HID) and mask01.shape == (B, N) and mask01.dtype == torch.float32
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[:2] == (B, D) and out.shape[2] >= col0 + N
+    X.check(X.lib().t2s_ptr_scores(X.ptr(q), X.ptr(k), X.ptr(mask01.contiguous()), X.ptr(out), B, D, N, out.shape[2], col0,
+                                   1.0 / math.sqrt(HID), X.dtype_code(k), 1 if exact_fp32 else 0, X.stream()), "t2s_ptr_scores")
+    return out
+
+
+def question_pool(qp, w, bias, qmask):
+    """qp: [B, T, 768] fp32 projected question -> [B, 768] (t2s.py:453-459)."""
+    B, T, _ = qp.shape
+    assert qp.dtype == torch.float32 and qp.is_contiguous() and w.numel() == HID and qmask.shape == (B, T)
+    out = torch.empty(B, HID, dtype=torch.float32, device=qp.device)
+    X.check(X.lib().t2s_question_pool(X.ptr(qp), X.ptr(w.contiguous()), X.ptr(bias), X.ptr(qmask.float().contiguous()),
+                                      X.ptr(out), B, T, X.stream()), "t2s_question_pool")
+    return out
+
+
+def attention_score(q, k, mask):
+    """q: [B, 768] fp32, k: [B, M, 768], mask: [B, M] fp32 -> [B, M] fp32 (spatio_temporal_grounding.py:15-23)."""
+    B, M, _ = k.shape
+    assert q.shape == (B, HID) and q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous()
+    assert mask.shape == (B, M) and mask.dtype == torch.float32 and mask.is_contiguous()
+    score = torch.empty(B, M, dtype=torch.float32, device=k.device)
+    X.check(X.lib().t2s_attention_score(X.ptr(q), X.ptr(k), X.ptr(mask), X.ptr(score), B, M, X.dtype_code(k), X.stream()),
+            "t2s_attention_score")
+    return score
+
+
+def ground_select(frame_score, frame_mask, expo_frame, frame_id, q_global, ocr_feat, expo_ocr, temporal_id, bbox,
+                  F, P, frame_topk, ocr_topk):
+    """Temporal + spatial grounding selection (see include/t2s_hip.h).  Returns a dict of masks / outputs."""
+    B = frame_score.shape[0]
+    N = F * P
+    dev = frame_score.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    assert frame_score.shape == (B, F) and frame_mask.shape == (B, F) and expo_frame.shape == (B, 2, F)
+    assert expo_ocr.shape == (B, 2, N) and ocr_feat.shape == (B, N, HID) and bbox.shape == (B, N, 4)
+    assert frame_id.dtype == torch.int64 and temporal_id.dtype == torch.int64 and temporal_id.shape == (B, N)
+    for t in (frame_score, frame_mask, expo_frame, expo_ocr, q_global, bbox):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert ocr_feat.is_contiguous() and frame_id.is_contiguous() and temporal_id.is_contiguous()
+    o = dict(pos_obj_mask=torch.empty(B, F, **f32), neg_obj_mask=torch.empty(B, F, **f32),
+             ground_frame=torch.empty(B, frame_topk, dtype=torch.int64, device=dev),
+             new_ocr_mask=torch.empty(B, N, **f32), ocr_score=torch.empty(B, N, **f32),
+             pos_ocr_mask=torch.empty(B, N, **f32), neg_ocr_mask=torch.empty(B, N, **f32),
+             ground_box=torch.empty(B, F * ocr_topk, 4, **f32))
+    X.check(X.lib().t2s_ground_select(
+        X.ptr(frame_score), X.ptr(frame_mask), X.ptr(expo_frame), X.ptr(frame_id), X.ptr(q_global), X.ptr(ocr_feat),
+        X.dtype_code(ocr_feat), X.ptr(expo_ocr), X.ptr(temporal_id), X.ptr(bbox), X.ptr(o["pos_obj_mask"]),
+        X.ptr(o["neg_obj_mask"]), X.ptr(o["ground_frame"]), X.ptr(o["new_ocr_mask"]), X.ptr(o["ocr_score"]),
+        X.ptr(o["pos_ocr_mask"]), X.ptr(o["neg_ocr_mask"]), X.ptr(o["ground_box"]), B, F, P, frame_topk, ocr_topk,
+        X.stream()), "t2s_ground_select")
+    return o

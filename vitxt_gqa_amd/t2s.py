@@ -125,30 +125,6 @@ class _AttentionScoreParams(nn.Module):
         self.linear_k = nn.Linear(hidden, hidden)
 
 
-def attention_score(q, k, attn_mask):
-    """spatio_temporal_grounding.py:15-23 (Q7)."""
-    a = torch.bmm(q, k.transpose(-2, -1)).squeeze(1)
-    a = torch.softmax(a, dim=-1) * attn_mask
-    a = a / (a.sum(dim=-1, keepdim=True) + 1e-12)
-    return torch.where(attn_mask == 0, torch.full_like(a, -10000.0), a)
-
-
-def _gumbel_split(score, expo):
-    """2-way hard gumbel-softmax over identical pos/neg scores (Q8): argmax of noise, tie -> pos."""
-    g = -torch.log(expo)
-    pos = (g[:, 0] >= g[:, 1]).to(score.dtype)
-    # the reference adds the SAME score to both rows; in floating point (s+g0) >= (s+g1) can differ from
-    # g0 >= g1 only through rounding of the sum, so evaluate exactly what the reference evaluates:
-    y = torch.stack([score, score], dim=1) + g
-    pos = (y.argmax(dim=1) == 0).to(score.dtype)
-    return pos, 1.0 - pos
-
-
-def _topk_lowest_index(score, k, largest):
-    key = -score if largest else score
-    return torch.sort(key, dim=-1, stable=True).indices[..., :k]
-
-
 class Grounding_Module(nn.Module):
     """t2s.py:434-518 + spatio_temporal_grounding.py (forward only: nothing here receives gradients)."""
 
@@ -183,45 +159,22 @@ class Grounding_Module(nn.Module):
         else:
             e1, e2 = noise[0].to(ocr_feat.device).float(), noise[1].to(ocr_feat.device).float()
 
-        # question pooling, t2s.py:453-459,472-473 (Q6)
-        qp = F.linear(q_feat, self.q_linear.weight, self.q_linear.bias)
-        a = torch.softmax(F.linear(qp, self.self_attn.weight, self.self_attn.bias).squeeze(-1), dim=-1) * q_mask
-        a = a / (a.sum(1, keepdim=True) + 1e-12)
-        gq = torch.bmm(a.unsqueeze(1), qp)
+        # question pooling, t2s.py:453-459,472-473 (Q6): projection = library GEMM, pooling = HIP kernel
+        qp = F.linear(q_feat, self.q_linear.weight, self.q_linear.bias).contiguous()
+        gq = ops.question_pool(qp, self.self_attn.weight.view(-1), self.self_attn.bias, q_mask)           # [B, 768]
 
-        # stage 1: temporal grounding (spatio_temporal_grounding.py:34-68)
-        f_score = attention_score(gq, frame_feat, frame_mask)
-        pos_m, neg_m = _gumbel_split(f_score, e1)
-        pos_m, neg_m = pos_m * frame_mask, neg_m * frame_mask
-        pos_s = torch.where(pos_m == 0, torch.full_like(f_score, -10000.0), f_score * pos_m)
-        neg_s = torch.where(neg_m == 0, torch.full_like(f_score, -10000.0), f_score * neg_m)
-        k = self.frame_topk
-        pos_top = torch.zeros_like(f_score).scatter_(1, _topk_lowest_index(pos_s, k, True), 1.0)
-        neg_top = torch.zeros_like(f_score).scatter_(1, _topk_lowest_index(neg_s, k, False), 1.0)
-        pos_f = torch.sort(torch.sort(pos_top, dim=1, descending=True, stable=True).indices[:, :k], dim=1).values
-        ground_frame = torch.gather(sample_list.frame_id, 1, pos_f)
-        ground_frame_mask, neg_frame_mask = pos_top * frame_mask, neg_top * frame_mask
-
-        # stage 2: spatial grounding (t2s.py:486-494, spatio_temporal_grounding.py:79-142)
-        gfix = torch.where(ground_frame == 0, torch.ones_like(ground_frame), ground_frame)
-        new_mask = torch.eq(sample_list.temporal_id.unsqueeze(1), gfix.unsqueeze(-1)).any(dim=1).float()
-        o_score = attention_score(gq, ocr_feat, new_mask)
-        opos_m, oneg_m = _gumbel_split(o_score, e2)
-        opos_m, oneg_m = opos_m * new_mask, oneg_m * new_mask
-        opos_s = torch.where(opos_m == 0, torch.full_like(o_score, -10000.0), o_score * opos_m)
-        oneg_s = torch.where(oneg_m == 0, torch.full_like(o_score, -10000.0), o_score * oneg_m)
-        P, ot = self.frame_ocr_num, self.ocr_topk
-        assert N == self.frame_num * P, "OCR slots must equal frame_num * ocr_frame_num"
-        opos_top = torch.zeros(B, self.frame_num, P, device=o_score.device).scatter_(
-            2, _topk_lowest_index(opos_s.view(B, self.frame_num, P), ot, True), 1.0).view(B, -1)
-        oneg_top = torch.zeros(B, self.frame_num, P, device=o_score.device).scatter_(
-            2, _topk_lowest_index(oneg_s.view(B, self.frame_num, P), ot, False), 1.0).view(B, -1) * new_mask
-        # ground_ocr_box = masked_select(bbox, pos mask) -> [B, frame_num*ocr_topk, 4]: ascending slot order
-        sel = torch.sort(torch.sort(opos_top, dim=1, descending=True, stable=True).indices[:, :self.frame_num * ot], dim=1).values
-        ground_box = torch.gather(sample_list.ocr_bbox_coordinates, 1, sel.unsqueeze(-1).expand(-1, -1, 4))
-
-        masks = dict(pos_obj_mask=ground_frame_mask, neg_obj_mask=neg_frame_mask,
-                     pos_ocr_mask=opos_top, neg_ocr_mask=oneg_top)
+        # stage 1 + 2: temporal scorer, gumbel split, frame top-k, OCR slots of the grounded frames, spatial
+        # scorer, per-frame OCR top-k, boxes (spatio_temporal_grounding.py:15-142, t2s.py:486-494) on the HIP kernels
+        P, ot, k = self.frame_ocr_num, self.ocr_topk, self.frame_topk
+        assert Fn == self.frame_num and N == self.frame_num * P, "OCR slots must equal frame_num * ocr_frame_num"
+        f_score = ops.attention_score(gq, frame_feat.contiguous(), frame_mask.contiguous())
+        sel = ops.ground_select(f_score, frame_mask.contiguous(), e1.contiguous(), sample_list.frame_id.contiguous(), gq,
+                                ocr_feat.contiguous(), e2.contiguous(), sample_list.temporal_id.contiguous(),
+                                sample_list.ocr_bbox_coordinates.float().contiguous(), Fn, P, k, ot)
+        ground_frame, ground_box = sel["ground_frame"], sel["ground_box"]
+        o_score, new_mask = sel["ocr_score"], sel["new_ocr_mask"]
+        masks = dict(pos_obj_mask=sel["pos_obj_mask"], neg_obj_mask=sel["neg_obj_mask"],
+                     pos_ocr_mask=sel["pos_ocr_mask"], neg_ocr_mask=sel["neg_ocr_mask"])
         inject = sample_list.get("grounding_masks", None)
         if inject is not None:
             masks.update({k_: v.to(ocr_feat.device).float() for k_, v in inject.items() if k_ in masks})
@@ -306,8 +259,7 @@ class OcrPtrNet(nn.Module):
         # 12 query rows per sample: fp32 GEMM (tiny); N key rows per sample: operand-dtype GEMM
         q = F.linear(query_inputs, self.query.weight, self.query.bias)
         k = F.linear(key_inputs.to(dtype), self.key.weight.to(dtype), self.key.bias.to(dtype))
-        scores = torch.matmul(q, k.float().transpose(-1, -2)) / math.sqrt(self.query_key_size)
-        return scores + attention_mask.float().unsqueeze(1)
+        return q, k                      # scored by the HIP pointer kernel inside T2S._forward_output
 
 
 class _Classifier(nn.Module):
@@ -417,7 +369,8 @@ class T2S(BaseModel):
 
     def _forward_output(self, ocr_out, dec_out, mask, dt):
         fixed = F.linear(dec_out, self.classifier.module.weight, self.classifier.module.bias)      # fp32, 12 rows/sample
-        return torch.cat([fixed, self.ocr_ptr_net(dec_out, ocr_out, mask, dt)], dim=-1)
+        q, k = self.ocr_ptr_net(dec_out, ocr_out, mask, dt)
+        return FN.ptr_logits(fixed, q, k, mask.float())
 
     def _three_pass(self, fwd, prev_inds, dt):
         g = self.Grounding_Module
