@@ -145,6 +145,30 @@ int t2s_ground_select(const float* frame_score, const float* frame_mask, const f
                       float* ocr_score, float* pos_ocr_mask, float* neg_ocr_mask, float* ground_box,
                       int B, int F, int P, int frame_topk, int ocr_topk, t2s_stream_t stream);
 
+/* ---- feature-row embedding (T2S._forward_obj_encoding / _forward_ocr_encoding t2s.py:192-258 up to
+ * the Linear): out[row] = [ f0[row]/max(||f0[row]||,1e-12) | f1[row]/max(||f1[row]||,1e-12) |
+ * emb0[id0[row]] | emb1[id1[row]] ] in out_dtype with row stride ld_out.  f0: [rows, d0] fp32,
+ * f1: [rows, d1] fp32 or NULL (d1 = 0), id*: [rows] int64 or NULL, emb*: [emb_rows, emb_dim] fp32.
+ * Frames: f0 = video_feat (1024), id0 = frame_id.  OCR: f0 = fastText (300), f1 = PHOC (604),
+ * id0 = temporal_id, id1 = track_id. */
+int t2s_embed_rows(const float* f0, int d0, const float* f1, int d1, const int64_t* id0, const float* emb0,
+                   const int64_t* id1, const float* emb1, int emb_dim, int emb_rows, void* out, int ld_out,
+                   int64_t rows, int out_dtype, t2s_stream_t stream);
+
+/* ---- losses (pythia/modules/losses.py).
+ * t2s_bce_masked: POSBCEWithMaskLoss.forward :329-343.  scores/targets/grad: [rows, cols] fp32,
+ *   row_mask: [rows]; row_loss[r] = mask[r] * sum_c BCEWithLogits(x, t); grad = (sigmoid(x)-t)*mask[r]
+ *   (the caller divides by max(sum(mask), 1)).
+ * t2s_infonce_stats / t2s_infonce_bwd: InfoNCE.forward :361-385.  q/p/n = ref/pos/neg logits
+ *   [rows, cols] fp32; stats[r] = (q.q, p.p, n.n, q.p, q.n); given gstats = dLoss/dstats the
+ *   backward writes dq = 2 g0 q + g3 p + g4 n, dp = 2 g1 p + g3 q, dn = 2 g2 n + g4 q. */
+int t2s_bce_masked(const float* scores, const float* targets, const float* row_mask, float* row_loss,
+                   float* grad, int64_t rows, int cols, t2s_stream_t stream);
+int t2s_infonce_stats(const float* q, const float* p, const float* n, float* stats, int64_t rows, int cols,
+                      t2s_stream_t stream);
+int t2s_infonce_bwd(const float* q, const float* p, const float* n, const float* gstats, float* dq, float* dp,
+                    float* dn, int64_t rows, int cols, t2s_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,3 +121,61 @@ def test_ground_select_matches_oracle_rule(B, F, P):
     assert sel["ground_box"].shape == (B, 5 * F, 4)
     if same == 1.0:
         assert torch.equal(sel["ground_box"].cpu(), box)
+
+
+def test_embed_rows():
+    _need_gpu()
+    from vitxt_gqa_amd import functional as FN
+    g = torch.Generator().manual_seed(3)
+    B, N = 2, 37
+    f0 = torch.randn(B, N, 300, generator=g)
+    f1 = (torch.rand(B, N, 604, generator=g) < 0.1).float()
+    f1[0, 0] = 0                                             # all-zero PHOC row: x / max(||x||, 1e-12) = 0
+    id0 = torch.randint(0, 4000, (B, N), generator=g)
+    id1 = torch.randint(0, 50, (B, N), generator=g)
+    e0 = torch.randn(4000, 50, generator=g)
+    e1 = torch.randn(4000, 50, generator=g)
+    ref = torch.cat([O.l2_normalize(f0.double()), O.l2_normalize(f1.double()), e0.double()[id0], e1.double()[id1]], -1)
+    e0g, e1g = e0.to(DEV).requires_grad_(True), e1.to(DEV).requires_grad_(True)
+    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+        out = FN.embed_rows(f0.to(DEV), f1.to(DEV), id0.to(DEV), e0g, id1.to(DEV), e1g, dt)
+        assert out.dtype == dt and out.shape == (B, N, 1004)
+        assert (out.double().cpu() - ref).abs().max().item() < tol
+    gout = torch.randn(B, N, 1004, generator=g)
+    out.float().backward(gout.to(DEV))
+    r0 = torch.zeros(4000, 50).index_add_(0, id0.reshape(-1), gout.reshape(-1, 1004)[:, 904:954])
+    r1 = torch.zeros(4000, 50).index_add_(0, id1.reshape(-1), gout.reshape(-1, 1004)[:, 954:1004])
+    assert (e0g.grad.cpu() - r0).abs().max().item() < 2e-2 and (e1g.grad.cpu() - r1).abs().max().item() < 2e-2
+    # frames: single feature + single id table
+    v = torch.randn(B, 5, 1024, generator=g)
+    fid = torch.arange(1, 6).repeat(B, 1)
+    o2 = FN.embed_rows(v.to(DEV), None, fid.to(DEV), e0g, None, None, torch.float32)
+    assert (o2.double().cpu() - torch.cat([O.l2_normalize(v.double()), e0.double()[fid]], -1)).abs().max().item() < 1e-6
+
+
+def test_losses_match_oracle():
+    _need_gpu()
+    from vitxt_gqa_amd import SampleList
+    from vitxt_gqa_amd.losses import POSBCEWithMaskLoss, InfoNCE
+    g = torch.Generator().manual_seed(4)
+    B, D, C = 3, 12, 1601
+    ref, pos, neg = [torch.randn(B, D, C, generator=g) * 2 for _ in range(3)]
+    targets = (torch.rand(B, D, C, generator=g) < 0.01).float()
+    mask = (torch.rand(B, D, generator=g) < 0.7).float()
+    rd, pd, nd = [t.double().requires_grad_(True) for t in (ref, pos, neg)]
+    l_ref, a_ref, b_ref = O.total_loss(dict(ref_scores=rd, pos_scores=pd, neg_scores=nd), targets.double(), mask.double())
+    g_ref = torch.autograd.grad(l_ref, (rd, pd, nd))
+    rg, pg, ng = [t.to(DEV).requires_grad_(True) for t in (ref, pos, neg)]
+    s = SampleList({"targets": targets.to(DEV), "train_loss_mask": mask.to(DEV)})
+    out = {"ref_scores": rg, "pos_scores": pg, "neg_scores": ng}
+    a = POSBCEWithMaskLoss()(s, out)
+    b = InfoNCE()(s, out)
+    assert abs(a.item() - a_ref.item()) < 1e-4 * abs(a_ref.item())
+    assert abs(1000 * b.item() - b_ref.item()) < 1e-3 * abs(b_ref.item()) + 1e-4
+    (a + 1000 * b).backward()
+    for got, want in zip((rg, pg, ng), g_ref):
+        sc = want.abs().max().item()
+        assert (got.grad.double().cpu() - want).abs().max().item() < 1e-4 * sc + 1e-9
+    # all-zero mask: count clamps to 1, loss 0
+    s0 = SampleList({"targets": targets.to(DEV), "train_loss_mask": torch.zeros(B, D, device=DEV)})
+    assert POSBCEWithMaskLoss()(s0, out).item() == 0.0

@@ -150,6 +150,36 @@ class PtrLogitsFn(torch.autograd.Function):
         return dlogits[:, :, :V], dq, dk, None
 
 
+class EmbedRowsFn(torch.autograd.Function):
+    """[ L2norm(f0) | L2norm(f1) | emb0[id0] | emb1[id1] ] as the GEMM operand (t2s.py:192-258).  The features are
+    inputs (no gradient); the id-embedding tables receive index-add gradients."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, id0, emb0, id1, emb1, dtype):
+        out = ops.embed_rows(f0.float().contiguous(), f1.float().contiguous() if f1 is not None else None,
+                             id0.contiguous(), emb0, id1.contiguous() if id1 is not None else None, emb1, dtype)
+        ctx.save_for_backward(id0, id1 if id1 is not None else id0)
+        ctx.has1 = id1 is not None
+        ctx.d = f0.shape[-1] + (f1.shape[-1] if f1 is not None else 0)
+        ctx.shape0 = emb0.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        id0, id1 = ctx.saved_tensors
+        d, e = ctx.d, ctx.shape0[1]
+        g2 = g.reshape(-1, g.shape[-1])
+        ge0 = torch.zeros(ctx.shape0, dtype=F32, device=g.device).index_add_(0, id0.reshape(-1), g2[:, d:d + e].float())
+        ge1 = None
+        if ctx.has1:
+            ge1 = torch.zeros(ctx.shape0, dtype=F32, device=g.device).index_add_(0, id1.reshape(-1), g2[:, d + e:d + 2 * e].float())
+        return None, None, None, ge0, None, ge1, None
+
+
+def embed_rows(f0, f1, id0, emb0, id1, emb1, dtype):
+    return EmbedRowsFn.apply(f0, f1, id0, emb0, id1, emb1, dtype)
+
+
 def ptr_logits(fixed, q, k, mask01):
     return PtrLogitsFn.apply(fixed, q, k, mask01)
 

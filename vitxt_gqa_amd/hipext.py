@@ -32,6 +32,10 @@ _SIGS = {
     "t2s_question_pool": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "t2s_attention_score": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
     "t2s_ground_select": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
+    "t2s_embed_rows": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "t2s_bce_masked": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),
+    "t2s_infonce_stats": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p]),
+    "t2s_infonce_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_void_p]),
 }
 
 _lib = None

@@ -208,3 +208,56 @@ def ground_select(frame_score, frame_mask, expo_frame, frame_id, q_global, ocr_f
         X.ptr(o["pos_ocr_mask"]), X.ptr(o["neg_ocr_mask"]), X.ptr(o["ground_box"]), B, F, P, frame_topk, ocr_topk,
         X.stream()), "t2s_ground_select")
     return o
+
+
+def embed_rows(f0, f1, id0, emb0, id1, emb1, out_dtype):
+    """[ L2norm(f0) | L2norm(f1) | emb0[id0] | emb1[id1] ] -> [..., d0 + d1 + 50k] in out_dtype (t2s.py:192-258)."""
+    lead = f0.shape[:-1]
+    rows = f0.numel() // f0.shape[-1]
+    d0 = f0.shape[-1]
+    d1 = f1.shape[-1] if f1 is not None else 0
+    edim = emb0.shape[1] if emb0 is not None else 0
+    width = d0 + d1 + (edim if id0 is not None else 0) + (edim if id1 is not None else 0)
+    assert f0.dtype == torch.float32 and f0.is_contiguous() and (f1 is None or (f1.dtype == torch.float32 and f1.is_contiguous()))
+    for ids, emb in ((id0, emb0), (id1, emb1)):
+        if ids is not None:
+            assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == rows
+            assert emb.dtype == torch.float32 and emb.is_contiguous() and emb.shape[1] == edim
+    out = torch.empty(*lead, width, dtype=out_dtype, device=f0.device)
+    X.check(X.lib().t2s_embed_rows(X.ptr(f0), d0, X.ptr(f1), d1, X.ptr(id0), X.ptr(emb0), X.ptr(id1), X.ptr(emb1), edim,
+                                   emb0.shape[0] if emb0 is not None else 1, X.ptr(out), width, rows, X.dtype_code(out),
+                                   X.stream()), "t2s_embed_rows")
+    return out
+
+
+def bce_masked(scores, targets, row_mask):
+    """Returns (row_loss [rows], grad [rows, cols]) -- see include/t2s_hip.h."""
+    cols = scores.shape[-1]
+    rows = scores.numel() // cols
+    assert scores.dtype == torch.float32 and targets.dtype == torch.float32 and scores.is_contiguous() and targets.is_contiguous()
+    assert targets.shape == scores.shape and row_mask.numel() == rows and row_mask.dtype == torch.float32
+    row_loss = torch.empty(rows, dtype=torch.float32, device=scores.device)
+    grad = torch.empty_like(scores)
+    X.check(X.lib().t2s_bce_masked(X.ptr(scores), X.ptr(targets), X.ptr(row_mask.contiguous()), X.ptr(row_loss), X.ptr(grad),
+                                   rows, cols, X.stream()), "t2s_bce_masked")
+    return row_loss, grad
+
+
+def infonce_stats(q, p, n):
+    cols = q.shape[-1]
+    rows = q.numel() // cols
+    for t in (q, p, n):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == q.shape
+    stats = torch.empty(rows, 5, dtype=torch.float32, device=q.device)
+    X.check(X.lib().t2s_infonce_stats(X.ptr(q), X.ptr(p), X.ptr(n), X.ptr(stats), rows, cols, X.stream()), "t2s_infonce_stats")
+    return stats
+
+
+def infonce_bwd(q, p, n, gstats):
+    cols = q.shape[-1]
+    rows = q.numel() // cols
+    assert gstats.shape == (rows, 5) and gstats.dtype == torch.float32 and gstats.is_contiguous()
+    dq, dp, dn = torch.empty_like(q), torch.empty_like(p), torch.empty_like(n)
+    X.check(X.lib().t2s_infonce_bwd(X.ptr(q), X.ptr(p), X.ptr(n), X.ptr(gstats), X.ptr(dq), X.ptr(dp), X.ptr(dn), rows, cols,
+                                    X.stream()), "t2s_infonce_bwd")
+    return dq, dp, dn

@@ -348,7 +348,7 @@ class T2S(BaseModel):
 
     def _forward_obj_encoding(self, s, fwd, dt):
         assert s.video_feat.size(-1) == 1024
-        x = torch.cat([F.normalize(s.video_feat.float(), dim=-1), self.frame_embeddings(s.frame_id)], dim=-1).to(dt)
+        x = FN.embed_rows(s.video_feat, None, s.frame_id, self.frame_embeddings.weight, None, None, dt)
         y = F.linear(x, self.linear_obj_feat_to_mmt_in.weight.to(dt), self.linear_obj_feat_to_mmt_in.bias.to(dt))
         y = FN.layer_norm(y, self.obj_feat_layer_norm.weight, self.obj_feat_layer_norm.bias)
         fwd["obj_mmt_in"] = self._drop(y, self.obj_drop_p)
@@ -356,9 +356,8 @@ class T2S(BaseModel):
 
     def _forward_ocr_encoding(self, s, fwd, dt):
         assert s.context_feature_0.size(-1) == 300 and s.context_feature_1.size(-1) == 604
-        x = torch.cat([F.normalize(s.context_feature_0.float(), dim=-1), F.normalize(s.context_feature_1.float(), dim=-1),
-                       self.temporal_position_embeddings(s.temporal_id), self.track_position_embeddings(s.track_id)],
-                      dim=-1).to(dt)
+        x = FN.embed_rows(s.context_feature_0, s.context_feature_1, s.temporal_id, self.temporal_position_embeddings.weight,
+                          s.track_id, self.track_position_embeddings.weight, dt)
         a = F.linear(x, self.linear_ocr_feat_to_mmt_in.weight.to(dt), self.linear_ocr_feat_to_mmt_in.bias.to(dt))
         a = FN.layer_norm(a, self.ocr_feat_layer_norm.weight, self.ocr_feat_layer_norm.bias)
         b = F.linear(s.ocr_bbox_coordinates.float(), self.linear_ocr_bbox_to_mmt_in.weight,
