@@ -18,6 +18,9 @@ from . import ops
 
 HID = ops.HID
 F32 = torch.float32
+# True: keep only the FFN pre-activation and rebuild GELU / LN1 outputs in backward (-5 GB per layer at B=64,
+# +2 HBM passes); False (default): keep them -- 288 GB of HBM3E leave the room (peak ~210 GB at B=64).
+RECOMPUTE_ACTIVATIONS = False
 
 
 def _mm_bias(x2, w, b):
@@ -41,14 +44,16 @@ class BertLayerFn(torch.autograd.Function):
         a = _mm_bias(att.view(B * L, HID), w_ao, b_ao)
         y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo)
         del a
-        u = _mm_bias(y1_lo if lo else y1, w_i, b_i)
-        del y1_lo
+        y1_op = y1_lo if lo else y1
+        u = _mm_bias(y1_op, w_i, b_i)
         gact = ops.gelu_fwd(u)
         o = _mm_bias(gact, w_o, b_o)
-        del gact
         y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, y1, g2, be2, stream_dtype=F32, want_lo=lo)
         ctx.keys = keys
-        ctx.save_for_backward(xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2)
+        ctx.recompute = RECOMPUTE_ACTIVATIONS
+        if ctx.recompute:      # store less: GELU output and the LN1 operand copy are rebuilt in backward
+            gact = y1_op = None
+        ctx.save_for_backward(xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op)
         y2 = y2.view(B, L, HID)
         y2_lo = y2_lo.view(B, L, HID) if lo else y2.detach()
         ctx.mark_non_differentiable(y2_lo)
@@ -56,7 +61,7 @@ class BertLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dy_lo):
-        xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2 = ctx.saved_tensors
+        xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op = ctx.saved_tensors
         keys = ctx.keys
         B, L, _ = qkv.shape
         dt = w_qkv.dtype
@@ -64,17 +69,21 @@ class BertLayerFn(torch.autograd.Function):
         dy = dy.contiguous().view(B * L, HID)
         # ---- output LayerNorm + FFN
         dz2, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt)
-        gact = ops.gelu_fwd(u)
+        if gact is None:
+            gact = ops.gelu_fwd(u)
         dw_o = dz2.t() @ gact
         db_o = dz2.sum(0)
         dgact = dz2 @ w_o
         del gact
         du, db_i = ops.gelu_bwd(dgact, u)
         del dgact
-        y1, y1_lo, _, _ = ops.add_layernorm_fwd(z1, None, g1, be1, save=False, stream_dtype=F32, want_lo=lo, want_y=not lo)
-        dw_i = du.t() @ (y1_lo if lo else y1)                                # recomputed LN1 output
+        if y1_op is None:                                                    # recompute the LN1 output
+            y1, y1_lo, _, _ = ops.add_layernorm_fwd(z1, None, g1, be1, save=False, stream_dtype=F32, want_lo=lo, want_y=not lo)
+            y1_op = y1_lo if lo else y1
+            del y1, y1_lo
+        dw_i = du.t() @ y1_op
         dy1 = torch.addmm(dz2, du, w_i)                                      # + residual branch of LN2
-        del du, y1, y1_lo, dz2
+        del du, y1_op, dz2
         # ---- attention output LayerNorm + projection
         dz1, dg1, dbe1 = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt)
         del dy1
