@@ -48,6 +48,13 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   }
   const int kdec = kpos - n_prefix;        // decoder step of this key (negative: prefix key)
   const float c = p.scale * LOG2E;
+  // Fold the softmax scale into the K operand (one bf16 rounding per element, once per wave) and the per-row
+  // constants into the accumulators' initial values: S'' = c*Q.K - LSE*log2e and dP' = dO.V - delta come straight
+  // out of the MFMA chains, so P = exp2(S'') and dS = P * dP' need one v_exp and one v_mul per element.
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kf[s][j] = (bf16_t)((float)kf[s][j] * c);
   const int nqt = (p.Lq + QROWS - 1) / QROWS;
   const bool edge = (kp0 + 128 > n_prefix);
 
@@ -70,8 +77,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
     const int r2_ = (qt_) * QROWS + lrow;                                                       \
     const int r2c_ = r2_ < p.Lq ? r2_ : p.Lq - 1;                                               \
     const float l_ = LSE[r2c_] * LOG2E, dl_ = DELTA[r2c_];                                      \
-    lreg = r2_ < p.Lq ? l_ : INFINITY; /* +inf => P = 0 for rows past Lq */                     \
-    dreg = r2_ < p.Lq ? dl_ : 0.f;                                                              \
+    lreg = r2_ < p.Lq ? -l_ : -INFINITY; /* -inf => P = exp2(-inf) = 0 for rows past Lq */       \
+    dreg = r2_ < p.Lq ? -dl_ : 0.f;                                                             \
   }
 #define STAGE_WRITE(buf_)                                                                       \
   {                                                                                             \
@@ -107,33 +114,32 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
     f32x16 sacc[2], dpacc[2];
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { sacc[sb][i] = 0.f; dpacc[sb][i] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sacc[sb] = mfma_bf16(lds_row_frag(qb, sb * 32 + lr, s, lh), kf[s], sacc[sb]);        // S[q, key]
-        dpacc[sb] = mfma_bf16(lds_row_frag(dob, sb * 32 + lr, s, lh), vf[s], dpacc[sb]);     // dP[q, key]
-      }
-    }
-    // rows of this lane's accumulator registers: q = acc_row(r, lh): 4 groups of 4 consecutive rows
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
+      // initial accumulators = row constants (rows of this lane's registers: acc_row(r, lh) = 8g + 4lh + j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + sb * 32 + 8 * g + 4 * lh);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + sb * 32 + 8 * g + 4 * lh);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g + j;
-          float pv = fast_exp2(sacc[sb][r] * c - l4[j]);
-          if (edge) {
-            const int qdec = qt * QROWS + sb * 32 + 8 * g + 4 * lh + j - p.dec_q0;
-            const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
-            pv = ok ? pv : 0.f;
-          }
-          sacc[sb][r] = pv;
-          dpacc[sb][r] = pv * (dpacc[sb][r] - d4[j]);
+        for (int j = 0; j < 4; ++j) { sacc[sb][4 * g + j] = l4[j]; dpacc[sb][4 * g + j] = d4[j]; }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sacc[sb] = mfma_bf16(lds_row_frag(qb, sb * 32 + lr, s, lh), kf[s], sacc[sb]);        // c*S[q, key] - LSE*log2e
+        dpacc[sb] = mfma_bf16(lds_row_frag(dob, sb * 32 + lr, s, lh), vf[s], dpacc[sb]);     // dP[q, key] - delta
+      }
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = fast_exp2(sacc[sb][r]);
+        if (edge) {
+          const int qdec = qt * QROWS + sb * 32 + acc_row(r, lh) - p.dec_q0;
+          const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
+          pv = ok ? pv : 0.f;
         }
+        sacc[sb][r] = pv;
+        dpacc[sb][r] = pv * dpacc[sb][r];
       }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
