@@ -173,7 +173,7 @@ def main():
     B, F, P, V = args.batch, args.frames, args.ocr, args.vocab
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = make_model(F, P, V, seed=0, dtype=dtype).to(dev)        # identical weights on every rank (name-seeded)
-    model.train(not args.forward_only)
+    model.train(True)          # --forward-only = the teacher-forced training forward under no_grad (not the 12-step greedy decode)
     cfg = training_config()
     opt = build_optimizer(model, cfg)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda it: lr_lambda_update(it, cfg))
