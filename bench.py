@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--forward-only", action="store_true", help="BASELINE configs[1]: forward-only throughput")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="hidden/embedding dropout probability (reference default 0.1; 0 keeps GPU and CPU-oracle steps identical)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +174,7 @@ def main():
 
     B, F, P, V = args.batch, args.frames, args.ocr, args.vocab
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = make_model(F, P, V, seed=0, dtype=dtype).to(dev)        # identical weights on every rank (name-seeded)
+    model = make_model(F, P, V, seed=0, dtype=dtype, dropout=args.dropout).to(dev)        # identical weights on every rank (name-seeded)
     model.train(True)          # --forward-only = the teacher-forced training forward under no_grad (not the 12-step greedy decode)
     cfg = training_config()
     opt = build_optimizer(model, cfg)
@@ -230,6 +232,7 @@ def main():
                                "(BASELINE.json configs[%d])" % ("forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam, pos-BCE + 1000*InfoNCE)",
                                                                B, F, P, V, 1 if args.forward_only else 2),
                    "global_batch": world * B, "seq_len": T_Q + F + F * P + DEC, "parallelism": "dp%d" % world,
+                   "dropout": args.dropout,
                    "precision": "bf16 MFMA operands, fp32 accumulate / residual stream / master weights" if args.dtype == "bf16" else "fp32"},
         "model_flops_per_sample": mult * f_total,
         "model_tflops": sps * mult * f_total / 1e12 / world,

@@ -87,18 +87,27 @@ int t2s_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
  * both compute modes, so bf16 rounding never touches the running hidden state).  y_lo (may be
  * NULL) receives a bf16 copy of y for the next GEMM; y may be NULL when only y_lo is wanted.  z_out (may be NULL; may alias x when the
  * two dtypes are equal) keeps the pre-norm sum for backward; stats: [rows, 2] fp32 (mean, rstd),
- * may be NULL.  Supported (x, stream): (f32,f32), (bf16,f32), (bf16,bf16). */
+ * may be NULL.  Supported (x, stream): (f32,f32), (bf16,f32), (bf16,bf16).
+ * drop_p > 0 applies the hidden-state dropout of BertSelfOutput / BertOutput to x BEFORE the residual
+ * add: x <- x * keep / (1 - drop_p), keep(row, col) a stateless hash of (drop_seed, row*768 + col)
+ * (t2s_dropout_mask exports it), so the backward call regenerates the mask from the same seed. */
 int t2s_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                           void* y, void* y_lo, void* z_out, float* stats, int64_t rows, float eps,
-                          int x_dtype, int stream_dtype, t2s_stream_t stream);
+                          int x_dtype, int stream_dtype, float drop_p, uint64_t drop_seed,
+                          t2s_stream_t stream);
 
 /* dz = LN backward wrt z (= grad of both x and res); dgamma_part/dbeta_part: [n_part, 768] fp32
  * partial sums (n_part = t2s_layernorm_bwd_parts(rows)); the caller reduces over dim 0.
- * Supported (dy, z, dz) dtypes: (f32,f32,f32), (f32,f32,bf16), (bf16,f32,bf16), (bf16,bf16,bf16). */
+ * Supported (dy, z, dz) dtypes: (f32,f32,f32), (f32,f32,bf16), (bf16,f32,bf16), (bf16,bf16,bf16).
+ * With drop_p > 0, dzx (same dtype as dz, required) receives the gradient of the dropped branch input
+ * dz * keep / (1 - drop_p); dz itself is the gradient of the residual input. */
 int t2s_layernorm_bwd_parts(int64_t rows);
 int t2s_add_layernorm_bwd(const void* dy, const void* z, const float* stats, const float* gamma,
-                          void* dz, float* dgamma_part, float* dbeta_part, int64_t rows,
-                          int dy_dtype, int z_dtype, int dz_dtype, t2s_stream_t stream);
+                          void* dz, void* dzx, float* dgamma_part, float* dbeta_part, int64_t rows,
+                          int dy_dtype, int z_dtype, int dz_dtype, float drop_p, uint64_t drop_seed,
+                          t2s_stream_t stream);
+/* keep mask (0/1 bytes) of the dropout above for element indices 0..n-1 (test / debugging aid). */
+int t2s_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 
 /* ---- GELU (erf form) of BertIntermediate: y = gelu(u); backward du = dy * gelu'(u) with
  * per-column partial sums of du (bias gradient): dbias_part [n_part, cols] fp32,

@@ -132,7 +132,8 @@ def test_add_layernorm(rows, xdt, sdt, tol):
         if sdt == torch.float32 and ddt == torch.bfloat16 and odt == torch.float32:
             continue
         d = dy.to(ddt)
-        dz, dg, db = ops.add_layernorm_bwd(d, zz, st, gam, out_dtype=odt)
+        dz, dzx, dg, db = ops.add_layernorm_bwd(d, zz, st, gam, out_dtype=odt)
+        assert dzx is dz                                   # no dropout: one gradient for branch and residual
         gx, gg, gb = torch.autograd.grad(ref, (xr, gr, br), d.double(), retain_graph=True)
         t2 = tol if odt == torch.float32 else 2e-2
         assert (dz.double() - gx).abs().max().item() < t2 * 5

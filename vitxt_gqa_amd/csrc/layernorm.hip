@@ -19,11 +19,26 @@ constexpr int H = T2S_HIDDEN;           // 768 = 64 lanes * 3 vectors * 4
 constexpr int ROWS_PER_BLOCK = 4;       // 4 waves per workgroup
 constexpr int BWD_MAX_PARTS = 2048;
 
+// Hidden-state dropout of BertSelfOutput / BertOutput (dropout(dense(.)) before the residual add), fused here:
+// keep(row, col) is a stateless hash of (seed, row*768 + col), so backward regenerates the same mask from the seed.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropCfg {
+  uint32_t seed_lo, seed_hi, thresh;     // drop iff (hash >> 8) < thresh, thresh = p * 2^24
+  float scale;                           // 1 / (1 - p); thresh == 0 disables dropout
+};
+__device__ __forceinline__ float drop_keep_scale(const DropCfg& d, uint32_t idx) {
+  const uint32_t h = hash32(hash32(idx + d.seed_lo) ^ d.seed_hi);
+  return (h >> 8) < d.thresh ? 0.f : d.scale;
+}
+
 template <typename TX, typename TS>
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const TX* __restrict__ x, const TS* __restrict__ res,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 TS* __restrict__ y, bf16_t* __restrict__ y_lo, TS* z_out,
-                                                                float* __restrict__ stats, int64_t rows, float eps) {
+                                                                float* __restrict__ stats, int64_t rows, float eps, DropCfg drop) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -33,6 +48,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const TX* __rest
   for (int i = 0; i < 3; ++i) {
     const int e = (i * 64 + lane) * 4;
     v[i] = Vec4<TX>::load(x + row * H + e);
+    if (drop.thresh) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] *= drop_keep_scale(drop, (uint32_t)(row * H + e + j));
+    }
     if (res) {
       const f32x4 r = Vec4<TS>::load(res + row * H + e);
       v[i] += r;
@@ -76,8 +95,9 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const TX* __rest
 template <typename TDY, typename TZ, typename TDZ>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const TDY* __restrict__ dy, const TZ* __restrict__ z,
                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                                TDZ* __restrict__ dz, float* __restrict__ dgamma_part,
-                                                                float* __restrict__ dbeta_part, int64_t rows) {
+                                                                TDZ* __restrict__ dz, TDZ* __restrict__ dzx,
+                                                                float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                                                                int64_t rows, DropCfg drop) {
   __shared__ float red[2][4][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 g[3], dg[3], db[3];
@@ -115,6 +135,11 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const TDY* __res
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = rstd * (d[i][j] - s1 - xh[i][j] * s2);
       Vec4<TDZ>::store(dz + row * H + (i * 64 + lane) * 4, o);
+      if (dzx) {             // gradient of the dropped branch input: dz * keep / (1 - p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] *= drop_keep_scale(drop, (uint32_t)(row * H + (i * 64 + lane) * 4 + j));
+        Vec4<TDZ>::store(dzx + row * H + (i * 64 + lane) * 4, o);
+      }
     }
   }
 #pragma unroll
@@ -138,44 +163,63 @@ int bwd_parts(int64_t rows) {
 
 bool is_dt(int d) { return d == T2S_F32 || d == T2S_BF16; }
 
+DropCfg make_drop(float p, uint64_t seed) {
+  DropCfg d;
+  d.seed_lo = (uint32_t)seed;
+  d.seed_hi = (uint32_t)(seed >> 32);
+  d.thresh = p > 0.f ? (uint32_t)(p * 16777216.0f) : 0u;
+  d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  return d;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, DropCfg drop) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = drop_keep_scale(drop, (uint32_t)i) != 0.f ? 1 : 0;
+}
+
 }  // namespace
 
 extern "C" int t2s_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* y_lo,
                                      void* z_out, float* stats, int64_t rows, float eps, int x_dtype, int stream_dtype,
-                                     t2s_stream_t stream) {
+                                     float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
   T2S_CHECK_ARG(x && gamma && beta && (y || y_lo), "add_layernorm_fwd: null pointer");
   T2S_CHECK_ARG(rows > 0 && rows < ((int64_t)1 << 33), "add_layernorm_fwd: bad rows %lld", (long long)rows);
   T2S_CHECK_ARG(is_dt(x_dtype) && is_dt(stream_dtype), "add_layernorm_fwd: bad dtype %d/%d", x_dtype, stream_dtype);
   T2S_CHECK_ARG(!(x_dtype == T2S_F32 && stream_dtype == T2S_BF16), "add_layernorm_fwd: fp32 branch with bf16 stream is not supported");
+  T2S_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "add_layernorm_fwd: dropout probability %f outside [0, 1)", drop_p);
+  T2S_CHECK_ARG(drop_p == 0.f || rows * H < ((int64_t)1 << 32), "add_layernorm_fwd: dropout index space exceeds 32 bits");
+  const DropCfg drop = make_drop(drop_p, drop_seed);
   dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype == T2S_BF16 && stream_dtype == T2S_BF16)
     hipLaunchKernelGGL((add_layernorm_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)res, gamma, beta,
-                       (bf16_t*)y, (bf16_t*)y_lo, (bf16_t*)z_out, stats, rows, eps);
+                       (bf16_t*)y, (bf16_t*)y_lo, (bf16_t*)z_out, stats, rows, eps, drop);
   else if (x_dtype == T2S_BF16)
     hipLaunchKernelGGL((add_layernorm_fwd_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)x, (const float*)res, gamma, beta,
-                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps);
+                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps, drop);
   else
     hipLaunchKernelGGL((add_layernorm_fwd_kernel<float, float>), grid, block, 0, st, (const float*)x, (const float*)res, gamma, beta,
-                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps);
+                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps, drop);
   T2S_CHECK_LAUNCH("add_layernorm_fwd");
   return 0;
 }
 
 extern "C" int t2s_layernorm_bwd_parts(int64_t rows) { return bwd_parts(rows); }
 
-extern "C" int t2s_add_layernorm_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* dz,
+extern "C" int t2s_add_layernorm_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* dz, void* dzx,
                                      float* dgamma_part, float* dbeta_part, int64_t rows, int dy_dtype, int z_dtype, int dz_dtype,
-                                     t2s_stream_t stream) {
+                                     float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
   T2S_CHECK_ARG(dy && z && stats && gamma && dz && dgamma_part && dbeta_part, "add_layernorm_bwd: null pointer");
   T2S_CHECK_ARG(rows > 0, "add_layernorm_bwd: bad rows");
   T2S_CHECK_ARG(is_dt(dy_dtype) && is_dt(z_dtype) && is_dt(dz_dtype), "add_layernorm_bwd: bad dtype");
+  T2S_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (dzx != nullptr) == (drop_p > 0.f), "add_layernorm_bwd: dzx must be given iff drop_p > 0");
+  const DropCfg drop = make_drop(drop_p, drop_seed);
   dim3 grid(bwd_parts(rows)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int combo = dy_dtype * 4 + z_dtype * 2 + dz_dtype;
 #define LN_BWD(TDY, TZ, TDZ)                                                                                                   \
   hipLaunchKernelGGL((add_layernorm_bwd_kernel<TDY, TZ, TDZ>), grid, block, 0, st, (const TDY*)dy, (const TZ*)z, stats, gamma, \
-                     (TDZ*)dz, dgamma_part, dbeta_part, rows)
+                     (TDZ*)dz, (TDZ*)dzx, dgamma_part, dbeta_part, rows, drop)
   switch (combo) {
     case 0: LN_BWD(float, float, float); break;
     case 1: LN_BWD(float, float, bf16_t); break;
@@ -187,5 +231,15 @@ extern "C" int t2s_add_layernorm_bwd(const void* dy, const void* z, const float*
   }
 #undef LN_BWD
   T2S_CHECK_LAUNCH("add_layernorm_bwd");
+  return 0;
+}
+
+extern "C" int t2s_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
+  T2S_CHECK_ARG(out && n > 0 && n < ((int64_t)1 << 32), "dropout_mask: bad arguments");
+  T2S_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "dropout_mask: bad probability");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, make_drop(drop_p, drop_seed));
+  T2S_CHECK_LAUNCH("dropout_mask");
   return 0;
 }

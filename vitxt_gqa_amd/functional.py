@@ -33,7 +33,7 @@ class BertLayerFn(torch.autograd.Function):
     (y_lo is y itself in fp32 mode).  Weights arrive in the operand dtype; LayerNorm affine stays fp32."""
 
     @staticmethod
-    def forward(ctx, x, x_lo, keys, w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2):
+    def forward(ctx, x, x_lo, keys, w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2, drop_p=0.0, seeds=(0, 0)):
         B, L, _ = x.shape
         dt = w_qkv.dtype
         lo = dt != F32
@@ -42,14 +42,15 @@ class BertLayerFn(torch.autograd.Function):
         qkv = _mm_bias(xl, w_qkv, b_qkv).view(B, L, 3 * HID)
         att, lse = ops.attn_fwd(qkv, keys)
         a = _mm_bias(att.view(B * L, HID), w_ao, b_ao)
-        y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo)
+        y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[0])
         del a
         y1_op = y1_lo if lo else y1
         u = _mm_bias(y1_op, w_i, b_i)
         gact = ops.gelu_fwd(u)
         o = _mm_bias(gact, w_o, b_o)
-        y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, y1, g2, be2, stream_dtype=F32, want_lo=lo)
+        y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, y1, g2, be2, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[1])
         ctx.keys = keys
+        ctx.drop = (drop_p, seeds)
         ctx.recompute = RECOMPUTE_ACTIVATIONS
         if ctx.recompute:      # store less: GELU output and the LN1 operand copy are rebuilt in backward
             gact = y1_op = None
@@ -68,13 +69,14 @@ class BertLayerFn(torch.autograd.Function):
         lo = dt != F32
         dy = dy.contiguous().view(B * L, HID)
         # ---- output LayerNorm + FFN
-        dz2, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt)
+        drop_p, seeds = ctx.drop
+        dz2, dz2x, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[1])
         if gact is None:
             gact = ops.gelu_fwd(u)
-        dw_o = dz2.t() @ gact
-        db_o = dz2.sum(0)
-        dgact = dz2 @ w_o
-        del gact
+        dw_o = dz2x.t() @ gact
+        db_o = dz2x.sum(0)
+        dgact = dz2x @ w_o
+        del gact, dz2x
         du, db_i = ops.gelu_bwd(dgact, u)
         del dgact
         if y1_op is None:                                                    # recompute the LN1 output
@@ -85,11 +87,12 @@ class BertLayerFn(torch.autograd.Function):
         dy1 = torch.addmm(dz2, du, w_i)                                      # + residual branch of LN2
         del du, y1_op, dz2
         # ---- attention output LayerNorm + projection
-        dz1, dg1, dbe1 = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt)
+        dz1, dz1x, dg1, dbe1 = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[0])
         del dy1
-        dw_ao = dz1.t() @ att.view(B * L, HID)
-        db_ao = dz1.sum(0)
-        datt = (dz1 @ w_ao).view(B, L, HID)
+        dw_ao = dz1x.t() @ att.view(B * L, HID)
+        db_ao = dz1x.sum(0)
+        datt = (dz1x @ w_ao).view(B, L, HID)
+        del dz1x
         # ---- attention
         dqkv = ops.attn_bwd(qkv, att, datt, lse, keys).view(B * L, 3 * HID)
         del datt
@@ -97,7 +100,7 @@ class BertLayerFn(torch.autograd.Function):
         db_qkv = dqkv.sum(0)
         dx = torch.addmm(dz1, dqkv, w_qkv)                                   # + residual branch of LN1
         return (dx.view(B, L, HID), None, None, dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1,
-                dw_i, db_i.to(dt), dw_o, db_o, dg2, dbe2)
+                dw_i, db_i.to(dt), dw_o, db_o, dg2, dbe2, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -120,7 +123,7 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         z, st, gamma = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, HID)
-        dz, dg, db = ops.add_layernorm_bwd(dy2.float() if dy2.dtype != F32 else dy2, z, st, gamma, out_dtype=F32)
+        dz, _, dg, db = ops.add_layernorm_bwd(dy2.float() if dy2.dtype != F32 else dy2, z, st, gamma, out_dtype=F32)
         dz = dz.view(dy.shape)
         return dz.to(ctx.x_dtype), (dz if ctx.has_res else None), dg, db
 
@@ -193,8 +196,14 @@ def ptr_logits(fixed, q, k, mask01):
     return PtrLogitsFn.apply(fixed, q, k, mask01)
 
 
-def bert_layer(x, x_lo, keys, lp, dtype):
+def _fresh_seed():
+    """64-bit seed from torch's CPU generator (follows torch.manual_seed; no device sync)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout=0.0):
     """lp: a module holding one layer's parameters under the reference's names (see t2s.BertLayerParams).
+    hidden_dropout: p of the dropout after the attention-output and FFN-output dense layers (training only).
     Returns (y fp32, y_lo operand dtype)."""
     att = lp.attention
     w_qkv = torch.cat([att.self.query.weight, att.self.key.weight, att.self.value.weight], 0).to(dtype)
@@ -205,12 +214,13 @@ def bert_layer(x, x_lo, keys, lp, dtype):
         att.output.LayerNorm.weight, att.output.LayerNorm.bias,
         lp.intermediate.dense.weight.to(dtype), lp.intermediate.dense.bias.to(dtype),
         lp.output.dense.weight.to(dtype), lp.output.dense.bias.to(dtype),
-        lp.output.LayerNorm.weight, lp.output.LayerNorm.bias)
+        lp.output.LayerNorm.weight, lp.output.LayerNorm.bias,
+        float(hidden_dropout), (_fresh_seed(), _fresh_seed()) if hidden_dropout > 0 else (0, 0))
 
 
-def bert_encoder(x, keys, layers, dtype):
+def bert_encoder(x, keys, layers, dtype, hidden_dropout=0.0):
     """x: fp32 [B, L, 768] -> fp32."""
     x_lo = None
     for lp in layers:
-        x, x_lo = bert_layer(x, x_lo, keys, lp, dtype)
+        x, x_lo = bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout)
     return x

@@ -93,7 +93,7 @@ def _check_keys(keys, B, L):
 
 
 def add_layernorm_fwd(x, res, gamma, beta, eps=1e-12, save=True, inplace_z=True, stream_dtype=None, want_lo=False,
-                      want_y=True):
+                      want_y=True, drop_p=0.0, drop_seed=0):
     """y = LN(x + res).  x: GEMM-output dtype; res / y / z: residual-stream dtype (``stream_dtype``, default
     x.dtype).  Returns (y, y_lo, z, stats): y_lo = bf16 copy of y (if want_lo), z = x + res kept for backward
     (written over x when the dtypes match and inplace_z), stats [rows, 2] = (mean, rstd).  res may be None."""
@@ -109,23 +109,33 @@ def add_layernorm_fwd(x, res, gamma, beta, eps=1e-12, save=True, inplace_z=True,
         z = x if (inplace_z and sdt == x.dtype) else torch.empty(x.shape, dtype=sdt, device=x.device)
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save else None
     X.check(X.lib().t2s_add_layernorm_fwd(X.ptr(x), X.ptr(res), X.ptr(gamma), X.ptr(beta), X.ptr(y), X.ptr(y_lo), X.ptr(z),
-                                          X.ptr(stats), rows, eps, X.dtype_code(x), X.T2S_F32 if sdt == torch.float32 else X.T2S_BF16, X.stream()),
+                                          X.ptr(stats), rows, eps, X.dtype_code(x), X.T2S_F32 if sdt == torch.float32 else X.T2S_BF16,
+                                          float(drop_p), int(drop_seed), X.stream()),
             "t2s_add_layernorm_fwd")
     return y, y_lo, z, stats
 
 
-def add_layernorm_bwd(dy, z, stats, gamma, out_dtype=None):
-    """Returns (dz [out_dtype, default dy.dtype], dgamma, dbeta)."""
+def add_layernorm_bwd(dy, z, stats, gamma, out_dtype=None, drop_p=0.0, drop_seed=0):
+    """Returns (dz [out_dtype, default dy.dtype], dzx, dgamma, dbeta); dzx = gradient of the dropped branch input
+    (dz itself when drop_p == 0)."""
     rows = _rows768(dy)
     assert z.shape == dy.shape and z.is_contiguous() and stats.shape == (rows, 2)
     parts = X.lib().t2s_layernorm_bwd_parts(rows)
     dz = torch.empty(dy.shape, dtype=out_dtype or dy.dtype, device=dy.device)
+    dzx = torch.empty_like(dz) if drop_p > 0 else None
     dgp = torch.empty(parts, HID, dtype=torch.float32, device=dy.device)
     dbp = torch.empty(parts, HID, dtype=torch.float32, device=dy.device)
-    X.check(X.lib().t2s_add_layernorm_bwd(X.ptr(dy), X.ptr(z), X.ptr(stats), X.ptr(gamma), X.ptr(dz), X.ptr(dgp), X.ptr(dbp),
-                                          rows, X.dtype_code(dy), X.dtype_code(z), X.dtype_code(dz), X.stream()),
-            "t2s_add_layernorm_bwd")
-    return dz, dgp.sum(0), dbp.sum(0)
+    X.check(X.lib().t2s_add_layernorm_bwd(X.ptr(dy), X.ptr(z), X.ptr(stats), X.ptr(gamma), X.ptr(dz), X.ptr(dzx), X.ptr(dgp),
+                                          X.ptr(dbp), rows, X.dtype_code(dy), X.dtype_code(z), X.dtype_code(dz),
+                                          float(drop_p), int(drop_seed), X.stream()), "t2s_add_layernorm_bwd")
+    return dz, (dzx if dzx is not None else dz), dgp.sum(0), dbp.sum(0)
+
+
+def dropout_mask(n, drop_p, drop_seed, device):
+    """0/1 keep mask of the fused hidden dropout for element indices 0..n-1 (tests)."""
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    X.check(X.lib().t2s_dropout_mask(X.ptr(out), n, float(drop_p), int(drop_seed), X.stream()), "t2s_dropout_mask")
+    return out
 
 
 def gelu_fwd(u):

@@ -61,6 +61,28 @@ class BertEncoderParams(nn.Module):
         self.layer = nn.ModuleList([BertLayerParams() for _ in range(num_layers)])
 
 
+_WARNED_ATTN_DROPOUT = [False]
+
+
+def _dropout_cfg(module, config):
+    """BertConfig defaults (Appendix A, Q1): hidden_dropout_prob = attention_probs_dropout_prob = 0.1 unless the yml
+    section overrides them.  Hidden dropout is fused into the residual+LayerNorm kernels; attention-probability
+    dropout is not implemented yet and is reported once."""
+    module.hidden_dropout = float(config.get("hidden_dropout_prob", 0.1))
+    module.attn_dropout = float(config.get("attention_probs_dropout_prob", 0.1))
+
+
+def _train_dropout(module):
+    if not module.training:
+        return 0.0
+    if module.attn_dropout > 0 and not _WARNED_ATTN_DROPOUT[0]:
+        _WARNED_ATTN_DROPOUT[0] = True
+        import warnings
+        warnings.warn("attention_probs_dropout_prob=%g is not applied by the MI355X attention kernel yet "
+                      "(hidden-state dropout is); set it to 0 to silence this" % module.attn_dropout)
+    return module.hidden_dropout
+
+
 def _bert_init(module):
     """BertPreTrainedModel.init_weights (Appendix A, Q3): N(0, 0.02), bias 0, LayerNorm (1, 0)."""
     for m in module.modules():
@@ -85,6 +107,7 @@ class TextBert(nn.Module):
         self.embeddings.token_type_embeddings = nn.Embedding(2, HID)
         self.embeddings.LayerNorm = nn.LayerNorm(HID, eps=LN_EPS)
         self.encoder = BertEncoderParams(config.get("num_hidden_layers", 12))
+        _dropout_cfg(self, config)
         _bert_init(self)
 
     def forward(self, txt_inds, txt_mask, dtype):
@@ -93,8 +116,11 @@ class TextBert(nn.Module):
         x = (e.word_embeddings(txt_inds) + e.position_embeddings.weight[:L].unsqueeze(0)
              + e.token_type_embeddings.weight[0])
         x = FN.layer_norm(x, e.LayerNorm.weight, e.LayerNorm.bias)
+        pd = _train_dropout(self)
+        if pd > 0:
+            x = F.dropout(x, pd, True)                      # BertEmbeddings dropout
         keys = ops.compact_keys(txt_mask > 0)
-        return FN.bert_encoder(x, keys, self.encoder.layer, dtype)
+        return FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd)
 
 
 class QTV(nn.Module):
@@ -103,13 +129,14 @@ class QTV(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.encoder = BertEncoderParams(config.get("num_hidden_layers", 12))
+        _dropout_cfg(self, config)
         _bert_init(self)
 
     def forward(self, fwd, dtype):
         txt, obj, ocr = fwd["txt_emb"], fwd["obj_mmt_in"], fwd["ocr_mmt_in"]
         x = torch.cat([txt, obj, ocr], dim=1)
         valid = torch.cat([fwd["txt_mask"] > 0, fwd["obj_mask"] > 0, fwd["ocr_mask"] > 0], dim=1)
-        out = FN.bert_encoder(x, ops.compact_keys(valid), self.encoder.layer, dtype)
+        out = FN.bert_encoder(x, ops.compact_keys(valid), self.encoder.layer, dtype, _train_dropout(self))
         T, Fn = txt.size(1), obj.size(1)
         fwd["txt_emb"] = txt + torch.tanh(out[:, :T])
         fwd["obj_mmt_in"] = obj + torch.tanh(out[:, T:T + Fn])
@@ -205,7 +232,7 @@ class PrevPredEmbeddings(nn.Module):
         self.ocr_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
         self.emb_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
 
-    def forward(self, ans_emb, ocr_emb, prev_inds, dtype):
+    def forward(self, ans_emb, ocr_emb, prev_inds, dtype, emb_dropout=0.0):
         # LayerNorm is row-wise, so LN(table)[gather] == LN(table[gather]): only the 12 gathered rows per
         # sample are normalised instead of the whole [V, 768] table + [B, N, 768] OCR tensor (t2s.py:702-709).
         B, D = prev_inds.shape
@@ -219,6 +246,8 @@ class PrevPredEmbeddings(nn.Module):
         raw = torch.where(is_ocr.unsqueeze(-1), ocr_n, ans_n)
         emb = self.position_embeddings.weight[:D].unsqueeze(0) + self.token_type_embeddings(is_ocr.long())
         emb = FN.layer_norm(emb, self.emb_layer_norm.weight, self.emb_layer_norm.bias)
+        if emb_dropout > 0:
+            emb = F.dropout(emb, emb_dropout, True)         # emb_dropout, t2s.py:720
         return raw + emb
 
 
@@ -229,18 +258,20 @@ class MMT(nn.Module):
         super().__init__()
         self.prev_pred_embeddings = PrevPredEmbeddings()
         self.encoder = BertEncoderParams(config.get("num_hidden_layers", 12))
+        _dropout_cfg(self, config)
         _bert_init(self)
 
     def forward(self, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, fixed_ans_emb, prev_inds, dtype,
                 max_keys=None):
-        dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype)
+        pd = _train_dropout(self)
+        dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd)
         x = torch.cat([txt_emb, obj_emb, ocr_emb, dec_emb], dim=1)
         T, Fn, N, D = txt_emb.size(1), obj_emb.size(1), ocr_emb.size(1), dec_emb.size(1)
         L1 = T + Fn + N
         valid = torch.cat([txt_mask > 0, obj_mask > 0, ocr_mask > 0], dim=1)
         # decoder keys: step j visible to decoder row i iff i >= j; prefix rows never see them (t2s.py:574-618)
         keys = ops.compact_keys(valid, n_dec=D, dec_row0=L1, cap_hint=max_keys)
-        out = FN.bert_encoder(x, keys, self.encoder.layer, dtype)
+        out = FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd)
         return out[:, T + Fn:L1], out[:, L1:]
 
 

@@ -23,13 +23,17 @@ def setup_registry(V, N, dataset="vtextgqa"):
     registry.register(dataset + "_answer_processor", _AnswerProcessor())
 
 
-def make_model(F, P, V, text_vocab=30522, seed=0, attn_gain=1.0, dtype=torch.bfloat16, state_dict=None):
-    """T2S with name-seeded reference-style init (or the given state_dict), dropout 0."""
+def make_model(F, P, V, text_vocab=30522, seed=0, attn_gain=1.0, dtype=torch.bfloat16, state_dict=None, dropout=0.0):
+    """T2S with name-seeded reference-style init (or the given state_dict); every dropout probability = ``dropout``
+    (0 for parity runs; the reference default is 0.1)."""
     setup_registry(V, F * P)
     cfg = t2s_model_config(frame_num=F, ocr_frame_num=P)
     cfg.text_bert["vocab_size"] = text_vocab
-    cfg.obj["dropout_prob"] = 0.0
-    cfg.ocr["dropout_prob"] = 0.0
+    cfg.obj["dropout_prob"] = dropout
+    cfg.ocr["dropout_prob"] = dropout
+    for sec in ("text_bert", "translayers", "encoder", "mmt"):
+        cfg[sec]["hidden_dropout_prob"] = dropout
+        cfg[sec]["attention_probs_dropout_prob"] = 0.0      # not implemented in the attention kernel yet
     model = build_model(cfg)
     sd = state_dict if state_dict is not None else make_state_dict(
         state_dict_schema(V, text_vocab=text_vocab), seed=seed, attn_gain=attn_gain)
