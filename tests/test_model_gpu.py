@@ -114,6 +114,28 @@ def test_eval_greedy_decode_indices_exact():
     assert torch.equal(out["pos_scores"].argmax(-1).cpu(), fx["eval_argmax"])
 
 
+@pytest.mark.parametrize("case,dtype,tol", [("tiny_b2_f6_p8", torch.float32, 1e-3), ("cfg1_b2_f20_p30", torch.bfloat16, 1e-2)])
+def test_cached_decode_equals_reference_loop(case, dtype, tol):
+    """Prefix-reuse greedy decoding == the reference's recompute-everything loop (same scores, same indices)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fx = Fixture(case)
+    model, s = _run(fx, dtype, train=False)
+    with torch.no_grad():
+        model.decode_with_prefix_cache = True
+        a = model(s)
+        pa = model._last_fwd["prev_inds"].clone()
+        model.decode_with_prefix_cache = False
+        b = model(s)
+        pb = model._last_fwd["prev_inds"].clone()
+    for k in ("ref_scores", "pos_scores", "neg_scores"):
+        assert (a[k] - b[k]).abs().max().item() < (1e-4 if dtype == torch.float32 else 2e-2), k
+        assert (a[k].cpu() - fx["eval_" + k]).abs().max().item() < tol, k
+    if dtype == torch.float32:          # bf16 near-ties may legitimately flip an argmax
+        assert torch.equal(pa, pb)
+        assert torch.equal(a["pos_scores"].argmax(-1).cpu(), fx["eval_argmax"])
+
+
 def test_no_cpu_fallback():
     """The product path refuses CPU tensors instead of silently computing elsewhere."""
     from vitxt_gqa_amd import ops

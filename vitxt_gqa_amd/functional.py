@@ -224,3 +224,62 @@ def bert_encoder(x, keys, layers, dtype, hidden_dropout=0.0):
     for lp in layers:
         x, x_lo = bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout)
     return x
+
+
+# ------------------------------------------------------------------------------------------------
+# inference-only helpers for the greedy decoder with prefix reuse (T2S eval branch, t2s.py:315-354).
+# The prefix rows (question / frames / OCR) never see the decoder columns (t2s.py:574-618), so their hidden
+# states -- and therefore their K/V projections in every layer -- do not depend on the decoding step.  Step 0
+# runs the full sequence once and keeps each layer's fused QKV buffer; later steps recompute only the 12
+# decoder rows against the cached K/V (the reference recomputes the whole [L2 x L2] pass 12 times).
+def _layer_weights(lp, dtype):
+    att = lp.attention
+    return (torch.cat([att.self.query.weight, att.self.key.weight, att.self.value.weight], 0).to(dtype),
+            torch.cat([att.self.query.bias, att.self.key.bias, att.self.value.bias], 0).to(dtype),
+            att.output.dense.weight.to(dtype), att.output.dense.bias.to(dtype),
+            att.output.LayerNorm.weight, att.output.LayerNorm.bias,
+            lp.intermediate.dense.weight.to(dtype), lp.intermediate.dense.bias.to(dtype),
+            lp.output.dense.weight.to(dtype), lp.output.dense.bias.to(dtype),
+            lp.output.LayerNorm.weight, lp.output.LayerNorm.bias)
+
+
+def _layer_tail(att2, res32, w, dtype):
+    """attention output [rows, 768] -> layer output (fp32 stream, operand copy)."""
+    _, _, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2 = w
+    lo = dtype != F32
+    a = _mm_bias(att2, w_ao, b_ao)
+    y1, y1_lo, _, _ = ops.add_layernorm_fwd(a, res32, g1, be1, save=False, stream_dtype=F32, want_lo=lo)
+    o = _mm_bias(ops.gelu_fwd(_mm_bias(y1_lo if lo else y1, w_i, b_i)), w_o, b_o)
+    y2, y2_lo, _, _ = ops.add_layernorm_fwd(o, y1, g2, be2, save=False, stream_dtype=F32, want_lo=lo)
+    return y2, (y2_lo if lo else y2)
+
+
+@torch.no_grad()
+def encoder_prefill(x, keys, layers, dtype):
+    """Full-sequence inference pass.  Returns (out fp32 [B, L, 768], caches = per-layer fused QKV [B, L, 2304])."""
+    B, L, _ = x.shape
+    x2 = x.contiguous().view(B * L, HID)
+    xl = x2.to(dtype)
+    caches = []
+    for lp in layers:
+        w = _layer_weights(lp, dtype)
+        qkv = _mm_bias(xl, w[0], w[1]).view(B, L, 3 * HID)
+        att, _ = ops.attn_fwd(qkv, keys)
+        caches.append(qkv)
+        x2, xl = _layer_tail(att.view(B * L, HID), x2, w, dtype)
+    return x2.view(B, L, HID), caches
+
+
+@torch.no_grad()
+def encoder_decode_rows(x_dec, caches, keys, layers, dtype, row0):
+    """Recompute only the decoder rows row0.. of the sequence: x_dec fp32 [B, D, 768] (their layer-0 inputs);
+    ``caches`` from encoder_prefill (the decoder rows of each cache are overwritten with this step's Q/K/V)."""
+    B, D, _ = x_dec.shape
+    x2 = x_dec.contiguous().view(B * D, HID)
+    xl = x2.to(dtype)
+    for lp, qkv in zip(layers, caches):
+        w = _layer_weights(lp, dtype)
+        qkv[:, row0:row0 + D] = _mm_bias(xl, w[0], w[1]).view(B, D, 3 * HID)
+        att = ops.attn_fwd_rows(qkv[:, row0:row0 + D, :HID], qkv, keys)
+        x2, xl = _layer_tail(att.view(B * D, HID), x2, w, dtype)
+    return x2.view(B, D, HID)

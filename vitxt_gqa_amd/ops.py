@@ -84,6 +84,26 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0):
     return dqkv
 
 
+def attn_fwd_rows(q_rows, kv_buf, keys, scale=1.0 / 8.0):
+    """Attention of a SUBSET of query rows against a fused QKV buffer: q_rows [B, Lq, 2304-strided view or
+    contiguous [B, Lq, 768]], kv_buf [B, L, 2304] (keys/values taken from its K/V thirds).  The decoder rule of
+    ``keys`` is applied with the query rows numbered 0..Lq-1 (keys.dec_q0 is ignored: the rows ARE the decoder
+    rows).  Used by the greedy decoder, which recomputes only the 12 decoding rows per step.  Returns ctx [B, Lq, 768]."""
+    B, L, _ = kv_buf.shape
+    Lq = q_rows.shape[1]
+    assert q_rows.shape[0] == B and q_rows.shape[2] == HID and q_rows.stride(2) == 1 and q_rows.dtype == kv_buf.dtype
+    _, k, v = _attn_views(kv_buf)
+    out = torch.empty(B, Lq, HID, dtype=kv_buf.dtype, device=kv_buf.device)
+    lse = torch.empty(B, HEADS, Lq, dtype=torch.float32, device=kv_buf.device)
+    assert keys.idx.shape[0] == B and keys.idx.is_contiguous() and keys.n_dec == Lq
+    X.check(X.lib().t2s_attn_fwd(
+        X.ptr(q_rows), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(lse), X.ptr(keys.idx), X.ptr(keys.cnt),
+        B, HEADS, Lq, keys.idx.shape[1], keys.n_dec, 0,
+        q_rows.stride(1), q_rows.stride(0), kv_buf.stride(1), kv_buf.stride(0), out.stride(1), out.stride(0),
+        scale, X.dtype_code(kv_buf), X.stream()), "t2s_attn_fwd")
+    return out
+
+
 def _check_keys(keys, B, L):
     assert keys.idx.dtype == torch.int32 and keys.cnt.dtype == torch.int32
     assert keys.idx.shape[0] == B and keys.cnt.shape == (B,) and keys.idx.is_contiguous()

@@ -344,6 +344,7 @@ class T2S(BaseModel):
         num_choices -= c.classifier.ocr_max_num
         self.classifier = _Classifier(HID, num_choices)
         self.answer_processor = registry.get(self._datasets[0] + "_answer_processor")
+        self.decode_with_prefix_cache = True      # eval: reuse the step-invariant prefix K/V (False = reference's loop)
         for n, p in self.named_parameters():
             if is_dead_param(n):
                 p.requires_grad_(False)
@@ -421,13 +422,59 @@ class T2S(BaseModel):
         if self.training:
             fwd["prev_inds"] = s.train_prev_inds.clone()
             self._three_pass(fwd, fwd["prev_inds"], dt)
-        else:
+        elif not self.decode_with_prefix_cache:
+            # the reference's loop verbatim (t2s.py:315-354): every step recomputes all three full MMT passes
             D = s.train_prev_inds.size(1)
             fwd["prev_inds"] = torch.zeros_like(s.train_prev_inds)
             fwd["prev_inds"][:, 0] = self.answer_processor.BOS_IDX
             for _ in range(D):
                 self._three_pass(fwd, fwd["prev_inds"], dt)
                 fwd["prev_inds"][:, 1:] = fwd["pos_scores"].argmax(dim=-1)[:, :-1]
+        else:
+            self._greedy_decode_cached(s, fwd, dt)
+
+    @torch.no_grad()
+    def _greedy_decode_cached(self, s, fwd, dt):
+        """Greedy decoding (t2s.py:315-354) with prefix reuse: the prefix rows cannot attend to the decoder columns
+        (t2s.py:574-618), so their hidden states are step-invariant.  Step 0 runs each of the three passes once over
+        the full sequence and keeps every layer's fused QKV buffer and the pointer-network keys; steps 1..D-1
+        recompute only the D decoder rows against the cached K/V.  Same outputs, ~D x fewer FLOPs."""
+        g = self.Grounding_Module
+        txt, obj, ocr = fwd["txt_emb"], fwd["obj_mmt_in"], fwd["ocr_mmt_in"]
+        T, Fn, N = txt.size(1), obj.size(1), ocr.size(1)
+        L1 = T + Fn + N
+        D = s.train_prev_inds.size(1)
+        prev = torch.zeros_like(s.train_prev_inds)
+        prev[:, 0] = self.answer_processor.BOS_IDX
+        layers = self.mmt.encoder.layer
+        pn = self.ocr_ptr_net
+        passes = (("ref", fwd["obj_mask"], fwd["ocr_mask"], None),
+                  ("pos", fwd["pos_obj_mask"], fwd["pos_ocr_mask"], T + g.frame_topk + g.ocr_topk * g.frame_num + D),
+                  ("neg", fwd["neg_obj_mask"], fwd["neg_ocr_mask"], T + g.frame_topk + g.ocr_topk * g.frame_topk + D))
+
+        def scores(dec_out, k_ptr, cm):
+            fixed = F.linear(dec_out, self.classifier.module.weight, self.classifier.module.bias)
+            q = F.linear(dec_out, pn.query.weight, pn.query.bias)
+            return FN.ptr_logits(fixed, q, k_ptr, cm.float())
+
+        state = {}
+        for name, om, cm, bound in passes:                       # step 0: full sequence once per pass
+            dec = self.mmt.prev_pred_embeddings(self.classifier.module.weight, ocr, prev, dt)
+            x = torch.cat([txt, obj, ocr, dec], dim=1)
+            valid = torch.cat([fwd["txt_mask"] > 0, om > 0, cm > 0], dim=1)
+            keys = ops.compact_keys(valid, n_dec=D, dec_row0=L1, cap_hint=bound)
+            out, caches = FN.encoder_prefill(x, keys, layers, dt)
+            k_ptr = F.linear(out[:, T + Fn:L1].to(dt), pn.key.weight.to(dt), pn.key.bias.to(dt)).contiguous()
+            state[name] = (keys, caches, k_ptr, cm)
+            fwd[name + "_scores"] = scores(out[:, L1:], k_ptr, cm)
+        prev[:, 1:] = fwd["pos_scores"].argmax(dim=-1)[:, :-1]
+        for _ in range(1, D):                                    # steps 1..D-1: decoder rows only
+            dec = self.mmt.prev_pred_embeddings(self.classifier.module.weight, ocr, prev, dt)
+            for name, (keys, caches, k_ptr, cm) in state.items():
+                dec_out = FN.encoder_decode_rows(dec, caches, keys, layers, dt, L1)
+                fwd[name + "_scores"] = scores(dec_out, k_ptr, cm)
+            prev[:, 1:] = fwd["pos_scores"].argmax(dim=-1)[:, :-1]
+        fwd["prev_inds"] = prev
 
     # -- optimizer hook (t2s.py:356-376) -------------------------------------------------------------
     def get_optimizer_parameters(self, config):
