@@ -57,14 +57,23 @@ int t2s_compact_keys(const uint8_t* valid, int32_t* out_idx, int32_t* out_cnt, i
  * dense key list 0..idx_cap-1 whose last n_dec rows are decoder keys.
  * Decoder rule: key position p >= kv_cnt[b] is decoder step j = p - kv_cnt[b]; it is visible to
  * query row r iff r - dec_q0 >= j.
- * lse: [B, H, Lq] fp32, natural-log-sum-exp of the scaled scores (saved for backward). */
+ * lse: [B, H, Lq] fp32, natural-log-sum-exp of the scaled scores (saved for backward).
+ * drop_p > 0: attention-probability dropout (BertSelfAttention: dropout(softmax(.)) before .V):
+ * out = (softmax(.) * keep / (1 - p')) V, keep(b, h, q, list position) a stateless hash of drop_seed,
+ * p' = round(256 p)/256 (one byte per score).  drop_ws: uint32 workspace of B*H*ceil(Lq/2) words
+ * (row hash keys; written here).  The backward call regenerates the mask from the same seed;
+ * t2s_attn_dropout_mask exports it. */
 int t2s_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                  const int32_t* kv_idx, const int32_t* kv_cnt,
                  int B, int H, int Lq, int idx_cap, int n_dec, int dec_q0,
                  int64_t q_row_stride, int64_t q_batch_stride,
                  int64_t kv_row_stride, int64_t kv_batch_stride,
                  int64_t o_row_stride, int64_t o_batch_stride,
-                 float scale, int dtype, t2s_stream_t stream);
+                 float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws,
+                 t2s_stream_t stream);
+/* keep mask [B, H, Lq, Lk] (0/1 bytes; Lk = key-list positions) of the dropout above (tests). */
+int t2s_attn_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p, uint64_t drop_seed,
+                          uint32_t* drop_ws, t2s_stream_t stream);
 
 /* Backward of the above.  delta: [B, H, Lq] fp32 workspace (rowsum(dO * O), written here).
  * dq/dk/dv use the q/kv strides.  dk/dv rows of keys that are not in the key list are NOT
@@ -78,7 +87,8 @@ int t2s_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
                  int64_t q_row_stride, int64_t q_batch_stride,
                  int64_t kv_row_stride, int64_t kv_batch_stride,
                  int64_t o_row_stride, int64_t o_batch_stride,
-                 float scale, int dtype, t2s_stream_t stream);
+                 float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws,
+                 t2s_stream_t stream);
 
 /* ---- residual + LayerNorm (BertSelfOutput / BertOutput / BertLayerNorm; also
  * t2s.py:87-88,116-117,685-687): z = x + res (res may be NULL); y = (z-mean)/sqrt(var+eps)*g+b,

@@ -106,3 +106,82 @@ def test_bert_layer_with_hidden_dropout():
             continue
         a = got[n[2:]].grad.double().cpu()
         assert (a - gr).norm().item() / max(gr.norm().item(), 1e-9) < 5e-4, n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# attention-probability dropout (BertSelfAttention: dropout(softmax(.)) before .V) inside the attention kernels
+def _attn_ref(qkv, keep, p_eff, n_dec):
+    """softmax(QK^T/8 + causal-tail mask) * keep / (1 - p') @ V with a dense key list."""
+    B, L, _ = qkv.shape
+    q, k, v = [t.view(B, L, 12, 64).permute(0, 2, 1, 3) for t in qkv.split(768, dim=-1)]
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    vis = torch.ones(L, L, dtype=torch.bool, device=qkv.device)
+    if n_dec:
+        L1 = L - n_dec
+        vis[:, L1:] = False
+        vis[L1:, L1:] = torch.tril(torch.ones(n_dec, n_dec, dtype=torch.bool, device=qkv.device))
+    s = s.masked_fill(~vis, float("-inf"))
+    a = torch.softmax(s, -1) * keep / (1.0 - p_eff)
+    return (a @ v).permute(0, 2, 1, 3).reshape(B, L, 768)
+
+
+def test_attention_dropout_mask_statistics():
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    m = ops.attn_dropout_mask(2, 300, 400, 0.1, 42, DEV).float()
+    p_eff = 26 / 256
+    assert abs(m.mean().item() - (1 - p_eff)) < 2e-3
+    assert torch.equal(m, ops.attn_dropout_mask(2, 300, 400, 0.1, 42, DEV).float())
+    assert not torch.equal(m, ops.attn_dropout_mask(2, 300, 400, 0.1, 43, DEV).float())
+    # per-row / per-column / per-head keep rates are flat, and neighbouring elements are uncorrelated
+    assert (m.mean(-1) - (1 - p_eff)).abs().max().item() < 0.08
+    assert (m.mean(-2) - (1 - p_eff)).abs().max().item() < 0.08
+    assert (m.mean((0, 2, 3)) - (1 - p_eff)).abs().max().item() < 5e-3
+    c = m - m.mean()
+    for a, b in ((c[..., :-1], c[..., 1:]), (c[..., :-1, :], c[..., 1:, :]), (c[..., :-2], c[..., 2:]), (c[:, :-1], c[:, 1:])):
+        assert abs((a * b).mean().item()) / c.var().item() < 0.01
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("L1,n_dec", [(150, 0), (300, 12)])
+def test_attention_dropout_fwd_bwd(L1, n_dec, dtype, tol):
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    g = torch.Generator().manual_seed(L1)
+    B, L, p, seed = 2, L1 + n_dec, 0.1, 20241003
+    qkv = torch.randn(B, L, 2304, generator=g).to(DEV).to(dtype)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(dtype)
+    keys = ops.compact_keys(torch.ones(B, L1, dtype=torch.bool, device=DEV), n_dec=n_dec, dec_row0=L1)   # dense list: position == row
+    keep = ops.attn_dropout_mask(B, L, L, p, seed, DEV).double()
+    out, lse = ops.attn_fwd(qkv, keys, drop_p=p, drop_seed=seed)
+    xr = qkv.double().requires_grad_(True)
+    ref = _attn_ref(xr, keep, 26 / 256, n_dec)
+    assert (out.double() - ref).abs().max().item() < tol
+    out0, lse0 = ops.attn_fwd(qkv, keys)                   # LSE is that of the undropped softmax
+    assert (lse - lse0).abs().max().item() < 1e-5
+    dqkv = ops.attn_bwd(qkv, out, dout, lse, keys, drop_p=p, drop_seed=seed)
+    (gref,) = torch.autograd.grad(ref, xr, dout.double())
+    sc = gref.abs().max().item()
+    assert (dqkv.double() - gref).abs().max().item() < tol * max(1.0, sc) * (1 if dtype == torch.float32 else 2)
+
+
+def test_model_trains_with_dropout():
+    """One train step with the reference's default dropout 0.1 everywhere: finite loss, gradients for exactly the live
+    parameters, and a different loss than the dropout-free step."""
+    _need_gpu()
+    from vitxt_gqa_amd.synth import make_batch, make_noise
+    from vitxt_gqa_amd.testing import make_model, to_device
+    B, F, P, V = 2, 6, 8, 64
+    batch = to_device(make_batch(B, F, P, V=V, seed=5, text_vocab=100), DEV)
+    batch.grounding_noise = tuple(t.to(DEV) for t in make_noise(B, F, P, 5))
+    losses = []
+    for drop in (0.0, 0.1):
+        torch.manual_seed(1)
+        m = make_model(F, P, V, text_vocab=100, dtype=torch.bfloat16, dropout=drop).to(DEV).train()
+        out = m(batch)
+        loss = sum(v.mean() for v in out["losses"].values())
+        loss.backward()
+        assert torch.isfinite(loss)
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
+        losses.append(loss.item())
+    assert abs(losses[0] - losses[1]) > 1e-4 * abs(losses[0])

@@ -33,9 +33,9 @@ def test_library_exports_every_declared_symbol(lib):
 def test_argument_validation_reports_errors(lib):
     rc = lib.t2s_gelu_fwd(None, None, 4, 0, None)
     assert rc != 0 and b"null pointer" in lib.t2s_last_error()
-    rc = lib.t2s_attn_fwd(*([ctypes.c_void_p(16)] * 5 + [None, None] + [1, 12, 0, 4, 0, 0] + [768] * 6 + [0.125, 1, None]))
+    rc = lib.t2s_attn_fwd(*([ctypes.c_void_p(16)] * 5 + [None, None] + [1, 12, 0, 4, 0, 0] + [768] * 6 + [0.125, 1, 0.0, 0, None, None]))
     assert rc != 0 and b"bad shape" in lib.t2s_last_error()
-    rc = lib.t2s_attn_fwd(*([ctypes.c_void_p(16)] * 5 + [None, None] + [1, 12, 4, 4, 0, 0] + [770] * 6 + [0.125, 1, None]))
+    rc = lib.t2s_attn_fwd(*([ctypes.c_void_p(16)] * 5 + [None, None] + [1, 12, 4, 4, 0, 0] + [770] * 6 + [0.125, 1, 0.0, 0, None, None]))
     assert rc != 0 and b"16 bytes" in lib.t2s_last_error()
 
 

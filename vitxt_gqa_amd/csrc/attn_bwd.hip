@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 
 // ---------------------------------------------------------------------------------------------
 // dQ, bf16.
-template <bool USE_IDX>
+template <bool USE_IDX, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE64];   // [buf][K, V]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   const float del = p.delta[((int64_t)b * p.H + h) * p.Lq + qr];
   const float c = p.scale * LOG2E;
   const int qdec = qrow - p.dec_q0;
+  const uint32_t rk = DROP ? p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qr >> 1)] : 0u;
 
   const int sr = tid >> 3, sc = tid & 7;
   uint4 kr0, kr1, vr0, vr1;
@@ -136,12 +137,14 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float pv = fast_exp2(sacc[kbk][r] * c - lse2);
+        const int pos = t * BK + kbk * 32 + acc_row(r, lh);
         if (edge) {
-          const int pos = t * BK + kbk * 32 + acc_row(r, lh);
           const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
           pv = ok ? pv : 0.f;
         }
-        dpacc[kbk][r] = pv * (dpacc[kbk][r] - del);
+        float dpv = dpacc[kbk][r];
+        if (DROP) dpv = attn_drop_keep(rk, qr, pos, p.drop_thresh) ? dpv * p.drop_inv : 0.f;   // dA = dD * M / (1 - p)
+        dpacc[kbk][r] = pv * (dpv - del);
       }
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk)
@@ -258,8 +261,16 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_f32_kernel(AttnParams p) {
       const int qdec = qt * 32 + qi - p.dec_q0;
       const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
       pv = ok ? pv : 0.f;
-      sacc[r] = pv;
-      dpacc[r] = pv * (dpacc[r] - del_s[qi]);
+      float dpv = dpacc[r];
+      bool keep = true;
+      if (p.drop_thresh) {
+        int qg = qt * 32 + qi;
+        qg = qg < p.Lq ? qg : p.Lq - 1;
+        keep = attn_drop_keep(p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qg >> 1)], qg, kpos, p.drop_thresh);
+        dpv = keep ? dpv * p.drop_inv : 0.f;
+      }
+      dpacc[r] = pv * (dpv - del_s[qi]);       // dS uses the UNdropped probability
+      sacc[r] = keep ? pv : 0.f;               // dV uses the dropped one (scaled by 1/(1-p) at the end)
     }
     // dV^T[d, key] += dO^T[d, q] P[q, key]:  A[i = d][k = lh] = dO[q = acc_row(r, lh)][d],  B = P register r
 #pragma unroll
@@ -281,7 +292,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_f32_kernel(AttnParams p) {
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * lh;
         f32x4 k4 = {dkacc[db][4 * g] * p.scale, dkacc[db][4 * g + 1] * p.scale, dkacc[db][4 * g + 2] * p.scale, dkacc[db][4 * g + 3] * p.scale};
-        f32x4 v4 = {dvacc[db][4 * g], dvacc[db][4 * g + 1], dvacc[db][4 * g + 2], dvacc[db][4 * g + 3]};
+        const float vs_ = p.drop_thresh ? p.drop_inv : 1.f;
+        f32x4 v4 = {dvacc[db][4 * g] * vs_, dvacc[db][4 * g + 1] * vs_, dvacc[db][4 * g + 2] * vs_, dvacc[db][4 * g + 3] * vs_};
         *reinterpret_cast<f32x4*>(dkp + d) = k4;
         *reinterpret_cast<f32x4*>(dvp + d) = v4;
       }
@@ -316,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_f32_kernel(AttnParams p) {
   const float del = p.delta[((int64_t)b * p.H + h) * p.Lq + qr];
   const float c = p.scale * LOG2E;
   const int qdec = qrow - p.dec_q0;
+  const uint32_t rk = p.drop_thresh ? p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qr >> 1)] : 0u;
   const int sr = tid >> 4, sc = tid & 15;
   f32x16 dqacc[2];
 #pragma unroll
@@ -354,7 +367,9 @@ __global__ __launch_bounds__(256, 2) void attn_dq_f32_kernel(AttnParams p) {
         const int pos = t * BK + kbk * 32 + acc_row(r, lh);
         const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
         const float pv = ok ? fast_exp2(sacc[kbk][r] * c - lse2) : 0.f;
-        dpacc[kbk][r] = pv * (dpacc[kbk][r] - del);
+        float dpv = dpacc[kbk][r];
+        if (p.drop_thresh) dpv = attn_drop_keep(rk, qr, pos, p.drop_thresh) ? dpv * p.drop_inv : 0.f;
+        dpacc[kbk][r] = pv * (dpv - del);
       }
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk)
@@ -384,7 +399,7 @@ extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const v
                             float* delta, void* dq, void* dk, void* dv, const int32_t* kv_idx, const int32_t* kv_cnt, int B,
                             int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys, int64_t q_row_stride, int64_t q_batch_stride,
                             int64_t kv_row_stride, int64_t kv_batch_stride, int64_t o_row_stride, int64_t o_batch_stride,
-                            float scale, int dtype, t2s_stream_t stream) {
+                            float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, t2s_stream_t stream) {
   T2S_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
   T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "attn_bwd: bad dtype %d", dtype);
   T2S_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && idx_cap > 0 && n_dec >= 0 && n_dec <= idx_cap, "attn_bwd: bad shape");
@@ -401,14 +416,20 @@ extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const v
   p.q_rs = q_row_stride; p.q_bs = q_batch_stride; p.kv_rs = kv_row_stride; p.kv_bs = kv_batch_stride;
   p.o_rs = o_row_stride; p.o_bs = o_batch_stride; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
+  if (int e = attn_setup_dropout(p, drop_p, drop_seed, drop_ws, st, "attn_bwd")) return e;
   const int64_t rows = (int64_t)B * Lq;
   dim3 gd((unsigned)((rows + 3) / 4)), blk(256);
   dim3 gkv((max_keys + 127) / 128, H, B), gq((Lq + 127) / 128, H, B);
   if (dtype == T2S_BF16) {
     hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, gd, blk, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, H, Lq, o_row_stride, o_batch_stride);
     launch_attn_dkdv_bf16(p, max_keys, st);
-    if (kv_idx) hipLaunchKernelGGL(attn_dq_bf16_kernel<true>, gq, blk, 0, st, p);
-    else hipLaunchKernelGGL(attn_dq_bf16_kernel<false>, gq, blk, 0, st, p);
+    if (p.drop_thresh) {
+      if (kv_idx) hipLaunchKernelGGL((attn_dq_bf16_kernel<true, true>), gq, blk, 0, st, p);
+      else hipLaunchKernelGGL((attn_dq_bf16_kernel<false, true>), gq, blk, 0, st, p);
+    } else {
+      if (kv_idx) hipLaunchKernelGGL((attn_dq_bf16_kernel<true, false>), gq, blk, 0, st, p);
+      else hipLaunchKernelGGL((attn_dq_bf16_kernel<false, false>), gq, blk, 0, st, p);
+    }
   } else {
     hipLaunchKernelGGL(attn_delta_kernel<float>, gd, blk, 0, st, (const float*)out, (const float*)dout, delta, B, H, Lq, o_row_stride, o_batch_stride);
     if (kv_idx) {

@@ -19,7 +19,48 @@ struct AttnParams {
   int B, H, Lq, idx_cap, n_dec, dec_q0;
   int64_t q_rs, q_bs, kv_rs, kv_bs, o_rs, o_bs;
   float scale;
+  // attention-probability dropout (BertSelfAttention: dropout(softmax(.)) before .V); thresh == 0 disables it
+  const uint32_t* drop_rowkey;   // [B, H, ceil(Lq/2)] per-(sample, head, query pair) hash keys (attn_drop_rowkeys_kernel)
+  uint32_t drop_thresh;          // drop iff byte < thresh, thresh = round(p * 256)
+  float drop_inv;                // 1 / (1 - thresh/256)
 };
+
+// ---- attention-probability dropout.  keep(q, kpos) is a stateless function of (seed, sample, head, q, kpos) so the
+// forward, dQ and dK/dV kernels regenerate the same mask in their different register layouts; kpos is the POSITION in
+// the compacted key list.  One 32-bit word serves a 2x2 block {q, q^1} x {kpos, kpos^1} (a byte per element), which is
+// the largest block both layouts share: with the query on the lane a register pair holds two consecutive keys, with
+// the key on the lane two consecutive queries.  rowkey[b,h,q>>1] is a full-quality hash (precomputed table); the
+// per-block mixer uses only 24-bit multiplies, shifts and xors (v_mul_lo_u32 is quarter rate on CDNA).
+__device__ __forceinline__ uint32_t attn_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t attn_drop_block(uint32_t rowkey, uint32_t kp2) {
+  uint32_t x = rowkey + __umul24(kp2, 0x9E3779u);
+  x ^= x >> 15;
+  x = __umul24(x, 0x2C1B3Du) + (x >> 9);
+  x ^= x >> 13;
+  x = __umul24(x, 0x6D2B79u) ^ (x >> 11);
+  return x;
+}
+// generic per-element form (fp32 kernels, mask export): byte (q&1)*2 + (kpos&1) of the block word
+__device__ __forceinline__ bool attn_drop_keep(uint32_t rowkey, int q, int kpos, uint32_t thresh) {
+  const uint32_t x = attn_drop_block(rowkey, (uint32_t)kpos >> 1);
+  return ((x >> (8 * ((q & 1) * 2 + (kpos & 1)))) & 0xFFu) >= thresh;
+}
+// packed form: returns the AND-mask for a bf16x2 word holding the block's elements whose bytes are `sel`-selected
+// (sel = v_perm selector placing the two bytes in the low byte of each 16-bit half): 0xFFFF per kept half.
+__device__ __forceinline__ uint32_t attn_drop_pair_mask(uint32_t x, uint32_t sel, uint32_t thresh2 /* thresh | thresh << 16 */) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const uint32_t t = __builtin_amdgcn_perm(0u, x, sel);
+  const s16x2 d = __builtin_bit_cast(s16x2, t) - __builtin_bit_cast(s16x2, thresh2);
+  const s16x2 m = d >> 15;                       // 0xFFFF where byte < thresh (dropped)
+  return ~__builtin_bit_cast(uint32_t, m);
+}
+__device__ __forceinline__ uint32_t attn_drop_sel(int b0, int b1) { return 0x0c000c00u | ((uint32_t)b1 << 16) | (uint32_t)b0; }
+
+void launch_attn_drop_rowkeys(uint32_t* rowkey, int B, int H, int Lq, uint64_t seed, hipStream_t st);
+int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, hipStream_t st, const char* who);
 
 // ---- LDS tile image shared by every bf16 tile (K, V, Q, dO): rows of 64 bf16 = 128 B = eight
 // 16-byte chunks, chunk c of row r stored at chunk position c ^ f(r).  f is chosen so that BOTH

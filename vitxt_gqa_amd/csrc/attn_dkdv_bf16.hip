@@ -14,9 +14,9 @@ namespace {
 
 constexpr int QROWS = 64;                         // query rows per iteration
 constexpr int TILE = QROWS * 128;                 // bytes of a 64-row bf16 tile
-constexpr int STAGE = 2 * TILE + 2 * QROWS * 4;   // Q | dO | lse | delta
+constexpr int STAGE = 2 * TILE + 2 * QROWS * 4 + (QROWS / 2) * 4;   // Q | dO | -lse | -delta | dropout row keys
 
-template <bool USE_IDX>
+template <bool USE_IDX, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
@@ -64,6 +64,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   const int lrow = tid & 63;
   uint4 q0r, q1r, d0r, d1r;
   float lreg, dreg;
+  uint32_t rkreg = 0;
+  const int Lq2 = (p.Lq + 1) >> 1;
+  const uint32_t* __restrict__ RK = DROP ? p.drop_rowkey + ((int64_t)b * p.H + h) * Lq2 : nullptr;
+  const uint32_t kp2 = (uint32_t)kpos >> 1;
+  const uint32_t ksel = attn_drop_sel(kpos & 1, 2 + (kpos & 1));      // bytes (q even, q odd) of this lane's key
+  const uint32_t th2 = p.drop_thresh | (p.drop_thresh << 16);
 #define STAGE_LOAD(qt_)                                                                         \
   {                                                                                             \
     const int r0_ = (qt_) * QROWS + sr, r1_ = r0_ + 32;                                         \
@@ -79,6 +85,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
     const float l_ = LSE[r2c_] * LOG2E, dl_ = DELTA[r2c_];                                      \
     lreg = r2_ < p.Lq ? -l_ : -INFINITY; /* -inf => P = exp2(-inf) = 0 for rows past Lq */       \
     dreg = r2_ < p.Lq ? -dl_ : 0.f;                                                             \
+    if (DROP) {                                                                                 \
+      const int q2_ = (qt_) * (QROWS / 2) + (tid & 31);                                         \
+      rkreg = RK[q2_ < Lq2 ? q2_ : Lq2 - 1];                                                    \
+    }                                                                                           \
   }
 #define STAGE_WRITE(buf_)                                                                       \
   {                                                                                             \
@@ -91,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
       reinterpret_cast<float*>(base_ + 2 * TILE)[tid] = lreg;                                   \
       reinterpret_cast<float*>(base_ + 2 * TILE + QROWS * 4)[tid] = dreg;                       \
     }                                                                                           \
+    if (DROP && tid < QROWS / 2) reinterpret_cast<uint32_t*>(base_ + 2 * TILE + 2 * QROWS * 4)[tid] = rkreg; \
   }
 
   f32x16 dkacc[2], dvacc[2];
@@ -110,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
     const char* dob = qb + TILE;
     const float* lse_s = reinterpret_cast<const float*>(qb + 2 * TILE);
     const float* del_s = lse_s + QROWS;
+    const uint32_t* rk_s = reinterpret_cast<const uint32_t*>(del_s + QROWS);
 
     f32x16 sacc[2], dpacc[2];
 #pragma unroll
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + sb * 32 + 8 * g + 4 * lh);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + sb * 32 + 8 * g + 4 * lh);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sacc[sb][4 * g + j] = l4[j]; dpacc[sb][4 * g + j] = d4[j]; }
+        for (int j = 0; j < 4; ++j) { sacc[sb][4 * g + j] = l4[j]; dpacc[sb][4 * g + j] = DROP ? 0.f : d4[j]; }
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -139,13 +151,31 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
           pv = ok ? pv : 0.f;
         }
         sacc[sb][r] = pv;
-        dpacc[sb][r] = pv * dpacc[sb][r];
+        if (DROP) {      // dA = dD * M / (1 - p);  dS = P * (dA - delta) with the UNdropped P
+          const int qi = sb * 32 + acc_row(r, lh);
+          const uint32_t x = attn_drop_block(rk_s[qi >> 1], kp2);
+          const bool keep = ((x >> (8 * ((qi & 1) * 2 + (kpos & 1)))) & 0xFFu) >= p.drop_thresh;
+          dpacc[sb][r] = pv * ((keep ? dpacc[sb][r] * p.drop_inv : 0.f) + del_s[qi]);
+        } else {
+          dpacc[sb][r] = pv * dpacc[sb][r];
+        }
       }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = acc_to_frag(sacc[sb], s), dsf = acc_to_frag(dpacc[sb], s);
+        bf16x8 pf = acc_to_frag(sacc[sb], s);
+        const bf16x8 dsf = acc_to_frag(dpacc[sb], s);
+        if (DROP) {      // dV uses the dropped probabilities: word i = query rows (2*q2, 2*q2 + 1) of this lane's key
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 w = __builtin_bit_cast(u32x4, pf);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int q2i = sb * 16 + (i & 1) + 4 * (2 * s + (i >> 1)) + 2 * lh;
+            w[i] &= attn_drop_pair_mask(attn_drop_block(rk_s[q2i], kp2), ksel, th2);
+          }
+          pf = __builtin_bit_cast(bf16x8, w);
+        }
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           dvacc[db] = mfma_bf16(lds_tr_frag(dob, sb * 32 + 16 * s, db, lane), pf, dvacc[db]);   // dV^T[d,key] += dO^T[d,q] P[q,key]
@@ -168,7 +198,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
         const int d = db * 32 + 8 * g + 4 * lh;
         bf16x4 k4 = {(bf16_t)(dkacc[db][4 * g] * p.scale), (bf16_t)(dkacc[db][4 * g + 1] * p.scale),
                      (bf16_t)(dkacc[db][4 * g + 2] * p.scale), (bf16_t)(dkacc[db][4 * g + 3] * p.scale)};
-        bf16x4 v4 = {(bf16_t)dvacc[db][4 * g], (bf16_t)dvacc[db][4 * g + 1], (bf16_t)dvacc[db][4 * g + 2], (bf16_t)dvacc[db][4 * g + 3]};
+        const float vs_ = DROP ? p.drop_inv : 1.f;
+        bf16x4 v4 = {(bf16_t)(dvacc[db][4 * g] * vs_), (bf16_t)(dvacc[db][4 * g + 1] * vs_), (bf16_t)(dvacc[db][4 * g + 2] * vs_),
+                     (bf16_t)(dvacc[db][4 * g + 3] * vs_)};
         *reinterpret_cast<bf16x4*>(dkp + d) = k4;
         *reinterpret_cast<bf16x4*>(dvp + d) = v4;
       }
@@ -179,6 +211,11 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
 
 void launch_attn_dkdv_bf16(const AttnParams& p, int max_keys, hipStream_t st) {
   dim3 grid((max_keys + 127) / 128, p.H, p.B), block(256);
-  if (p.kv_idx) hipLaunchKernelGGL(attn_dkdv_bf16_kernel<true>, grid, block, 0, st, p);
-  else hipLaunchKernelGGL(attn_dkdv_bf16_kernel<false>, grid, block, 0, st, p);
+  if (p.drop_thresh) {
+    if (p.kv_idx) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, true>), grid, block, 0, st, p);
+  } else {
+    if (p.kv_idx) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, false>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, false>), grid, block, 0, st, p);
+  }
 }

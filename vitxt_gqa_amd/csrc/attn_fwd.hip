@@ -49,12 +49,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnParams p) {
   const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
 
   float qf[32];
+  const int qrc = qrow < p.Lq ? qrow : p.Lq - 1;
   {
-    const int qr = qrow < p.Lq ? qrow : p.Lq - 1;
-    const float* qp = Q + (int64_t)qr * p.q_rs + lh;
+    const float* qp = Q + (int64_t)qrc * p.q_rs + lh;
 #pragma unroll
     for (int t = 0; t < 32; ++t) qf[t] = qp[2 * t];
   }
+  const uint32_t rk = p.drop_thresh ? p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qrc >> 1)] : 0u;
   f32x16 oacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
@@ -113,8 +114,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pv = fast_exp2(sacc[kbk][r] * c - mc);
-        sacc[kbk][r] = pv;
-        lsum += pv;
+        lsum += pv;                                        // the normaliser sums the UNdropped probabilities
+        const bool keep = !p.drop_thresh || attn_drop_keep(rk, qrc, t * BK + kbk * 32 + acc_row(r, lh), p.drop_thresh);
+        sacc[kbk][r] = keep ? pv : 0.f;
       }
     l_run = l_run * alpha + lsum;
 #pragma unroll
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnParams p) {
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (p.drop_thresh ? p.drop_inv : 1.f);
   float* __restrict__ O = reinterpret_cast<float*>(p.out) + (int64_t)b * p.o_bs + h * 64;
   if (qrow < p.Lq) {
 #pragma unroll
@@ -181,6 +183,19 @@ __global__ __launch_bounds__(256) void compact_keys_kernel(const uint8_t* __rest
   if (tid == 0) out_cnt[b] = n;
 }
 
+__global__ __launch_bounds__(256) void attn_drop_rowkeys_kernel(uint32_t* __restrict__ rowkey, int64_t n, uint32_t seed_lo, uint32_t seed_hi) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    rowkey[i] = attn_hash32(attn_hash32((uint32_t)i + seed_lo) ^ seed_hi);
+}
+
+__global__ __launch_bounds__(256) void attn_drop_mask_kernel(uint8_t* __restrict__ out, const uint32_t* __restrict__ rowkey, int H, int Lq,
+                                                            int Lk, uint32_t thresh) {
+  const int b = blockIdx.z, h = blockIdx.y, q = blockIdx.x;
+  const uint32_t rk = rowkey[((int64_t)b * H + h) * ((Lq + 1) >> 1) + (q >> 1)];
+  for (int k = threadIdx.x; k < Lk; k += 256)
+    out[(((int64_t)b * H + h) * Lq + q) * Lk + k] = attn_drop_keep(rk, q, k, thresh) ? 1 : 0;
+}
+
 int check_common(const AttnParams& p, int dtype) {
   T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "attn: bad dtype %d", dtype);
   T2S_CHECK_ARG(p.B > 0 && p.H > 0 && p.Lq > 0 && p.idx_cap > 0, "attn: bad shape B=%d H=%d Lq=%d cap=%d", p.B, p.H, p.Lq, p.idx_cap);
@@ -195,6 +210,42 @@ int check_common(const AttnParams& p, int dtype) {
 
 }  // namespace
 
+void launch_attn_drop_rowkeys(uint32_t* rowkey, int B, int H, int Lq, uint64_t seed, hipStream_t st) {
+  const int64_t n = (int64_t)B * H * ((Lq + 1) >> 1);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(attn_drop_rowkeys_kernel, dim3((unsigned)blocks), dim3(256), 0, st, rowkey, n, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// shared by the forward / backward entry points: validates the dropout arguments and fills the table + params
+int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, hipStream_t st, const char* who) {
+  p.drop_rowkey = nullptr;
+  p.drop_thresh = 0;
+  p.drop_inv = 1.f;
+  if (drop_p <= 0.f) return 0;
+  T2S_CHECK_ARG(drop_p < 1.f, "%s: dropout probability %f outside [0, 1)", who, drop_p);
+  T2S_CHECK_ARG(drop_ws != nullptr, "%s: dropout needs the drop_ws workspace (B*H*ceil(Lq/2) uint32)", who);
+  int th = (int)(drop_p * 256.f + 0.5f);
+  th = th < 1 ? 1 : (th > 255 ? 255 : th);
+  p.drop_thresh = (uint32_t)th;
+  p.drop_inv = 256.f / (256.f - (float)th);
+  p.drop_rowkey = drop_ws;
+  launch_attn_drop_rowkeys(drop_ws, p.B, p.H, p.Lq, drop_seed, st);
+  return 0;
+}
+
+extern "C" int t2s_attn_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p, uint64_t drop_seed, uint32_t* drop_ws,
+                                     t2s_stream_t stream) {
+  T2S_CHECK_ARG(out && B > 0 && H > 0 && Lq > 0 && Lk > 0 && B <= 65535 && H <= 65535, "attn_dropout_mask: bad arguments");
+  AttnParams p = {};
+  p.B = B; p.H = H; p.Lq = Lq;
+  if (int e = attn_setup_dropout(p, drop_p, drop_seed, drop_ws, (hipStream_t)stream, "attn_dropout_mask")) return e;
+  T2S_CHECK_ARG(p.drop_thresh != 0, "attn_dropout_mask: drop_p must be > 0");
+  hipLaunchKernelGGL(attn_drop_mask_kernel, dim3(Lq, H, B), dim3(256), 0, (hipStream_t)stream, out, p.drop_rowkey, H, Lq, Lk, p.drop_thresh);
+  T2S_CHECK_LAUNCH("attn_dropout_mask");
+  return 0;
+}
+
 extern "C" int t2s_compact_keys(const uint8_t* valid, int32_t* out_idx, int32_t* out_cnt, int B, int L, int idx_cap,
                                 int n_dec, int dec_row0, t2s_stream_t stream) {
   T2S_CHECK_ARG(valid && out_idx && out_cnt, "compact_keys: null pointer");
@@ -207,7 +258,8 @@ extern "C" int t2s_compact_keys(const uint8_t* valid, int32_t* out_idx, int32_t*
 extern "C" int t2s_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, const int32_t* kv_idx,
                             const int32_t* kv_cnt, int B, int H, int Lq, int idx_cap, int n_dec, int dec_q0,
                             int64_t q_row_stride, int64_t q_batch_stride, int64_t kv_row_stride, int64_t kv_batch_stride,
-                            int64_t o_row_stride, int64_t o_batch_stride, float scale, int dtype, t2s_stream_t stream) {
+                            int64_t o_row_stride, int64_t o_batch_stride, float scale, int dtype, float drop_p, uint64_t drop_seed,
+                            uint32_t* drop_ws, t2s_stream_t stream) {
   T2S_CHECK_ARG(q && k && v && out && lse, "attn_fwd: null pointer");
   AttnParams p = {};
   p.q = q; p.k = k; p.v = v; p.out = out; p.lse = lse; p.kv_idx = kv_idx; p.kv_cnt = kv_cnt;
@@ -217,6 +269,7 @@ extern "C" int t2s_attn_fwd(const void* q, const void* k, const void* v, void* o
   if (int e = check_common(p, dtype)) return e;
   dim3 grid((Lq + BQ - 1) / BQ, H, B), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (int e = attn_setup_dropout(p, drop_p, drop_seed, drop_ws, st, "attn_fwd")) return e;
   if (dtype == T2S_BF16) {
     launch_attn_fwd_bf16(p, st);
   } else {

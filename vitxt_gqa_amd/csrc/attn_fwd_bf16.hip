@@ -11,7 +11,7 @@ namespace {
 constexpr int BK = 64;    // keys per tile
 constexpr int TILE_BYTES = BK * 128;
 
-template <bool USE_IDX, int QB>
+template <bool USE_IDX, int QB, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];   // [buf][K,V]
   constexpr int BQ = 128 * QB;
@@ -29,10 +29,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   // Q fragments: B operand of S^T = K Q^T; lane (q = lr, half lh) holds Q[q][16s + 8lh .. +7]
   bf16x8 qf[QB][4];
   int qdec[QB];             // decoder step of the lane's query row (negative: not a decoder row)
+  uint32_t rk[QB], dsel[QB];   // dropout: row hash key and byte selector of the lane's query row
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int qrow = q0 + qb * 32 + lr;
     const int qr = qrow < p.Lq ? qrow : p.Lq - 1;
+    if (DROP) {
+      rk[qb] = p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qr >> 1)];
+      dsel[qb] = (qr & 1) ? attn_drop_sel(2, 3) : attn_drop_sel(0, 1);
+    }
     const bf16_t* qp = Q + (int64_t)qr * p.q_rs + 8 * lh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
@@ -156,7 +161,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       for (int s = 0; s < 2; ++s) {
         bf16x8 pf[QB];
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) pf[qb] = acc_to_frag(sacc[qb][kbk], s);
+        for (int qb = 0; qb < QB; ++qb) {
+          pf[qb] = acc_to_frag(sacc[qb][kbk], s);
+          if (DROP) {     // word i of the fragment = keys (2*kp2, 2*kp2 + 1) of this lane's query row
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 w = __builtin_bit_cast(u32x4, pf[qb]);
+            const uint32_t th2 = p.drop_thresh | (p.drop_thresh << 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t kp2 = (uint32_t)(t * 32 + kbk * 16 + 8 * s + 4 * (i >> 1) + (i & 1) + 2 * lh);
+              w[i] &= attn_drop_pair_mask(attn_drop_block(rk[qb], kp2), dsel[qb], th2);
+            }
+            pf[qb] = __builtin_bit_cast(bf16x8, w);
+          }
+        }
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const bf16x8 vf = lds_tr_frag(vb, kbk * 32 + 16 * s, db, lane);
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   for (int qb = 0; qb < QB; ++qb) {
     const int qrow = q0 + qb * 32 + lr;
     const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (DROP ? p.drop_inv : 1.f);   // normaliser uses the UNdropped sum
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -206,16 +224,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 
 }  // namespace
 
-void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st) {
+template <bool DROP>
+static void launch_fwd(const AttnParams& p, hipStream_t st) {
   const bool wide = p.Lq > 256;       // 64 rows per wave once there is more than one workgroup of queries
   dim3 block(256);
   if (wide) {
     dim3 grid((p.Lq + 255) / 256, p.H, p.B);
-    if (p.kv_idx) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, 2>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, 2>), grid, block, 0, st, p);
+    if (p.kv_idx) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, 2, DROP>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, 2, DROP>), grid, block, 0, st, p);
   } else {
     dim3 grid((p.Lq + 127) / 128, p.H, p.B);
-    if (p.kv_idx) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, 1>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, 1>), grid, block, 0, st, p);
+    if (p.kv_idx) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, 1, DROP>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, 1, DROP>), grid, block, 0, st, p);
   }
+}
+
+void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st) {
+  if (p.drop_thresh) launch_fwd<true>(p, st);
+  else launch_fwd<false>(p, st);
 }

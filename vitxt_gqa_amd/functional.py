@@ -33,14 +33,15 @@ class BertLayerFn(torch.autograd.Function):
     (y_lo is y itself in fp32 mode).  Weights arrive in the operand dtype; LayerNorm affine stays fp32."""
 
     @staticmethod
-    def forward(ctx, x, x_lo, keys, w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2, drop_p=0.0, seeds=(0, 0)):
+    def forward(ctx, x, x_lo, keys, w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2, drop_p=0.0, seeds=(0, 0, 0),
+                attn_drop_p=0.0):
         B, L, _ = x.shape
         dt = w_qkv.dtype
         lo = dt != F32
         x2 = x.contiguous().view(B * L, HID)
         xl = (x_lo if x_lo is not None else x.to(dt)).contiguous().view(B * L, HID)
         qkv = _mm_bias(xl, w_qkv, b_qkv).view(B, L, 3 * HID)
-        att, lse = ops.attn_fwd(qkv, keys)
+        att, lse = ops.attn_fwd(qkv, keys, drop_p=attn_drop_p, drop_seed=seeds[2])
         a = _mm_bias(att.view(B * L, HID), w_ao, b_ao)
         y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[0])
         del a
@@ -50,7 +51,7 @@ class BertLayerFn(torch.autograd.Function):
         o = _mm_bias(gact, w_o, b_o)
         y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, y1, g2, be2, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[1])
         ctx.keys = keys
-        ctx.drop = (drop_p, seeds)
+        ctx.drop = (drop_p, seeds, attn_drop_p)
         ctx.recompute = RECOMPUTE_ACTIVATIONS
         if ctx.recompute:      # store less: GELU output and the LN1 operand copy are rebuilt in backward
             gact = y1_op = None
@@ -69,7 +70,7 @@ class BertLayerFn(torch.autograd.Function):
         lo = dt != F32
         dy = dy.contiguous().view(B * L, HID)
         # ---- output LayerNorm + FFN
-        drop_p, seeds = ctx.drop
+        drop_p, seeds, attn_drop_p = ctx.drop
         dz2, dz2x, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[1])
         if gact is None:
             gact = ops.gelu_fwd(u)
@@ -94,13 +95,13 @@ class BertLayerFn(torch.autograd.Function):
         datt = (dz1x @ w_ao).view(B, L, HID)
         del dz1x
         # ---- attention
-        dqkv = ops.attn_bwd(qkv, att, datt, lse, keys).view(B * L, 3 * HID)
+        dqkv = ops.attn_bwd(qkv, att, datt, lse, keys, drop_p=attn_drop_p, drop_seed=seeds[2]).view(B * L, 3 * HID)
         del datt
         dw_qkv = dqkv.t() @ xl
         db_qkv = dqkv.sum(0)
         dx = torch.addmm(dz1, dqkv, w_qkv)                                   # + residual branch of LN1
         return (dx.view(B, L, HID), None, None, dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1,
-                dw_i, db_i.to(dt), dw_o, db_o, dg2, dbe2, None, None)
+                dw_i, db_i.to(dt), dw_o, db_o, dg2, dbe2, None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -201,9 +202,10 @@ def _fresh_seed():
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
-def bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout=0.0):
+def bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout=0.0, attn_dropout=0.0):
     """lp: a module holding one layer's parameters under the reference's names (see t2s.BertLayerParams).
-    hidden_dropout: p of the dropout after the attention-output and FFN-output dense layers (training only).
+    hidden_dropout: p of the dropout after the attention-output and FFN-output dense layers (training only);
+    attn_dropout: p of the attention-probability dropout.
     Returns (y fp32, y_lo operand dtype)."""
     att = lp.attention
     w_qkv = torch.cat([att.self.query.weight, att.self.key.weight, att.self.value.weight], 0).to(dtype)
@@ -215,14 +217,16 @@ def bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout=0.0):
         lp.intermediate.dense.weight.to(dtype), lp.intermediate.dense.bias.to(dtype),
         lp.output.dense.weight.to(dtype), lp.output.dense.bias.to(dtype),
         lp.output.LayerNorm.weight, lp.output.LayerNorm.bias,
-        float(hidden_dropout), (_fresh_seed(), _fresh_seed()) if hidden_dropout > 0 else (0, 0))
+        float(hidden_dropout),
+        (_fresh_seed(), _fresh_seed(), _fresh_seed()) if (hidden_dropout > 0 or attn_dropout > 0) else (0, 0, 0),
+        float(attn_dropout))
 
 
-def bert_encoder(x, keys, layers, dtype, hidden_dropout=0.0):
+def bert_encoder(x, keys, layers, dtype, hidden_dropout=0.0, attn_dropout=0.0):
     """x: fp32 [B, L, 768] -> fp32."""
     x_lo = None
     for lp in layers:
-        x, x_lo = bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout)
+        x, x_lo = bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout, attn_dropout)
     return x
 
 

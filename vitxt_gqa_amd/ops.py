@@ -49,7 +49,20 @@ def _attn_views(qkv):
     return qkv[..., :HID], qkv[..., HID:2 * HID], qkv[..., 2 * HID:]
 
 
-def attn_fwd(qkv, keys, scale=1.0 / 8.0):
+def _drop_ws(B, L, drop_p, device):
+    return torch.empty(B * HEADS * ((L + 1) // 2), dtype=torch.int32, device=device) if drop_p > 0 else None
+
+
+def attn_dropout_mask(B, Lq, Lk, drop_p, drop_seed, device):
+    """[B, 12, Lq, Lk] 0/1 keep mask of the attention-probability dropout (Lk = key-list positions); tests."""
+    out = torch.empty(B, HEADS, Lq, Lk, dtype=torch.uint8, device=device)
+    ws = _drop_ws(B, Lq, drop_p, device)
+    X.check(X.lib().t2s_attn_dropout_mask(X.ptr(out), B, HEADS, Lq, Lk, float(drop_p), int(drop_seed), X.ptr(ws), X.stream()),
+            "t2s_attn_dropout_mask")
+    return out
+
+
+def attn_fwd(qkv, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0):
     """Self-attention over a fused QKV buffer [B, L, 2304].  Returns (ctx [B, L, 768], lse [B, 12, L])."""
     B, L, _ = qkv.shape
     q, k, v = _attn_views(qkv)
@@ -60,11 +73,12 @@ def attn_fwd(qkv, keys, scale=1.0 / 8.0):
         X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(lse), X.ptr(keys.idx), X.ptr(keys.cnt),
         B, HEADS, L, keys.idx.shape[1], keys.n_dec, keys.dec_q0,
         qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
-        scale, X.dtype_code(qkv), X.stream()), "t2s_attn_fwd")
+        scale, X.dtype_code(qkv), float(drop_p), int(drop_seed), X.ptr(_drop_ws(B, L, drop_p, qkv.device)), X.stream()),
+        "t2s_attn_fwd")
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0):
+def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0):
     """Returns dqkv [B, L, 2304] (rows of keys outside the key list get exact zeros in the K/V thirds)."""
     B, L, _ = qkv.shape
     q, k, v = _attn_views(qkv)
@@ -80,7 +94,8 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0):
         X.ptr(dq), X.ptr(dk), X.ptr(dv), X.ptr(keys.idx), X.ptr(keys.cnt),
         B, HEADS, L, cap, keys.n_dec, keys.dec_q0, keys.cap_hint,
         qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
-        scale, X.dtype_code(qkv), X.stream()), "t2s_attn_bwd")
+        scale, X.dtype_code(qkv), float(drop_p), int(drop_seed), X.ptr(_drop_ws(B, L, drop_p, qkv.device)), X.stream()),
+        "t2s_attn_bwd")
     return dqkv
 
 
@@ -100,7 +115,7 @@ def attn_fwd_rows(q_rows, kv_buf, keys, scale=1.0 / 8.0):
         X.ptr(q_rows), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(lse), X.ptr(keys.idx), X.ptr(keys.cnt),
         B, HEADS, Lq, keys.idx.shape[1], keys.n_dec, 0,
         q_rows.stride(1), q_rows.stride(0), kv_buf.stride(1), kv_buf.stride(0), out.stride(1), out.stride(0),
-        scale, X.dtype_code(kv_buf), X.stream()), "t2s_attn_fwd")
+        scale, X.dtype_code(kv_buf), 0.0, 0, None, X.stream()), "t2s_attn_fwd")
     return out
 
 

@@ -61,26 +61,19 @@ class BertEncoderParams(nn.Module):
         self.layer = nn.ModuleList([BertLayerParams() for _ in range(num_layers)])
 
 
-_WARNED_ATTN_DROPOUT = [False]
-
-
 def _dropout_cfg(module, config):
     """BertConfig defaults (Appendix A, Q1): hidden_dropout_prob = attention_probs_dropout_prob = 0.1 unless the yml
-    section overrides them.  Hidden dropout is fused into the residual+LayerNorm kernels; attention-probability
-    dropout is not implemented yet and is reported once."""
+    section overrides them.  Hidden dropout is fused into the residual+LayerNorm kernels, attention-probability
+    dropout into the attention kernels."""
     module.hidden_dropout = float(config.get("hidden_dropout_prob", 0.1))
     module.attn_dropout = float(config.get("attention_probs_dropout_prob", 0.1))
 
 
 def _train_dropout(module):
+    """(hidden, attention) dropout probabilities in effect: the configured ones in training, 0 in eval."""
     if not module.training:
-        return 0.0
-    if module.attn_dropout > 0 and not _WARNED_ATTN_DROPOUT[0]:
-        _WARNED_ATTN_DROPOUT[0] = True
-        import warnings
-        warnings.warn("attention_probs_dropout_prob=%g is not applied by the MI355X attention kernel yet "
-                      "(hidden-state dropout is); set it to 0 to silence this" % module.attn_dropout)
-    return module.hidden_dropout
+        return 0.0, 0.0
+    return module.hidden_dropout, module.attn_dropout
 
 
 def _bert_init(module):
@@ -116,11 +109,11 @@ class TextBert(nn.Module):
         x = (e.word_embeddings(txt_inds) + e.position_embeddings.weight[:L].unsqueeze(0)
              + e.token_type_embeddings.weight[0])
         x = FN.layer_norm(x, e.LayerNorm.weight, e.LayerNorm.bias)
-        pd = _train_dropout(self)
+        pd, pa = _train_dropout(self)
         if pd > 0:
             x = F.dropout(x, pd, True)                      # BertEmbeddings dropout
         keys = ops.compact_keys(txt_mask > 0)
-        return FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd)
+        return FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd, pa)
 
 
 class QTV(nn.Module):
@@ -136,7 +129,7 @@ class QTV(nn.Module):
         txt, obj, ocr = fwd["txt_emb"], fwd["obj_mmt_in"], fwd["ocr_mmt_in"]
         x = torch.cat([txt, obj, ocr], dim=1)
         valid = torch.cat([fwd["txt_mask"] > 0, fwd["obj_mask"] > 0, fwd["ocr_mask"] > 0], dim=1)
-        out = FN.bert_encoder(x, ops.compact_keys(valid), self.encoder.layer, dtype, _train_dropout(self))
+        out = FN.bert_encoder(x, ops.compact_keys(valid), self.encoder.layer, dtype, *_train_dropout(self))
         T, Fn = txt.size(1), obj.size(1)
         fwd["txt_emb"] = txt + torch.tanh(out[:, :T])
         fwd["obj_mmt_in"] = obj + torch.tanh(out[:, T:T + Fn])
@@ -263,7 +256,7 @@ class MMT(nn.Module):
 
     def forward(self, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, fixed_ans_emb, prev_inds, dtype,
                 max_keys=None):
-        pd = _train_dropout(self)
+        pd, pa = _train_dropout(self)
         dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd)
         x = torch.cat([txt_emb, obj_emb, ocr_emb, dec_emb], dim=1)
         T, Fn, N, D = txt_emb.size(1), obj_emb.size(1), ocr_emb.size(1), dec_emb.size(1)
@@ -271,7 +264,7 @@ class MMT(nn.Module):
         valid = torch.cat([txt_mask > 0, obj_mask > 0, ocr_mask > 0], dim=1)
         # decoder keys: step j visible to decoder row i iff i >= j; prefix rows never see them (t2s.py:574-618)
         keys = ops.compact_keys(valid, n_dec=D, dec_row0=L1, cap_hint=max_keys)
-        out = FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd)
+        out = FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd, pa)
         return out[:, T + Fn:L1], out[:, L1:]
 
 

@@ -33,7 +33,7 @@ def make_model(F, P, V, text_vocab=30522, seed=0, attn_gain=1.0, dtype=torch.bfl
     cfg.ocr["dropout_prob"] = dropout
     for sec in ("text_bert", "translayers", "encoder", "mmt"):
         cfg[sec]["hidden_dropout_prob"] = dropout
-        cfg[sec]["attention_probs_dropout_prob"] = 0.0      # not implemented in the attention kernel yet
+        cfg[sec]["attention_probs_dropout_prob"] = dropout
     model = build_model(cfg)
     sd = state_dict if state_dict is not None else make_state_dict(
         state_dict_schema(V, text_vocab=text_vocab), seed=seed, attn_gain=attn_gain)
