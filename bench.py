@@ -47,12 +47,12 @@ class AttnFwdTimer:
         self.events, self.enabled = [], False
 
     def __enter__(self):
-        def timed(qkv, keys, scale=0.125):
+        def timed(qkv, keys, *args, **kwargs):
             if not self.enabled:
-                return self.orig(qkv, keys, scale)
+                return self.orig(qkv, keys, *args, **kwargs)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = self.orig(qkv, keys, scale)
+            r = self.orig(qkv, keys, *args, **kwargs)
             e1.record()
             B, L, _ = qkv.shape
             self.events.append((e0, e1, 4.0 * B * 12 * L * L * 64, L, keys.cnt, keys.n_dec))
