@@ -44,7 +44,9 @@ CASES = [  # B, L1 (prefix rows), n_dec, keep probability
 ]
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+# bf16 tolerance: |out| reaches ~4 and the scores ~12 on this data (std-1.5 inputs); operand roundings of 2^-9 (Q*scale*log2e,
+# P, the output itself) each contribute up to ~1e-2 absolute
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("B,L1,n_dec,keep", CASES)
 def test_attention_fwd_bwd(B, L1, n_dec, keep, dtype, tol):
     _need_gpu()
@@ -75,7 +77,8 @@ def test_attention_fwd_bwd(B, L1, n_dec, keep, dtype, tol):
     q, k, _ = [t.view(B, L, 12, 64).permute(0, 2, 1, 3) for t in xr.detach().split(768, dim=-1)]
     s = (q @ k.transpose(-1, -2)) * 0.125
     s = s.masked_fill(~dense_mask(valid, n_dec, L).unsqueeze(1), float("-inf"))
-    assert (lse.double() - torch.logsumexp(s, -1)).abs().max().item() < (1e-4 if dtype == torch.float32 else 2e-2)
+    # bf16: the kernel folds scale*log2(e) into Q with one more bf16 rounding (2^-9 relative on scores of |s| ~ 10)
+    assert (lse.double() - torch.logsumexp(s, -1)).abs().max().item() < (1e-4 if dtype == torch.float32 else 4e-2)
 
     dqkv = ops.attn_bwd(x, out, dout.to(dtype), lse, keys)
     (gref,) = torch.autograd.grad(ref, xr, dout.to(dtype).double())

@@ -1,0 +1,327 @@
+// bf16 flash-attention forward kernel for gfx950 (see attn_fwd.hip for the design notes and the
+// reference call sites).  Templated on QB = number of 32-row query blocks per wave:
+//   QB = 2: a wave owns 64 query rows (256 per workgroup); every K row fragment and V^T fragment read
+//           from LDS feeds two MFMAs, halving LDS bytes and barriers per MFMA, and the two blocks'
+//           softmax chains give the scheduler independent VALU work to put beside the MFMAs;
+//   QB = 1: 32 rows per wave (128 per workgroup) for short sequences.
+#include <type_traits>
+
+#include "attn_common.h"
+
+#define EX(x) ((ABL & 2) ? (x) : fast_exp2(x))
+namespace {
+
+constexpr int BK = 64;    // keys per tile
+constexpr int TILE_BYTES = BK * 128;
+
+template <bool USE_IDX, int QB, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];   // [buf][K,V]
+  constexpr int BQ = 128 * QB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * BQ + wave * (32 * QB);
+  const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
+  const int nk = n_prefix + p.n_dec;
+  const int ntiles = (nk + BK - 1) / BK;
+  const bf16_t* __restrict__ Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_bs + h * 64;
+  const bf16_t* __restrict__ K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.kv_bs + h * 64;
+  const bf16_t* __restrict__ V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.kv_bs + h * 64;
+  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
+
+  // Q fragments: B operand of S^T = K Q^T; lane (q = lr, half lh) holds Q[q][16s + 8lh .. +7]
+  const float c = p.scale * LOG2E;
+  bf16x8 qf[QB][4];
+  int qdec[QB];             // decoder step of the lane's query row (negative: not a decoder row)
+  uint32_t rk[QB], dsel[QB];   // dropout: row hash key and byte selector of the lane's query row
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qrow = q0 + qb * 32 + lr;
+    const int qr = qrow < p.Lq ? qrow : p.Lq - 1;
+    if (DROP) {
+      rk[qb] = p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qr >> 1)];
+      dsel[qb] = (qr & 1) ? attn_drop_sel(2, 3) : attn_drop_sel(0, 1);
+    }
+    const bf16_t* qp = Q + (int64_t)qr * p.q_rs + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[qb][s][j] = (bf16_t)((float)qf[qb][s][j] * c);    // fold scale*log2e into Q
+    }
+    qdec[qb] = qrow - p.dec_q0;
+  }
+
+  // staging: thread -> (row sr / sr+32, 16-B chunk sc) of the K and V tiles.  Plain named registers and
+  // unconditional (clamped) loads: arrays captured by a lambda or loads under a branch end up in scratch.
+  const int sr = tid >> 3, sc = tid & 7;
+  uint4 kr0, kr1, vr0, vr1;
+#define STAGE_LOAD(t_)                                                                              \
+  {                                                                                                 \
+    int p0_ = (t_) * BK + sr, p1_ = p0_ + 32;                                                       \
+    p0_ = p0_ < nk ? p0_ : nk - 1;                                                                  \
+    p1_ = p1_ < nk ? p1_ : nk - 1;                                                                  \
+    const int64_t r0_ = USE_IDX ? (int64_t)idx[p0_] : (int64_t)p0_;                                 \
+    const int64_t r1_ = USE_IDX ? (int64_t)idx[p1_] : (int64_t)p1_;                                 \
+    kr0 = *reinterpret_cast<const uint4*>(K + r0_ * p.kv_rs + sc * 8);                              \
+    vr0 = *reinterpret_cast<const uint4*>(V + r0_ * p.kv_rs + sc * 8);                              \
+    kr1 = *reinterpret_cast<const uint4*>(K + r1_ * p.kv_rs + sc * 8);                              \
+    vr1 = *reinterpret_cast<const uint4*>(V + r1_ * p.kv_rs + sc * 8);                              \
+  }
+#define STAGE_WRITE(buf_)                                                                           \
+  {                                                                                                 \
+    char* kb_ = smem + (buf_) * 2 * TILE_BYTES;                                                     \
+    *reinterpret_cast<uint4*>(kb_ + tile_off(sr, sc)) = kr0;                                        \
+    *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + tile_off(sr, sc)) = vr0;                           \
+    *reinterpret_cast<uint4*>(kb_ + tile_off(sr + 32, sc)) = kr1;                                   \
+    *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + tile_off(sr + 32, sc)) = vr1;                      \
+  }
+
+  f32x16 oacc[QB][2];
+  // Running row maximum m (log2 units: Q is pre-scaled by scale*log2e) and the accumulator seed negm = -m in all 16
+  // registers.  The steady-state tile starts its S accumulators AT -m, so P = exp2(S - m) is one v_exp per element
+  // with no subtract, and it never computes a row maximum: m only has to be close enough for exp2 not to overflow,
+  // which the row sum itself certifies (every P >= 0, so sum < BIG bounds each of them).  A tile whose sum fails
+  // the test - the first tiles of a row, or a late outlier - is redone by the general path, which finds the true
+  // maximum, rescales O and l and reseeds negm.  Softmax is shift-invariant, so the result is the same function.
+  float m_run[QB], l_run[QB];
+  f32x16 negm[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[qb][0][i] = 0.f; oacc[qb][1][i] = 0.f; negm[qb][i] = INFINITY; }
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.f;
+  }
+  constexpr float BIG = 1.0995116e12f;     // 2^40: P stays far inside bf16/fp32 range
+
+  if (ntiles > 0) {
+    STAGE_LOAD(0);
+    STAGE_WRITE(0);
+  }
+  __syncthreads();
+
+  // ---- O^T[d, q] += V^T[d, key] P^T[key, q] for the tile in buffer vb_ (P in sacc)
+#define PV_PHASE(vb_, t_)                                                                           \
+  _Pragma("unroll") for (int kbk = 0; kbk < 2; ++kbk)                                               \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
+    bf16x8 pf[QB];                                                                                  \
+    _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) {                                             \
+      pf[qb] = acc_to_frag(sacc[qb][kbk], s);                                                       \
+      if (DROP) { /* word i of the fragment = keys (2*kp2, 2*kp2 + 1) of this lane's query row */   \
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                 \
+        u32x4 w = __builtin_bit_cast(u32x4, pf[qb]);                                                \
+        const uint32_t th2 = p.drop_thresh | (p.drop_thresh << 16);                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+          const uint32_t kp2 = (uint32_t)((t_) * 32 + kbk * 16 + 8 * s + 4 * (i >> 1) + (i & 1) + 2 * lh); \
+          w[i] &= attn_drop_pair_mask(attn_drop_block(rk[qb], kp2), dsel[qb], th2);                 \
+        }                                                                                           \
+        pf[qb] = __builtin_bit_cast(bf16x8, w);                                                     \
+      }                                                                                             \
+    }                                                                                               \
+    _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                              \
+      const bf16x8 vf = (ABL & 8) ? qf[0][2 * s + db] : lds_tr_frag(vb_, kbk * 32 + 16 * s, db, lane);                              \
+      _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = mfma_bf16(vf, pf[qb], oacc[qb][db]); \
+    }                                                                                               \
+  }
+
+  // tiles [0, nfast) lie wholly inside the prefix keys: the steady-state loop has no masking code at all
+  const int nfast = (n_prefix / BK) < ntiles ? (n_prefix / BK) : ntiles;
+  int t = 0;
+  while (t < ntiles) {
+    // ---- steady state: seeded accumulators, exp, sum; leaves the loop (tile untouched) when a row sum fails the test
+    for (; t < nfast; ++t) {
+      const int buf = t & 1;
+      {
+        const int tn = t + 1 < ntiles ? t + 1 : t;      // last iteration re-loads its own tile (harmless)
+        if (!(ABL & 1)) { STAGE_LOAD(tn); }
+      }
+      const char* kb = smem + buf * 2 * TILE_BYTES;
+      const char* vb = kb + TILE_BYTES;
+      f32x16 sacc[QB][2];
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 kf = (ABL & 4) ? qf[0][(s + kbk) & 3] : lds_row_frag(kb, kbk * 32 + lr, s, lh);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) sacc[qb][kbk] = mfma_bf16(kf, qf[qb][s], s == 0 ? negm[qb] : sacc[qb][kbk]);
+        }
+      float lsum[QB];
+      bool bad = false;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 16; r += 4) {
+            const float p0 = EX(sacc[qb][kbk][r]), p1 = EX(sacc[qb][kbk][r + 1]);
+            const float p2 = EX(sacc[qb][kbk][r + 2]), p3 = EX(sacc[qb][kbk][r + 3]);
+            sacc[qb][kbk][r] = p0; sacc[qb][kbk][r + 1] = p1; sacc[qb][kbk][r + 2] = p2; sacc[qb][kbk][r + 3] = p3;
+            a0 += p0; a1 += p1; a2 += p2; a3 += p3;
+          }
+        lsum[qb] = (a0 + a1) + (a2 + a3);
+        bad |= !(lsum[qb] < BIG);
+      }
+      if (!(ABL & 2) && __any(bad)) break;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) l_run[qb] += lsum[qb];
+      PV_PHASE(vb, t);
+      if (!(ABL & 16)) { STAGE_WRITE(buf ^ 1); }
+      if (!(ABL & 32)) __syncthreads();
+    }
+    if (t >= ntiles) break;
+    // ---- general tile: S from zero, masks, true running maximum, rescale of O and l, reseed of negm
+    {
+      const int buf = t & 1;
+      {
+        const int tn = t + 1 < ntiles ? t + 1 : t;
+        STAGE_LOAD(tn);
+      }
+      const char* kb = smem + buf * 2 * TILE_BYTES;
+      const char* vb = kb + TILE_BYTES;
+      f32x16 sacc[QB][2];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sacc[qb][0][i] = 0.f; sacc[qb][1][i] = 0.f; }
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 kf = lds_row_frag(kb, kbk * 32 + lr, s, lh);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) sacc[qb][kbk] = mfma_bf16(kf, qf[qb][s], sacc[qb][kbk]);
+        }
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pos = t * BK + kbk * 32 + acc_row(r, lh);
+            const bool ok = pos < nk && (pos < n_prefix || qdec[qb] >= pos - n_prefix);
+            const float sv = ok ? sacc[qb][kbk][r] : -INFINITY;
+            sacc[qb][kbk][r] = sv;
+            mx = fmaxf(mx, sv);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[qb], mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m_run[qb] - m_use);
+        m_run[qb] = m_new;
+        float ls = 0.f;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float pv = fast_exp2(sacc[qb][kbk][r] - m_use);
+            sacc[qb][kbk][r] = pv;
+            ls += pv;
+          }
+        l_run[qb] = l_run[qb] * alpha + ls;
+        const float seed = (m_new == -INFINITY) ? INFINITY : -m_new;    // no visible key yet: stay on this path
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          oacc[qb][0][i] *= alpha;
+          oacc[qb][1][i] *= alpha;
+          negm[qb][i] = seed;
+        }
+      }
+      PV_PHASE(vb, t);
+      STAGE_WRITE(buf ^ 1);
+      __syncthreads();
+      ++t;
+    }
+  }
+#undef PV_PHASE
+#undef STAGE_LOAD
+#undef STAGE_WRITE
+
+  // ---- epilogue: normalise, stage O through LDS (per-wave 32 x 64 tile, 144-B rows), store whole rows
+  char* ob = smem + wave * (32 * 144);
+  bf16_t* __restrict__ O = reinterpret_cast<bf16_t*>(p.out) + (int64_t)b * p.o_bs + h * 64;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qrow = q0 + qb * 32 + lr;
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (DROP ? p.drop_inv : 1.f);   // normaliser uses the UNdropped sum
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 t4 = {(bf16_t)(oacc[qb][db][4 * g] * inv), (bf16_t)(oacc[qb][db][4 * g + 1] * inv),
+                     (bf16_t)(oacc[qb][db][4 * g + 2] * inv), (bf16_t)(oacc[qb][db][4 * g + 3] * inv)};
+        const int d = db * 32 + 8 * g + 4 * lh;
+        *reinterpret_cast<bf16x4*>(ob + lr * 144 + d * 2) = t4;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = i * 64 + lane, r = id >> 3, cc = id & 7;
+      const int row = q0 + qb * 32 + r;
+      if (row < p.Lq)
+        *reinterpret_cast<uint4*>(O + (int64_t)row * p.o_rs + cc * 8) = *reinterpret_cast<const uint4*>(ob + r * 144 + cc * 16);
+    }
+    if (lh == 0 && qrow < p.Lq) {
+      const float m_use = (m_run[qb] == -INFINITY) ? 0.f : m_run[qb];
+      p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_use * 0.6931471805599453f + logf(l_tot);   // m is in log2 units
+    }
+    if (qb + 1 < QB) __syncthreads();
+  }
+}
+
+}  // namespace
+
+template <bool DROP>
+static void launch_fwd(const AttnParams& p, hipStream_t st) {
+  const bool wide = p.Lq > 256;       // 64 rows per wave once there is more than one workgroup of queries
+  dim3 block(256);
+  if (wide) {
+    dim3 grid((p.Lq + 255) / 256, p.H, p.B);
+    if (p.kv_idx) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, 2, DROP>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, 2, DROP>), grid, block, 0, st, p);
+  } else {
+    dim3 grid((p.Lq + 127) / 128, p.H, p.B);
+    if (p.kv_idx) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, 1, DROP>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, 1, DROP>), grid, block, 0, st, p);
+  }
+}
+
+void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st) {
+  if (p.drop_thresh) launch_fwd<true>(p, st);
+  else launch_fwd<false>(p, st);
+}
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+int main(int argc, char** argv) {
+  const int B = 8, H = 12, L = 10132, ND = 12;
+  const size_t nqkv = (size_t)B * L * 3 * 768, no = (size_t)B * L * 768, nl = (size_t)B * H * L;
+  std::vector<uint16_t> h(nqkv);
+  srand(1);
+  for (size_t i = 0; i < nqkv; ++i) { float f = (rand() / (float)RAND_MAX - 0.5f) * 3.4f; uint32_t u; memcpy(&u, &f, 4); h[i] = u >> 16; }
+  void *qkv, *out; float *lse;
+  CK(hipMalloc(&qkv, nqkv * 2)); CK(hipMalloc(&out, no * 2)); CK(hipMalloc(&lse, nl * 4));
+  CK(hipMemcpy(qkv, h.data(), nqkv * 2, hipMemcpyHostToDevice));
+  AttnParams p{};
+  p.q = qkv; p.k = (char*)qkv + 768 * 2; p.v = (char*)qkv + 2 * 768 * 2; p.out = out;
+  p.lse = lse; p.kv_idx = nullptr; p.kv_cnt = nullptr;
+  p.B = B; p.H = H; p.Lq = L; p.idx_cap = L; p.n_dec = ND; p.dec_q0 = L - ND;
+  p.q_rs = 3 * 768; p.q_bs = (int64_t)L * 3 * 768; p.kv_rs = 3 * 768; p.kv_bs = p.q_bs; p.o_rs = 768; p.o_bs = (int64_t)L * 768;
+  p.scale = 0.125f; p.drop_thresh = 0; p.drop_inv = 1.f; p.drop_rowkey = nullptr;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  launch_attn_fwd_bf16(p, 0); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < 5; ++i) launch_attn_fwd_bf16(p, 0);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double fl = 2.0 * 2.0 * B * H * (double)L * L * 64;
+  printf("ABL=%d fwd %.3f ms  %.1f TF/s\n", ABL, ms / 5, fl / (ms / 5 * 1e-3) / 1e12);
+  return 0;
+}
