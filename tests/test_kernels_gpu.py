@@ -106,6 +106,32 @@ def test_attention_spiky_rows_force_rescale():
         assert (out.double() - ref).abs().max().item() < tol
 
 
+def test_attention_fwd_repair_launch():
+    """The bf16 steady-state tile has no running maximum: a score more than 2^80 above the row's reference (set by key
+    tile 0) poisons the wave and the repair launch redoes its workgroup through the general path.  Keys of the first
+    tile score ~ -100 for query 3, a late key scores ~ +100 (log2 units ~ 290 apart): exact result required, and the
+    rows of every other workgroup must be untouched by the repair."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    B, L = 1, 900                                            # > 256 rows: 64 rows per wave, 14 whole key tiles
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B, L, 2304, generator=g).to(DEV)
+    q3 = qkv[:, 3, :768].clone()
+    qkv[:, :64, 768:1536] = -q3.unsqueeze(1) * (100.0 * 8 / 64) / (q3.view(12, 64).pow(2).mean()).item()
+    qkv[:, 700, 768:1536] = q3 * (100.0 * 8 / 64) / (q3.view(12, 64).pow(2).mean()).item()
+    keys = ops.compact_keys(torch.ones(B, L, dtype=torch.bool, device=DEV))
+    x = qkv.to(torch.bfloat16)
+    out, lse = ops.attn_fwd(x, keys)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    ref = ref_attention(x.double(), torch.ones(B, L, L, dtype=torch.bool, device=DEV), 0.125)
+    err = (out.double() - ref).abs()
+    # scores reach +-100 here: a 2^-9 operand rounding moves them by ~0.2, i.e. near-tied probabilities by ~20 %
+    assert err.max().item() < 0.15, err.max().item()
+    # query 3 attends (all heads) to key 700 alone
+    v700 = x[:, 700, 1536:].double()
+    assert (out[:, 3].double() - v700).abs().max().item() < 5e-2
+
+
 @pytest.mark.parametrize("xdt,sdt,tol", [(torch.float32, torch.float32, 2e-5), (torch.bfloat16, torch.float32, 2e-5),
                                          (torch.bfloat16, torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("rows", [1, 7, 1000])

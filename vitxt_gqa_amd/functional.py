@@ -28,6 +28,18 @@ def _mm_bias(x2, w, b):
     return torch.addmm(b, x2, w.t())
 
 
+def _wgrad(dy2, x2, B):
+    """dW[out, in] = dy2[rows, out]^T @ x2[rows, in] with rows = B * L.  The contraction runs over ALL rows (648 k at
+    B=64, L=10132) into a tiny output, which the library runs at 0.4-0.8 PFLOP/s as one GEMM; as a batched GEMM per
+    sample (contraction L) followed by an fp32 sum over the B partial products it runs at 0.8-1.1 PFLOP/s
+    (tools/wgrad_probe.py), and the partials are summed in fp32 instead of inside a bf16-output GEMM."""
+    rows = dy2.size(0)
+    if B < 2 or rows // B < 1024 or dy2.dtype == F32:
+        return dy2.t() @ x2
+    part = torch.bmm(dy2.view(B, rows // B, -1).transpose(1, 2), x2.view(B, rows // B, -1))     # [B, out, in]
+    return part.sum(0, dtype=F32).to(dy2.dtype)
+
+
 class BertLayerFn(torch.autograd.Function):
     """(y, y_lo) = BertLayer(x; keys).  x / y: fp32 residual stream; x_lo / y_lo: operand-dtype copies
     (y_lo is y itself in fp32 mode).  Weights arrive in the operand dtype; LayerNorm affine stays fp32."""
@@ -74,7 +86,7 @@ class BertLayerFn(torch.autograd.Function):
         dz2, dz2x, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[1])
         if gact is None:
             gact = ops.gelu_fwd(u)
-        dw_o = dz2x.t() @ gact
+        dw_o = _wgrad(dz2x, gact, B)
         db_o = dz2x.sum(0)
         dgact = dz2x @ w_o
         del gact, dz2x
@@ -84,20 +96,20 @@ class BertLayerFn(torch.autograd.Function):
             y1, y1_lo, _, _ = ops.add_layernorm_fwd(z1, None, g1, be1, save=False, stream_dtype=F32, want_lo=lo, want_y=not lo)
             y1_op = y1_lo if lo else y1
             del y1, y1_lo
-        dw_i = du.t() @ y1_op
+        dw_i = _wgrad(du, y1_op, B)
         dy1 = torch.addmm(dz2, du, w_i)                                      # + residual branch of LN2
         del du, y1_op, dz2
         # ---- attention output LayerNorm + projection
         dz1, dz1x, dg1, dbe1 = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[0])
         del dy1
-        dw_ao = dz1x.t() @ att.view(B * L, HID)
+        dw_ao = _wgrad(dz1x, att.view(B * L, HID), B)
         db_ao = dz1x.sum(0)
         datt = (dz1x @ w_ao).view(B, L, HID)
         del dz1x
         # ---- attention
         dqkv = ops.attn_bwd(qkv, att, datt, lse, keys, drop_p=attn_drop_p, drop_seed=seeds[2]).view(B * L, 3 * HID)
         del datt
-        dw_qkv = dqkv.t() @ xl
+        dw_qkv = _wgrad(dqkv, xl, B)
         db_qkv = dqkv.sum(0)
         dx = torch.addmm(dz1, dqkv, w_qkv)                                   # + residual branch of LN1
         return (dx.view(B, L, HID), None, None, dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1,
