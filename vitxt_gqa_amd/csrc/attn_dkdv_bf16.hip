@@ -8,13 +8,11 @@
 //   S = Q K^T, dP = dO V^T            (A = row reads of the LDS tiles, B = register fragments)
 //   P = exp2(c S - LSE log2e), dS = P (dP - delta)
 //   dV^T += dO^T P, dK^T += Q^T dS    (A = ds_read_b64_tr_b16 reads of the same tiles, B = P / dS accumulators)
-#include <type_traits>
-
 #include "attn_common.h"
 
 namespace {
 
-constexpr int QROWS = 64;                        // query rows per iteration
+constexpr int QROWS = 64;                         // query rows per iteration
 constexpr int TILE = QROWS * 128;                 // bytes of a 64-row bf16 tile
 constexpr int STAGE = 2 * TILE + 2 * QROWS * 4 + (QROWS / 2) * 4;   // Q | dO | -lse | -delta | dropout row keys
 
@@ -58,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) kf[s][j] = (bf16_t)((float)kf[s][j] * c);
   const int nqt = (p.Lq + QROWS - 1) / QROWS;
-  const bool has_dec = p.n_dec > 0 && (kp0 + 128 > n_prefix);    // this workgroup holds decoder keys
+  const bool edge = (kp0 + 128 > n_prefix);
 
   // staging: thread -> rows sr / sr+32, 16-B chunk sc of the Q and dO tiles; plain named registers and
   // unconditional clamped loads (keeps the staging out of scratch memory)
@@ -113,13 +111,6 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   STAGE_LOAD(0);
   STAGE_WRITE(0);
   __syncthreads();
-  // The query sweep exists in two compiled forms selected by ONE workgroup-uniform branch: only the workgroup that
-  // holds the decoder keys needs the causal rule.  (Left inside the loop, the rule is if-converted into 32 compares,
-  // 40 selects and ~100 scalar ops per iteration for every workgroup.)  Lanes whose key lies past the end of the list
-  // need no masking at all: with the key on the lane, their garbage stays in their own dK/dV columns, which are never
-  // stored.
-  auto sweep = [&](auto masked_tag) {
-  constexpr bool MASKED = decltype(masked_tag)::value;
   for (int qt = 0; qt < nqt; ++qt) {
     const int buf = qt & 1;
     {
@@ -154,9 +145,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float pv = fast_exp2(sacc[sb][r]);
-        if (MASKED) {     // decoder key j is visible to query row r iff r - dec_q0 >= j
+        if (edge) {
           const int qdec = qt * QROWS + sb * 32 + acc_row(r, lh) - p.dec_q0;
-          pv = (kdec < 0 || qdec >= kdec) ? pv : 0.f;
+          const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
+          pv = ok ? pv : 0.f;
         }
         sacc[sb][r] = pv;
         if (DROP) {      // dA = dD * M / (1 - p);  dS = P * (dA - delta) with the UNdropped P
@@ -193,9 +185,6 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
     STAGE_WRITE(buf ^ 1);
     __syncthreads();
   }
-  };
-  if (has_dec) sweep(std::true_type{});
-  else sweep(std::false_type{});
 #undef STAGE_LOAD
 #undef STAGE_WRITE
 
