@@ -13,6 +13,8 @@
 //   * dQ: query-stationary, same skeleton as the forward (query on the lane): S^T and dP^T from row
 //     reads of the K and V tiles, dQ^T += K^T dS^T with transposed reads of the K tile.
 // The fp32 variants keep the data flow on v_mfma_f32_32x32x2_f32.
+#include <type_traits>
+
 #include "attn_common.h"
 
 namespace {
@@ -49,7 +51,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 }
 
 // ---------------------------------------------------------------------------------------------
-// dQ, bf16.
+// dQ, bf16.  Query-stationary (query on the lane), 32 query rows per wave, 64-key tiles double-buffered in LDS.
+// VALU diet (these kernels are VALU-issue bound at head_dim 64, see attn_fwd_bf16.hip):
+//   * Q is pre-scaled by scale*log2(e) and the S accumulators are seeded with -LSE*log2(e) through the MFMA C operand, so
+//     P = exp2(S) is ONE v_exp; the dP accumulators are seeded with -delta, so dS = P * dP' is ONE v_mul (with attention
+//     dropout the mask has to act before delta is subtracted, so that variant seeds zero and subtracts);
+//   * per-lane LDS offsets computed once (4 row-fragment + 4 transposed-fragment addresses), global staging through a
+//     uniform base + 32-bit lane offset;
+//   * the unmasked tiles [0, nfast) run a loop with no masking code; the edge tiles run the same body with the masks;
+//   * the tile body is a wavefront S,dP(block 0) | S,dP(block 1) + softmax(block 0) | dQ(block 0) + softmax(block 1) |
+//     dQ(block 1) with scheduling fences between the stages.
 template <bool USE_IDX, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE64];   // [buf][K, V]
@@ -62,9 +73,11 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
   const int nk = n_prefix + p.n_dec;
   const int ntiles = (nk + BK - 1) / BK;
-  const bf16_t* __restrict__ K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.kv_bs + h * 64;
-  const bf16_t* __restrict__ V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.kv_bs + h * 64;
+  const int nfast = n_prefix / BK;                  // tiles [0, nfast) lie wholly inside the prefix keys: no masks
+  const char* __restrict__ K = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.kv_bs + h * 64);
+  const char* __restrict__ V = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.kv_bs + h * 64);
   const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
+  const float c = p.scale * LOG2E;
 
   bf16x8 qf[4], dof[4];
   {
@@ -74,35 +87,79 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
     for (int s = 0; s < 4; ++s) {
       qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
       dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (bf16_t)((float)qf[s][j] * c);
     }
   }
-  const float lse2 = qvalid ? p.lse[((int64_t)b * p.H + h) * p.Lq + qr] * LOG2E : INFINITY;
+  // accumulator seeds, constant for the whole kernel: -LSE*log2e (rows past Lq: -inf => P = 0) and -delta
   const float del = p.delta[((int64_t)b * p.H + h) * p.Lq + qr];
-  const float c = p.scale * LOG2E;
+  f32x16 seed_s, seed_dp;
+  {
+    const float nl = qvalid ? -p.lse[((int64_t)b * p.H + h) * p.Lq + qr] * LOG2E : -INFINITY;
+    const float nd = DROP ? 0.f : -del;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { seed_s[i] = nl; seed_dp[i] = nd; }
+  }
   const int qdec = qrow - p.dec_q0;
   const uint32_t rk = DROP ? p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qr >> 1)] : 0u;
 
+  int ka[4];                 // row fragment: row lr, chunk 2s + lh
+#pragma unroll
+  for (int s = 0; s < 4; ++s) ka[s] = tile_off(lr, 2 * s + lh);
+  int va[2][2];              // transposed fragment: rows 4lh + qq (+8), chunk 4db + 2g1 + (pp >> 1)
+  {
+    const int g1 = (lane >> 4) & 1, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = 4 * db + 2 * g1 + (pp >> 1);
+      va[db][0] = tile_off(4 * lh + qq, chunk) + ((pp & 1) << 3);
+      va[db][1] = tile_off(4 * lh + qq + 8, chunk) + ((pp & 1) << 3);
+    }
+  }
+#define ROW_FRAG(off_, blk_, s_) (*reinterpret_cast<const bf16x8*>(smem + (ka[s_] + (off_)) + (blk_) * 4096))
+  auto tr_frag = [&](const int off, const int rbase, const int db) __attribute__((always_inline)) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(smem + (va[db][0] + off) + rbase * 128));
+    const s16x4 bb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(smem + (va[db][1] + off) + rbase * 128));
+    const s16x8 cc = {a[0], a[1], a[2], a[3], bb[0], bb[1], bb[2], bb[3]};
+    return __builtin_bit_cast(bf16x8, cc);
+  };
+
   const int sr = tid >> 3, sc = tid & 7;
   uint4 kr0, kr1, vr0, vr1;
-#define STAGE_LOAD(t_)                                                                              \
+  // key-list lookups run one tile ahead of the row loads that depend on them (otherwise every tile waits out a full
+  // index-load latency before its K/V loads can even be issued)
+  uint32_t ri0, ri1;
+#define IDX_LOAD(t_)                                                                                \
   {                                                                                                 \
     int p0_ = (t_) * BK + sr, p1_ = p0_ + 32;                                                       \
     p0_ = p0_ < nk ? p0_ : nk - 1;                                                                  \
     p1_ = p1_ < nk ? p1_ : nk - 1;                                                                  \
-    const int64_t r0_ = USE_IDX ? (int64_t)idx[p0_] : (int64_t)p0_;                                 \
-    const int64_t r1_ = USE_IDX ? (int64_t)idx[p1_] : (int64_t)p1_;                                 \
-    kr0 = *reinterpret_cast<const uint4*>(K + r0_ * p.kv_rs + sc * 8);                              \
-    vr0 = *reinterpret_cast<const uint4*>(V + r0_ * p.kv_rs + sc * 8);                              \
-    kr1 = *reinterpret_cast<const uint4*>(K + r1_ * p.kv_rs + sc * 8);                              \
-    vr1 = *reinterpret_cast<const uint4*>(V + r1_ * p.kv_rs + sc * 8);                              \
+    ri0 = USE_IDX ? (uint32_t)idx[p0_] : (uint32_t)p0_;                                             \
+    ri1 = USE_IDX ? (uint32_t)idx[p1_] : (uint32_t)p1_;                                             \
+  }
+#define STAGE_LOAD_ROWS()                                                                           \
+  {                                                                                                 \
+    const uint32_t o0_ = (ri0 * (uint32_t)p.kv_rs + (uint32_t)sc * 8u) * 2u;                        \
+    const uint32_t o1_ = (ri1 * (uint32_t)p.kv_rs + (uint32_t)sc * 8u) * 2u;                        \
+    kr0 = *reinterpret_cast<const uint4*>(K + o0_);                                                 \
+    vr0 = *reinterpret_cast<const uint4*>(V + o0_);                                                 \
+    kr1 = *reinterpret_cast<const uint4*>(K + o1_);                                                 \
+    vr1 = *reinterpret_cast<const uint4*>(V + o1_);                                                 \
+  }
+#define STAGE_LOAD(t_)                                                                              \
+  {                                                                                                 \
+    IDX_LOAD(t_);                                                                                   \
+    STAGE_LOAD_ROWS();                                                                              \
   }
 #define STAGE_WRITE(buf_)                                                                           \
   {                                                                                                 \
-    char* kb_ = smem + (buf_) * 2 * TILE64;                                                         \
-    *reinterpret_cast<uint4*>(kb_ + tile_off(sr, sc)) = kr0;                                        \
-    *reinterpret_cast<uint4*>(kb_ + TILE64 + tile_off(sr, sc)) = vr0;                               \
-    *reinterpret_cast<uint4*>(kb_ + tile_off(sr + 32, sc)) = kr1;                                   \
-    *reinterpret_cast<uint4*>(kb_ + TILE64 + tile_off(sr + 32, sc)) = vr1;                          \
+    char* kb_ = smem + (buf_) * 2 * TILE64 + tile_off(sr, sc);                                      \
+    *reinterpret_cast<uint4*>(kb_) = kr0;                                                           \
+    *reinterpret_cast<uint4*>(kb_ + TILE64) = vr0;                                                  \
+    *reinterpret_cast<uint4*>(kb_ + 4096) = kr1;                                                    \
+    *reinterpret_cast<uint4*>(kb_ + TILE64 + 4096) = vr1;                                           \
   }
 
   f32x16 dqacc[2];
@@ -111,54 +168,74 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   if (ntiles > 0) {
     STAGE_LOAD(0);
     STAGE_WRITE(0);
+    IDX_LOAD(1);                                       // indices of tile 1 (clamped), consumed by the first iteration
   }
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    {
-      const int tn = t + 1 < ntiles ? t + 1 : t;
-      STAGE_LOAD(tn);
-    }
-    const char* kb = smem + buf * 2 * TILE64;
-    const char* vb = kb + TILE64;
-    f32x16 sacc[2], dpacc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sacc[0][i] = 0.f; sacc[1][i] = 0.f; dpacc[0][i] = 0.f; dpacc[1][i] = 0.f; }
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sacc[kbk] = mfma_bf16(lds_row_frag(kb, kbk * 32 + lr, s, lh), qf[s], sacc[kbk]);      // S^T[key, q]
-        dpacc[kbk] = mfma_bf16(lds_row_frag(vb, kbk * 32 + lr, s, lh), dof[s], dpacc[kbk]);   // dP^T[key, q]
-      }
-    const bool edge = (t * BK + BK > n_prefix);
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pv = fast_exp2(sacc[kbk][r] * c - lse2);
-        const int pos = t * BK + kbk * 32 + acc_row(r, lh);
-        if (edge) {
-          const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
-          pv = ok ? pv : 0.f;
-        }
-        float dpv = dpacc[kbk][r];
-        if (DROP) dpv = attn_drop_keep(rk, qr, pos, p.drop_thresh) ? dpv * p.drop_inv : 0.f;   // dA = dD * M / (1 - p)
-        dpacc[kbk][r] = pv * (dpv - del);
-      }
-#pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 dsf = acc_to_frag(dpacc[kbk], s);
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-          dqacc[db] = mfma_bf16(lds_tr_frag(kb, kbk * 32 + 16 * s, db, lane), dsf, dqacc[db]);   // dQ^T[d, q] += K^T[d, key] dS^T[key, q]
-      }
-    STAGE_WRITE(buf ^ 1);
-    __syncthreads();
+
+  // dS of key block kbk_ (P = exp2(S'), dS = P * dP') as bf16 operand fragments
+#define SOFTMAX_BLOCK(kbk_, t_, masked_)                                                            \
+  {                                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                \
+      float pv = fast_exp2(sacc[kbk_][r]);                                                          \
+      const int pos = (t_) * BK + (kbk_) * 32 + acc_row(r, lh);                                     \
+      if (masked_) {                                                                                \
+        const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);                     \
+        pv = ok ? pv : 0.f;                                                                         \
+      }                                                                                             \
+      float dpv = dpacc[kbk_][r];                                                                   \
+      if (DROP) dpv = (attn_drop_keep(rk, qr, pos, p.drop_thresh) ? dpv * p.drop_inv : 0.f) - del;  /* dA = dD * M / (1 - p) */ \
+      dpacc[kbk_][r] = pv * dpv;                                                                    \
+    }                                                                                               \
+    dsf[kbk_][0] = acc_to_frag(dpacc[kbk_], 0);                                                     \
+    dsf[kbk_][1] = acc_to_frag(dpacc[kbk_], 1);                                                     \
   }
+#define SDP_MFMAS(kb_, vb_, kbk_)                                                                   \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
+    sacc[kbk_] = mfma_bf16(ROW_FRAG(kb_, kbk_, s), qf[s], s == 0 ? seed_s : sacc[kbk_]);    /* S'^T[key, q] */  \
+    dpacc[kbk_] = mfma_bf16(ROW_FRAG(vb_, kbk_, s), dof[s], s == 0 ? seed_dp : dpacc[kbk_]); /* dP'^T[key, q] */ \
+  }
+#define DQ_MFMAS(kb_, kbk_)                                                                         \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                     \
+  _Pragma("unroll") for (int db = 0; db < 2; ++db)                                                  \
+    dqacc[db] = mfma_bf16(tr_frag(kb_, (kbk_) * 32 + 16 * s, db), dsf[kbk_][s], dqacc[db]);   /* dQ^T[d, q] += K^T[d, key] dS^T[key, q] */
+
+  auto run_tiles = [&](auto masked_tag, const int t0, const int t1) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    for (int t = t0; t < t1; ++t) {
+      const int buf = t & 1;
+      STAGE_LOAD_ROWS();                                 // tile t+1 (past the end: clamped copies, harmless)
+      IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
+      const int kb = buf * 2 * TILE64, vb = kb + TILE64;
+      f32x16 sacc[2], dpacc[2];
+      bf16x8 dsf[2][2];
+      __builtin_amdgcn_sched_barrier(0);
+      SDP_MFMAS(kb, vb, 0);                              // stage A
+      __builtin_amdgcn_sched_barrier(0);
+      SDP_MFMAS(kb, vb, 1);                              // stage B: 8 MFMA beside the softmax of block 0
+      SOFTMAX_BLOCK(0, t, MASKED);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      DQ_MFMAS(kb, 0);                                   // stage C: 4 MFMA beside the softmax of block 1
+      SOFTMAX_BLOCK(1, t, MASKED);
+      __builtin_amdgcn_sched_barrier(0);
+      DQ_MFMAS(kb, 1);                                   // stage D
+      STAGE_WRITE(buf ^ 1);
+      __syncthreads();
+    }
+  };
+  run_tiles(std::false_type{}, 0, nfast < ntiles ? nfast : ntiles);
+  run_tiles(std::true_type{}, nfast < ntiles ? nfast : ntiles, ntiles);
+#undef SOFTMAX_BLOCK
+#undef SDP_MFMAS
+#undef DQ_MFMAS
+#undef ROW_FRAG
 #undef STAGE_LOAD
+#undef STAGE_LOAD_ROWS
+#undef IDX_LOAD
 #undef STAGE_WRITE
 
   char* ob = smem + wave * (32 * 144);

@@ -113,19 +113,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   // clamped loads, uniform 64-bit base + 32-bit lane offset (a sample's K/V rows span < 4 GB).
   const int sr = tid >> 3, sc = tid & 7;
   uint4 kr0, kr1, vr0, vr1;
-#define STAGE_LOAD(t_)                                                                              \
+  // key-list lookups run one tile ahead of the row loads that depend on them (otherwise every tile waits out a full
+  // index-load latency before its K/V loads can even be issued)
+  uint32_t ri0, ri1;
+#define IDX_LOAD(t_)                                                                                \
   {                                                                                                 \
     int p0_ = (t_) * BK + sr, p1_ = p0_ + 32;                                                       \
     p0_ = p0_ < nk ? p0_ : nk - 1;                                                                  \
     p1_ = p1_ < nk ? p1_ : nk - 1;                                                                  \
-    const uint32_t r0_ = USE_IDX ? (uint32_t)idx[p0_] : (uint32_t)p0_;                              \
-    const uint32_t r1_ = USE_IDX ? (uint32_t)idx[p1_] : (uint32_t)p1_;                              \
-    const uint32_t o0_ = (r0_ * (uint32_t)p.kv_rs + (uint32_t)sc * 8u) * 2u;                        \
-    const uint32_t o1_ = (r1_ * (uint32_t)p.kv_rs + (uint32_t)sc * 8u) * 2u;                        \
+    ri0 = USE_IDX ? (uint32_t)idx[p0_] : (uint32_t)p0_;                                             \
+    ri1 = USE_IDX ? (uint32_t)idx[p1_] : (uint32_t)p1_;                                             \
+  }
+#define STAGE_LOAD_ROWS()                                                                           \
+  {                                                                                                 \
+    const uint32_t o0_ = (ri0 * (uint32_t)p.kv_rs + (uint32_t)sc * 8u) * 2u;                        \
+    const uint32_t o1_ = (ri1 * (uint32_t)p.kv_rs + (uint32_t)sc * 8u) * 2u;                        \
     kr0 = *reinterpret_cast<const uint4*>(K + o0_);                                                 \
     vr0 = *reinterpret_cast<const uint4*>(V + o0_);                                                 \
     kr1 = *reinterpret_cast<const uint4*>(K + o1_);                                                 \
     vr1 = *reinterpret_cast<const uint4*>(V + o1_);                                                 \
+  }
+#define STAGE_LOAD(t_)                                                                              \
+  {                                                                                                 \
+    IDX_LOAD(t_);                                                                                   \
+    STAGE_LOAD_ROWS();                                                                              \
   }
 #define STAGE_WRITE(buf_)                                                                           \
   {                                                                                                 \
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     __syncthreads();
     STAGE_LOAD(1);
     STAGE_WRITE(1);
+    IDX_LOAD(2);                                         // indices of tile 2 (clamped), consumed by the first iteration
     __syncthreads();
     // exp, row sum and operand fragment of one (query block, key block): 16 v_exp, 16 v_add, 8 v_cvt_pk
 #define SOFTMAX_BLOCK(qb_, kbk_, t_)                                                                \
@@ -260,10 +272,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   }
     for (int t = 1; t < nfast; ++t) {
       const int buf = t & 1;
-      {
-        const int tn = t + 1 < nfast ? t + 1 : t;      // last iteration re-loads its own tile (harmless)
-        STAGE_LOAD(tn);
-      }
+      STAGE_LOAD_ROWS();                                 // tile t+1 (after the last fast tile: an unused, harmless load)
+      IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
       const int kb = buf * 2 * TILE_BYTES, vb = kb + TILE_BYTES;
       float lsum[QB];
 #pragma unroll
@@ -318,6 +328,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #undef PV_MFMAS
 #undef ROW_FRAG
 #undef STAGE_LOAD
+#undef STAGE_LOAD_ROWS
+#undef IDX_LOAD
 #undef STAGE_WRITE
 
   // ---- epilogue: normalise, stage O through LDS (per-wave 32 x 64 tile, 144-B rows), store whole rows
