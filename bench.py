@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="also time the step with every batch staged from host memory (pinned arena, one async H2D copy per "
                          "batch overlapped with the previous step): reported as pcie_inclusive, never as value")
+    ap.add_argument("--compact-wire", action="store_true",
+                    help="with --host-inputs: ship the OCR tokens as 64-byte slots and build the 604-d PHOC rows "
+                         "(context_feature_1) on the GPU with t2s_phoc instead of transferring them")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="hidden/embedding dropout probability (reference default 0.1; 0 keeps GPU and CPU-oracle steps identical)")
     args = ap.parse_args()
@@ -224,9 +227,15 @@ def main():
 
     pcie = None
     if args.host_inputs:
-        from vitxt_gqa_amd.staging import ArenaLayout, BatchStager
+        from vitxt_gqa_amd.staging import ArenaLayout, BatchStager, phoc_expander
         host = make_batch(B, F, P, V=V, seed=100 + rank)
-        stager = BatchStager(ArenaLayout.from_batch(host), device=dev, depth=2)
+        if args.compact_wire:
+            from vitxt_gqa_amd.synth import make_token_slots
+            phoc_spec = {"context_feature_1": (tuple(host.pop("context_feature_1").shape), torch.float32)}
+            host["ocr_token_slots"] = make_token_slots(B, F * P, seed=100 + rank)
+            stager = BatchStager(ArenaLayout.from_batch(host), device=dev, depth=2, device_only=phoc_spec, post_upload=[phoc_expander()])
+        else:
+            stager = BatchStager(ArenaLayout.from_batch(host), device=dev, depth=2)
         n = args.warmup + args.steps
         it = stager.prefetch(host for _ in range(n))
         t0 = None
@@ -243,7 +252,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         pcie = {"value": world * B * args.steps / el, "unit": "samples/s", "ms_per_step": 1e3 * el / args.steps,
-                "host_bytes_per_step": stager.layout.nbytes,
+                "host_bytes_per_step": stager.layout.nbytes, "compact_wire": bool(args.compact_wire),
                 "note": "same step, every batch copied from a pageable host batch into a pinned arena by a loader thread and "
                         "uploaded with one async H2D copy overlapped with the previous step (vitxt_gqa_amd/staging.py)"}
 

@@ -188,6 +188,15 @@ int t2s_infonce_stats(const float* q, const float* p, const float* n, float* sta
 int t2s_infonce_bwd(const float* q, const float* p, const float* n, const float* gstats, float* dq, float* dp,
                     float* dn, int64_t rows, int cols, t2s_stream_t stream);
 
+/* ---- PHOC descriptor of OCR tokens (the producer of context_feature_1): replaces the reference's C extension
+ * pythia/utils/phoc/src/cphoc.c:12-117 as called per token by PhocProcessor (pythia/datasets/processors.py:904-928)
+ * through pythia/utils/phoc/build_phoc.py:9-14.  tokens: [n_tokens, width] bytes in HBM, each slot an already
+ * normalised token (lower-cased, stripped, only [a-z0-9] kept - build_phoc.py:10-11 stays on the host) padded with
+ * NUL; out: [n_tokens, out_row_stride] fp32, the first 604 elements of a row are written with exactly 0.0 / 1.0
+ * (14 unigram regions x 36 + 2 bigram regions x 50).  A byte outside [a-z0-9] before the first NUL - where the
+ * reference raises RuntimeError - turns that token's row into NaN; the host wrapper rejects such input beforehand. */
+int t2s_phoc(const uint8_t* tokens, int64_t n_tokens, int width, float* out, int64_t out_row_stride, t2s_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

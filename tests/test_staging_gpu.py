@@ -33,3 +33,26 @@ def test_staged_batch_equals_to_device_and_drives_the_model():
         assert torch.equal(a, b)
         outs.append(a.sum().item())
     assert len(outs) == 4
+
+
+def test_compact_wire_phoc_rows_built_on_device():
+    """OCR tokens travel as 64-byte slots; context_feature_1 is a device-only arena field filled by t2s_phoc on the copy
+    stream.  Must equal the oracle's rows for the same tokens (what the reference's PhocProcessor would have shipped)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import phoc_oracle as po
+    from vitxt_gqa_amd.staging import ArenaLayout, BatchStager, phoc_expander
+    from vitxt_gqa_amd.synth import make_batch, make_token_slots
+    B, F, P = 2, 4, 5
+    batches = []
+    for s in range(3):
+        b = make_batch(B, F, P, V=32, seed=s, text_vocab=100)
+        del b["context_feature_1"]
+        b["ocr_token_slots"] = make_token_slots(B, F * P, seed=s)
+        batches.append(b)
+    st = BatchStager(ArenaLayout.from_batch(batches[0]), device=DEV, depth=2,
+                     device_only={"context_feature_1": ((B, F * P, 604), torch.float32)}, post_upload=[phoc_expander()])
+    for i, d in enumerate(st.prefetch(batches)):
+        exp = po.build_phoc_batch(batches[i]["ocr_token_slots"].numpy().reshape(-1, 64)).reshape(B, F * P, 604)
+        assert torch.equal(d["context_feature_1"].cpu(), torch.from_numpy(exp))
+        assert torch.equal(d["context_feature_0"].cpu(), batches[i]["context_feature_0"])

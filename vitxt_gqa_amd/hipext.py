@@ -38,6 +38,7 @@ _SIGS = {
     "t2s_bce_masked": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),
     "t2s_infonce_stats": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p]),
     "t2s_infonce_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_void_p]),
+    "t2s_phoc": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

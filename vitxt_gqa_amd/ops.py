@@ -275,6 +275,22 @@ def embed_rows(f0, f1, id0, emb0, id1, emb1, out_dtype):
     return out
 
 
+def phoc(tokens, out=None):
+    """tokens: uint8 [..., width] NUL-padded normalised OCR tokens on the GPU -> fp32 [..., 604] PHOC features
+    (include/t2s_hip.h: t2s_phoc).  ``out`` may be a preallocated [..., >=604]-strided fp32 view (e.g. the arena field
+    the model reads as context_feature_1)."""
+    assert tokens.dtype == torch.uint8 and tokens.is_contiguous() and tokens.is_cuda
+    lead, width = tokens.shape[:-1], tokens.shape[-1]
+    n = tokens.numel() // width
+    if out is None:
+        out = torch.empty(*lead, 604, dtype=torch.float32, device=tokens.device)
+    assert out.dtype == torch.float32 and out.shape[-1] == 604 and out.numel() == n * 604 and out.stride(-1) == 1
+    rs = out.stride(-2) if out.dim() > 1 else 604
+    assert out.dim() <= 1 or out.view(-1, 604).stride(0) == rs, "rows of `out` must be evenly strided"
+    X.check(X.lib().t2s_phoc(X.ptr(tokens), n, width, X.ptr(out), rs, X.stream()), "t2s_phoc")
+    return out
+
+
 def bce_masked(scores, targets, row_mask):
     """Returns (row_loss [rows], grad [rows, cols]) -- see include/t2s_hip.h."""
     cols = scores.shape[-1]

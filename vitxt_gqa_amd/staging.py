@@ -15,6 +15,10 @@ Here a batch lives in ONE arena with a fixed layout (every field 256-byte aligne
 * ``depth`` arenas form a ring; an arena is reused only after the consumer stream has passed the point where its batch
   was last used (``release`` records that point).
 
+* fields can be produced ON the device instead of being transferred: ``device_only`` adds fields that exist only in the
+  HBM arena and ``post_upload`` hooks fill them on the copy stream right after the H2D copy - e.g. the 604-d PHOC rows
+  of the OCR tokens from their bytes (``phoc_expander``): 64 bytes instead of 2416 per token cross PCIe.
+
 Non-tensor fields (question ids, encoded strings ...) travel in the ``SampleList`` untouched.  On a CPU-only host
 (``device="cpu"``) the same layout is used without pinning and without streams, which is what the CPU tests exercise.
 """
@@ -68,15 +72,18 @@ class ArenaLayout:
 
 
 class _Slot:
-    def __init__(self, layout, device, pin):
+    def __init__(self, layout, device, pin, dev_layout=None):
         self.layout = layout
         self.host_arena = torch.empty(max(layout.nbytes, ALIGN), dtype=torch.uint8, pin_memory=pin)
         self.host = layout.views(self.host_arena)
-        if device.type == "cpu":
+        extra = dev_layout.nbytes if dev_layout is not None else 0
+        if device.type == "cpu" and not extra:
             self.dev_arena, self.dev = self.host_arena, self.host
         else:
-            self.dev_arena = torch.empty(max(layout.nbytes, ALIGN), dtype=torch.uint8, device=device)
+            self.dev_arena = torch.empty(max(layout.nbytes, ALIGN) + extra, dtype=torch.uint8, device=device)
             self.dev = layout.views(self.dev_arena)
+            if extra:       # device-only fields live behind the transferred prefix
+                self.dev.update(dev_layout.views(self.dev_arena[max(layout.nbytes, ALIGN):]))
         self.extras = {}
         self.ready = None        # event: H2D copy complete (recorded on the copy stream)
         self.released = None     # event: consumer done with the device views (recorded on the consumer stream)
@@ -100,11 +107,15 @@ class StagedBatch(SampleList):
 
 
 class BatchStager:
-    def __init__(self, layout, device="cuda:0", depth=2):
+    def __init__(self, layout, device="cuda:0", depth=2, device_only=None, post_upload=()):
+        """``device_only``: spec {name: (shape, dtype)} of fields that exist only in the device arena; ``post_upload``:
+        callables ``f(dev_views)`` run on the copy stream after the H2D copy (they fill the device-only fields)."""
         self.layout = layout
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
-        self.slots = [_Slot(layout, self.device, pin=self.cuda) for _ in range(depth)]
+        self.dev_layout = ArenaLayout(device_only) if device_only else None
+        self.post_upload = tuple(post_upload)
+        self.slots = [_Slot(layout, self.device, pin=self.cuda, dev_layout=self.dev_layout) for _ in range(depth)]
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self._next = 0
         self._lock = threading.Lock()
@@ -161,9 +172,16 @@ class BatchStager:
         """One async H2D copy of the whole arena on the copy stream; returns the device ``StagedBatch``."""
         if self.cuda:
             with torch.cuda.stream(self.copy_stream):
-                slot.dev_arena.copy_(slot.host_arena, non_blocking=True)
+                slot.dev_arena[:slot.host_arena.numel()].copy_(slot.host_arena, non_blocking=True)
+                for hook in self.post_upload:
+                    hook(slot.dev)
                 slot.ready = torch.cuda.Event()
                 slot.ready.record(self.copy_stream)
+        else:
+            if slot.dev_arena is not slot.host_arena:
+                slot.dev_arena[:slot.host_arena.numel()].copy_(slot.host_arena)
+            for hook in self.post_upload:
+                hook(slot.dev)
         out = StagedBatch(slot.dev)
         for k, v in slot.extras.items():
             out[k] = v
@@ -201,3 +219,15 @@ class BatchStager:
                 cur.wait()
             yield cur
             cur.release()
+
+
+def phoc_expander(slots_field="ocr_token_slots", out_field="context_feature_1"):
+    """``post_upload`` hook: context_feature_1 [B, N, 604] (device-only field) from the uploaded OCR token bytes
+    [B, N, width] with the ``t2s_phoc`` kernel (the reference computes these rows on the host, one C call per token:
+    ``pythia/datasets/processors.py:904-928``)."""
+    from . import ops
+
+    def hook(dev):
+        ops.phoc(dev[slots_field], out=dev[out_field])
+
+    return hook

@@ -42,3 +42,13 @@ def make_noise(B, F, P, seed=0):
     g = torch.Generator().manual_seed(seed + 7919)
     return (torch.empty(B, 2, F).exponential_(generator=g),
             torch.empty(B, 2, F * P).exponential_(generator=g))
+
+
+def make_token_slots(B, N, width=64, seed=0, max_len=14):
+    """Synthetic normalised OCR tokens as NUL-padded byte slots uint8 [B, N, width] (what ``phoc.pack_tokens`` produces
+    from real strings): lengths uniform in 1..max_len, symbols uniform in [a-z0-9]."""
+    g = torch.Generator().manual_seed(seed + 104729)
+    sym = torch.tensor(list(b"abcdefghijklmnopqrstuvwxyz0123456789"), dtype=torch.uint8)
+    ch = sym[torch.randint(0, 36, (B, N, width), generator=g)]
+    ln = torch.randint(1, max_len + 1, (B, N, 1), generator=g)
+    return torch.where(torch.arange(width).view(1, 1, width) < ln, ch, torch.zeros((), dtype=torch.uint8))
