@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 template <bool USE_IDX, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE64];   // [buf][K, V]
+  __shared__ uint32_t ck_s[2][32];                  // dropout: column keys of the tile's 32 key pairs (packed 16-bit halves)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * 128 + wave * 32;
@@ -101,7 +102,16 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
     for (int i = 0; i < 16; ++i) { seed_s[i] = nl; seed_dp[i] = nd; }
   }
   const int qdec = qrow - p.dec_q0;
-  const uint32_t rk = DROP ? p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qr >> 1)] : 0u;
+  const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
+  const uint32_t rk2 = DROP ? attn_drop_rowkey16(salt, qr) * 0x10001u : 0u;      // this lane's row key in both 16-bit halves
+  const uint32_t th2 = p.drop_thresh | (p.drop_thresh << 16);
+  uint32_t ckreg = 0;
+  // column keys of key pair `tid` of tile t_ (threads 0..31), staged beside the K/V tile
+#define CK_LOAD(t_)                                                                                 \
+  if (DROP && tid < 32) {                                                                           \
+    const int kp_ = (t_) * BK + 2 * tid;                                                            \
+    ckreg = attn_drop_colkey16(salt, kp_) | (attn_drop_colkey16(salt, kp_ + 1) << 16);              \
+  }
 
   int ka[4];                 // row fragment: row lr, chunk 2s + lh
 #pragma unroll
@@ -160,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
     *reinterpret_cast<uint4*>(kb_ + TILE64) = vr0;                                                  \
     *reinterpret_cast<uint4*>(kb_ + 4096) = kr1;                                                    \
     *reinterpret_cast<uint4*>(kb_ + TILE64 + 4096) = vr1;                                           \
+    if (DROP && tid < 32) ck_s[buf_][tid] = ckreg;                                                  \
   }
 
   f32x16 dqacc[2];
@@ -167,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
   if (ntiles > 0) {
     STAGE_LOAD(0);
+    CK_LOAD(0);
     STAGE_WRITE(0);
     IDX_LOAD(1);                                       // indices of tile 1 (clamped), consumed by the first iteration
   }
@@ -183,7 +195,11 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
         pv = ok ? pv : 0.f;                                                                         \
       }                                                                                             \
       float dpv = dpacc[kbk_][r];                                                                   \
-      if (DROP) dpv = (attn_drop_keep(rk, qr, pos, p.drop_thresh) ? dpv * p.drop_inv : 0.f) - del;  /* dA = dD * M / (1 - p) */ \
+      if (DROP) {   /* dA = dD * M / (1 - p): registers (r, r+1), r even, are the key pair (kbk*32 + acc_row(r, lh)) / 2 */ \
+        const uint32_t m_ = attn_drop_pair_dropped(rk2, ck_s[buf][(kbk_) * 16 + 4 * (r >> 2) + 2 * lh + ((r & 3) >> 1)], th2); \
+        const bool drop_ = (r & 1) ? (m_ >> 16) != 0u : (m_ & 0xFFFFu) != 0u;                       \
+        dpv = (drop_ ? 0.f : dpv * p.drop_inv) - del;                                               \
+      }                                                                                             \
       dpacc[kbk_][r] = pv * dpv;                                                                    \
     }                                                                                               \
     dsf[kbk_][0] = acc_to_frag(dpacc[kbk_], 0);                                                     \
@@ -205,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
       const int buf = t & 1;
       STAGE_LOAD_ROWS();                                 // tile t+1 (past the end: clamped copies, harmless)
       IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
+      CK_LOAD(t + 1);
       const int kb = buf * 2 * TILE64, vb = kb + TILE64;
       f32x16 sacc[2], dpacc[2];
       bf16x8 dsf[2][2];
@@ -236,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
 #undef STAGE_LOAD
 #undef STAGE_LOAD_ROWS
 #undef IDX_LOAD
+#undef CK_LOAD
 #undef STAGE_WRITE
 
   char* ob = smem + wave * (32 * 144);
@@ -294,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_f32_kernel(AttnParams p) {
   }
   const int kdec = kpos - n_prefix;
   const float c = p.scale * LOG2E;
+  const uint32_t salt = attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h));
   const int nqt = (p.Lq + 31) / 32;
   const int sr = tid >> 3, sc = tid & 7;     // 32 rows x 8 chunks of 8 floats
   f32x16 dkacc[2], dvacc[2];
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_f32_kernel(AttnParams p) {
       if (p.drop_thresh) {
         int qg = qt * 32 + qi;
         qg = qg < p.Lq ? qg : p.Lq - 1;
-        keep = attn_drop_keep(p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qg >> 1)], qg, kpos, p.drop_thresh);
+        keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg), attn_drop_colkey16(salt, kpos), p.drop_thresh);
         dpv = keep ? dpv * p.drop_inv : 0.f;
       }
       dpacc[r] = pv * (dpv - del_s[qi]);       // dS uses the UNdropped probability
@@ -405,7 +424,8 @@ __global__ __launch_bounds__(256, 2) void attn_dq_f32_kernel(AttnParams p) {
   const float del = p.delta[((int64_t)b * p.H + h) * p.Lq + qr];
   const float c = p.scale * LOG2E;
   const int qdec = qrow - p.dec_q0;
-  const uint32_t rk = p.drop_thresh ? p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qr >> 1)] : 0u;
+  const uint32_t salt = attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h));
+  const uint32_t rk = attn_drop_rowkey16(salt, qr);
   const int sr = tid >> 4, sc = tid & 15;
   f32x16 dqacc[2];
 #pragma unroll
@@ -445,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_f32_kernel(AttnParams p) {
         const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
         const float pv = ok ? fast_exp2(sacc[kbk][r] * c - lse2) : 0.f;
         float dpv = dpacc[kbk][r];
-        if (p.drop_thresh) dpv = attn_drop_keep(rk, qr, pos, p.drop_thresh) ? dpv * p.drop_inv : 0.f;
+        if (p.drop_thresh) dpv = attn_drop_keep16(rk, attn_drop_colkey16(salt, pos), p.drop_thresh) ? dpv * p.drop_inv : 0.f;
         dpacc[kbk][r] = pv * (dpv - del);
       }
 #pragma unroll
@@ -493,7 +513,8 @@ extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const v
   p.q_rs = q_row_stride; p.q_bs = q_batch_stride; p.kv_rs = kv_row_stride; p.kv_bs = kv_batch_stride;
   p.o_rs = o_row_stride; p.o_bs = o_batch_stride; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
-  if (int e = attn_setup_dropout(p, drop_p, drop_seed, drop_ws, st, "attn_bwd")) return e;
+  (void)drop_ws;
+  if (int e = attn_setup_dropout(p, drop_p, drop_seed, st, "attn_bwd")) return e;
   const int64_t rows = (int64_t)B * Lq;
   dim3 gd((unsigned)((rows + 3) / 4)), blk(256);
   dim3 gkv((max_keys + 127) / 128, H, B), gq((Lq + 127) / 128, H, B);

@@ -20,47 +20,61 @@ struct AttnParams {
   int64_t q_rs, q_bs, kv_rs, kv_bs, o_rs, o_bs;
   float scale;
   // attention-probability dropout (BertSelfAttention: dropout(softmax(.)) before .V); thresh == 0 disables it
-  const uint32_t* drop_rowkey;   // [B, H, ceil(Lq/2)] per-(sample, head, query pair) hash keys (attn_drop_rowkeys_kernel)
+  uint32_t drop_seed_lo, drop_seed_hi;
   uint32_t drop_thresh;          // drop iff byte < thresh, thresh = round(p * 256)
   float drop_inv;                // 1 / (1 - thresh/256)
 };
 
-// ---- attention-probability dropout.  keep(q, kpos) is a stateless function of (seed, sample, head, q, kpos) so the
-// forward, dQ and dK/dV kernels regenerate the same mask in their different register layouts; kpos is the POSITION in
-// the compacted key list.  One 32-bit word serves a 2x2 block {q, q^1} x {kpos, kpos^1} (a byte per element), which is
-// the largest block both layouts share: with the query on the lane a register pair holds two consecutive keys, with
-// the key on the lane two consecutive queries.  rowkey[b,h,q>>1] is a full-quality hash (precomputed table); the
-// per-block mixer uses only 24-bit multiplies, shifts and xors (v_mul_lo_u32 is quarter rate on CDNA).
+// ---- attention-probability dropout.  keep(q, kpos) is a stateless function of (seed, sample, head, q, kpos) so that
+// the forward, dQ and dK/dV kernels regenerate the same mask in their different register layouts; kpos is the POSITION
+// in the compacted key list.  The function is built to cost ~3 VALU instructions per score in kernels that are VALU
+// bound:   byte(q, kpos) = high byte of ((rowkey16(q) ^ colkey16(kpos)) * 0x9E37 mod 2^16),   keep iff byte >= thresh
+// where rowkey16 / colkey16 are 16 bits of full-quality 32-bit hashes of (seed, sample, head, q) and (seed, sample, head,
+// kpos).  Those hashes are per-lane constants on the stationary axis and are computed once per tile (32 threads, one
+// key pair each, staged in LDS) on the streamed axis, so the per-score work is xor + multiply + compare - and it is
+// done on TWO scores per instruction with packed 16-bit math: a bf16x2 word of P holds two consecutive keys of the
+// lane's query (forward, dQ) or two consecutive queries of the lane's key (dK/dV), exactly the two 16-bit halves.
+// For a fixed row the bytes are independent over keys and vice versa (colkey16 / rowkey16 are independent uniform
+// 16-bit values and x -> x * odd is a bijection); two rows share a mask only if their 16-bit keys collide (2^-16).
 __device__ __forceinline__ uint32_t attn_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ uint32_t attn_drop_block(uint32_t rowkey, uint32_t kp2) {
-  uint32_t x = rowkey + __umul24(kp2, 0x9E3779u);
-  x ^= x >> 15;
-  x = __umul24(x, 0x2C1B3Du) + (x >> 9);
-  x ^= x >> 13;
-  x = __umul24(x, 0x6D2B79u) ^ (x >> 11);
-  return x;
+__device__ __forceinline__ uint32_t attn_drop_salt(uint32_t seed_lo, uint32_t seed_hi, uint32_t bh) {
+  return attn_hash32(seed_lo ^ attn_hash32(seed_hi ^ (bh * 0x9E3779B1u)));
 }
-// generic per-element form (fp32 kernels, mask export): byte (q&1)*2 + (kpos&1) of the block word
-__device__ __forceinline__ bool attn_drop_keep(uint32_t rowkey, int q, int kpos, uint32_t thresh) {
-  const uint32_t x = attn_drop_block(rowkey, (uint32_t)kpos >> 1);
-  return ((x >> (8 * ((q & 1) * 2 + (kpos & 1)))) & 0xFFu) >= thresh;
+__device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q) { return attn_hash32(salt + (uint32_t)q * 0x85EBCA6Bu) >> 16; }
+__device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) {
+  return attn_hash32((salt ^ 0xC2B2AE35u) + (uint32_t)kpos * 0x27D4EB2Fu) >> 16;
 }
-// packed form: returns the AND-mask for a bf16x2 word holding the block's elements whose bytes are `sel`-selected
-// (sel = v_perm selector placing the two bytes in the low byte of each 16-bit half): 0xFFFF per kept half.
-__device__ __forceinline__ uint32_t attn_drop_pair_mask(uint32_t x, uint32_t sel, uint32_t thresh2 /* thresh | thresh << 16 */) {
+constexpr uint32_t ATTN_DROP_MUL = 0x9E37u;
+// generic per-element form (fp32 kernels, mask export)
+__device__ __forceinline__ bool attn_drop_keep16(uint32_t rk16, uint32_t ck16, uint32_t thresh) {
+  return ((((rk16 ^ ck16) * ATTN_DROP_MUL) & 0xFFFFu) >> 8) >= thresh;
+}
+// packed form: a2 ^ b2 holds (rowkey ^ colkey) of two scores in its 16-bit halves; returns 0xFFFF in every half whose
+// score is DROPPED (v_xor, v_pk_mul_lo_u16, v_pk_lshrrev_b16, v_pk_sub_i16, v_pk_ashrrev_i16)
+__device__ __forceinline__ uint32_t attn_drop_pair_dropped(uint32_t a2, uint32_t b2, uint32_t thresh2 /* thresh | thresh << 16 */) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const uint32_t t = __builtin_amdgcn_perm(0u, x, sel);
+  u16x2 t = __builtin_bit_cast(u16x2, a2 ^ b2) * u16x2{(unsigned short)ATTN_DROP_MUL, (unsigned short)ATTN_DROP_MUL};
+  t >>= 8;
   const s16x2 d = __builtin_bit_cast(s16x2, t) - __builtin_bit_cast(s16x2, thresh2);
-  const s16x2 m = d >> 15;                       // 0xFFFF where byte < thresh (dropped)
-  return ~__builtin_bit_cast(uint32_t, m);
+  const s16x2 m = d >> 15;
+  return __builtin_bit_cast(uint32_t, m);
 }
-__device__ __forceinline__ uint32_t attn_drop_sel(int b0, int b1) { return 0x0c000c00u | ((uint32_t)b1 << 16) | (uint32_t)b0; }
+// word of two bf16 probabilities with the dropped halves cleared (v_bfi_b32)
+__device__ __forceinline__ uint32_t attn_drop_apply(uint32_t w, uint32_t dropped) { return w & ~dropped; }
 
-void launch_attn_drop_rowkeys(uint32_t* rowkey, int B, int H, int Lq, uint64_t seed, hipStream_t st);
-int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, hipStream_t st, const char* who);
+// per-score 32-bit masks (all ones = dropped) of the two halves, and "zero the float if dropped" (v_bfe_i32 / v_ashrrev_i32,
+// v_bfi_b32): selects without compares
+__device__ __forceinline__ uint32_t attn_drop_lo32(uint32_t m) { return (uint32_t)((int32_t)(m << 16) >> 16); }
+__device__ __forceinline__ uint32_t attn_drop_hi32(uint32_t m) { return (uint32_t)((int32_t)m >> 16); }
+__device__ __forceinline__ float attn_drop_zero(float x, uint32_t m32) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & ~m32);
+}
+
+int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, hipStream_t st, const char* who);
 
 // ---- LDS tile image shared by every bf16 tile (K, V, Q, dO): rows of 64 bf16 = 128 B = eight
 // 16-byte chunks, chunk c of row r stored at chunk position c ^ f(r).  f is chosen so that BOTH

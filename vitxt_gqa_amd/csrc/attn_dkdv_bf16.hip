@@ -65,10 +65,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   uint4 q0r, q1r, d0r, d1r;
   float lreg, dreg;
   uint32_t rkreg = 0;
-  const int Lq2 = (p.Lq + 1) >> 1;
-  const uint32_t* __restrict__ RK = DROP ? p.drop_rowkey + ((int64_t)b * p.H + h) * Lq2 : nullptr;
-  const uint32_t kp2 = (uint32_t)kpos >> 1;
-  const uint32_t ksel = attn_drop_sel(kpos & 1, 2 + (kpos & 1));      // bytes (q even, q odd) of this lane's key
+  // dropout (attn_common.h): this lane's column key in both 16-bit halves; the row keys of the tile's 32 query pairs
+  // are hashed by threads 0..31 while the tile is staged
+  const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
+  const uint32_t ck2 = DROP ? attn_drop_colkey16(salt, kpos) * 0x10001u : 0u;
   const uint32_t th2 = p.drop_thresh | (p.drop_thresh << 16);
 #define STAGE_LOAD(qt_)                                                                         \
   {                                                                                             \
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
     const float l_ = LSE[r2c_] * LOG2E, dl_ = DELTA[r2c_];                                      \
     lreg = r2_ < p.Lq ? -l_ : -INFINITY; /* -inf => P = exp2(-inf) = 0 for rows past Lq */       \
     dreg = r2_ < p.Lq ? -dl_ : 0.f;                                                             \
-    if (DROP) {                                                                                 \
-      const int q2_ = (qt_) * (QROWS / 2) + (tid & 31);                                         \
-      rkreg = RK[q2_ < Lq2 ? q2_ : Lq2 - 1];                                                    \
+    if (DROP && tid < QROWS / 2) {                                                              \
+      const int qa_ = (qt_) * QROWS + 2 * tid, qb_ = qa_ + 1;                                   \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1) | (attn_drop_rowkey16(salt, qb_ < p.Lq ? qb_ : p.Lq - 1) << 16); \
     }                                                                                           \
   }
 #define STAGE_WRITE(buf_)                                                                       \
@@ -140,42 +140,50 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
         dpacc[sb] = mfma_bf16(lds_row_frag(dob, sb * 32 + lr, s, lh), vf[s], dpacc[sb]);     // dP[q, key] - delta
       }
     }
+    if (!DROP) {
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
+      for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pv = fast_exp2(sacc[sb][r]);
-        if (edge) {
-          const int qdec = qt * QROWS + sb * 32 + acc_row(r, lh) - p.dec_q0;
-          const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
-          pv = ok ? pv : 0.f;
-        }
-        sacc[sb][r] = pv;
-        if (DROP) {      // dA = dD * M / (1 - p);  dS = P * (dA - delta) with the UNdropped P
-          const int qi = sb * 32 + acc_row(r, lh);
-          const uint32_t x = attn_drop_block(rk_s[qi >> 1], kp2);
-          const bool keep = ((x >> (8 * ((qi & 1) * 2 + (kpos & 1)))) & 0xFFu) >= p.drop_thresh;
-          dpacc[sb][r] = pv * ((keep ? dpacc[sb][r] * p.drop_inv : 0.f) + del_s[qi]);
-        } else {
+        for (int r = 0; r < 16; ++r) {
+          float pv = fast_exp2(sacc[sb][r]);
+          if (edge) {
+            const int qdec = qt * QROWS + sb * 32 + acc_row(r, lh) - p.dec_q0;
+            const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
+            pv = ok ? pv : 0.f;
+          }
+          sacc[sb][r] = pv;
           dpacc[sb][r] = pv * dpacc[sb][r];
         }
-      }
+    } else {
+      // dA = dD * M / (1 - p);  dS = P * (dA - delta) with the UNdropped P;  dV uses the dropped P.  Registers (r, r+1),
+      // r even, are the query rows (qi, qi + 1) of this lane's key: one packed mask word per pair, selects by AND.
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int qi = sb * 32 + acc_row(r, lh);
+          float pv0 = fast_exp2(sacc[sb][r]), pv1 = fast_exp2(sacc[sb][r + 1]);
+          if (edge) {
+            const int qdec = qt * QROWS + qi - p.dec_q0;
+            pv0 = (kvalid && (kdec < 0 || qdec >= kdec)) ? pv0 : 0.f;
+            pv1 = (kvalid && (kdec < 0 || qdec + 1 >= kdec)) ? pv1 : 0.f;
+          }
+          const uint32_t m = attn_drop_pair_dropped(rk_s[qi >> 1], ck2, th2);
+          const uint32_t m0 = attn_drop_lo32(m), m1 = attn_drop_hi32(m);
+          const f32x2 nd = *reinterpret_cast<const f32x2*>(del_s + qi);
+          sacc[sb][r] = attn_drop_zero(pv0, m0);
+          sacc[sb][r + 1] = attn_drop_zero(pv1, m1);
+          dpacc[sb][r] = pv0 * (attn_drop_zero(dpacc[sb][r] * p.drop_inv, m0) + nd[0]);
+          dpacc[sb][r + 1] = pv1 * (attn_drop_zero(dpacc[sb][r + 1] * p.drop_inv, m1) + nd[1]);
+        }
+    }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        bf16x8 pf = acc_to_frag(sacc[sb], s);
+        const bf16x8 pf = acc_to_frag(sacc[sb], s);
         const bf16x8 dsf = acc_to_frag(dpacc[sb], s);
-        if (DROP) {      // dV uses the dropped probabilities: word i = query rows (2*q2, 2*q2 + 1) of this lane's key
-          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-          u32x4 w = __builtin_bit_cast(u32x4, pf);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int q2i = sb * 16 + (i & 1) + 4 * (2 * s + (i >> 1)) + 2 * lh;
-            w[i] &= attn_drop_pair_mask(attn_drop_block(rk_s[q2i], kp2), ksel, th2);
-          }
-          pf = __builtin_bit_cast(bf16x8, w);
-        }
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           dvacc[db] = mfma_bf16(lds_tr_frag(dob, sb * 32 + 16 * s, db, lane), pf, dvacc[db]);   // dV^T[d,key] += dO^T[d,q] P[q,key]

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnParams p) {
 #pragma unroll
     for (int t = 0; t < 32; ++t) qf[t] = qp[2 * t];
   }
-  const uint32_t rk = p.drop_thresh ? p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qrc >> 1)] : 0u;
+  const uint32_t salt = attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h));
+  const uint32_t rk = attn_drop_rowkey16(salt, qrc);
   f32x16 oacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const float pv = fast_exp2(sacc[kbk][r] * c - mc);
         lsum += pv;                                        // the normaliser sums the UNdropped probabilities
-        const bool keep = !p.drop_thresh || attn_drop_keep(rk, qrc, t * BK + kbk * 32 + acc_row(r, lh), p.drop_thresh);
+        const bool keep = !p.drop_thresh || attn_drop_keep16(rk, attn_drop_colkey16(salt, t * BK + kbk * 32 + acc_row(r, lh)), p.drop_thresh);
         sacc[kbk][r] = keep ? pv : 0.f;
       }
     l_run = l_run * alpha + lsum;
@@ -183,17 +184,13 @@ __global__ __launch_bounds__(256) void compact_keys_kernel(const uint8_t* __rest
   if (tid == 0) out_cnt[b] = n;
 }
 
-__global__ __launch_bounds__(256) void attn_drop_rowkeys_kernel(uint32_t* __restrict__ rowkey, int64_t n, uint32_t seed_lo, uint32_t seed_hi) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    rowkey[i] = attn_hash32(attn_hash32((uint32_t)i + seed_lo) ^ seed_hi);
-}
-
-__global__ __launch_bounds__(256) void attn_drop_mask_kernel(uint8_t* __restrict__ out, const uint32_t* __restrict__ rowkey, int H, int Lq,
+__global__ __launch_bounds__(256) void attn_drop_mask_kernel(uint8_t* __restrict__ out, uint32_t seed_lo, uint32_t seed_hi, int H, int Lq,
                                                             int Lk, uint32_t thresh) {
   const int b = blockIdx.z, h = blockIdx.y, q = blockIdx.x;
-  const uint32_t rk = rowkey[((int64_t)b * H + h) * ((Lq + 1) >> 1) + (q >> 1)];
+  const uint32_t salt = attn_drop_salt(seed_lo, seed_hi, (uint32_t)(b * H + h));
+  const uint32_t rk = attn_drop_rowkey16(salt, q);
   for (int k = threadIdx.x; k < Lk; k += 256)
-    out[(((int64_t)b * H + h) * Lq + q) * Lk + k] = attn_drop_keep(rk, q, k, thresh) ? 1 : 0;
+    out[(((int64_t)b * H + h) * Lq + q) * Lk + k] = attn_drop_keep16(rk, attn_drop_colkey16(salt, k), thresh) ? 1 : 0;
 }
 
 int check_common(const AttnParams& p, int dtype) {
@@ -210,27 +207,21 @@ int check_common(const AttnParams& p, int dtype) {
 
 }  // namespace
 
-void launch_attn_drop_rowkeys(uint32_t* rowkey, int B, int H, int Lq, uint64_t seed, hipStream_t st) {
-  const int64_t n = (int64_t)B * H * ((Lq + 1) >> 1);
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(attn_drop_rowkeys_kernel, dim3((unsigned)blocks), dim3(256), 0, st, rowkey, n, (uint32_t)seed, (uint32_t)(seed >> 32));
-}
-
-// shared by the forward / backward entry points: validates the dropout arguments and fills the table + params
-int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, hipStream_t st, const char* who) {
-  p.drop_rowkey = nullptr;
+// shared by the forward / backward entry points: validates the dropout arguments and fills the params.  The mask is a
+// stateless function of the seed (attn_common.h); the drop_ws workspace of earlier ABI versions is no longer used.
+int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, hipStream_t st, const char* who) {
+  (void)st;
+  p.drop_seed_lo = p.drop_seed_hi = 0;
   p.drop_thresh = 0;
   p.drop_inv = 1.f;
   if (drop_p <= 0.f) return 0;
   T2S_CHECK_ARG(drop_p < 1.f, "%s: dropout probability %f outside [0, 1)", who, drop_p);
-  T2S_CHECK_ARG(drop_ws != nullptr, "%s: dropout needs the drop_ws workspace (B*H*ceil(Lq/2) uint32)", who);
   int th = (int)(drop_p * 256.f + 0.5f);
   th = th < 1 ? 1 : (th > 255 ? 255 : th);
   p.drop_thresh = (uint32_t)th;
   p.drop_inv = 256.f / (256.f - (float)th);
-  p.drop_rowkey = drop_ws;
-  launch_attn_drop_rowkeys(drop_ws, p.B, p.H, p.Lq, drop_seed, st);
+  p.drop_seed_lo = (uint32_t)drop_seed;
+  p.drop_seed_hi = (uint32_t)(drop_seed >> 32);
   return 0;
 }
 
@@ -239,9 +230,11 @@ extern "C" int t2s_attn_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk,
   T2S_CHECK_ARG(out && B > 0 && H > 0 && Lq > 0 && Lk > 0 && B <= 65535 && H <= 65535, "attn_dropout_mask: bad arguments");
   AttnParams p = {};
   p.B = B; p.H = H; p.Lq = Lq;
-  if (int e = attn_setup_dropout(p, drop_p, drop_seed, drop_ws, (hipStream_t)stream, "attn_dropout_mask")) return e;
+  (void)drop_ws;
+  if (int e = attn_setup_dropout(p, drop_p, drop_seed, (hipStream_t)stream, "attn_dropout_mask")) return e;
   T2S_CHECK_ARG(p.drop_thresh != 0, "attn_dropout_mask: drop_p must be > 0");
-  hipLaunchKernelGGL(attn_drop_mask_kernel, dim3(Lq, H, B), dim3(256), 0, (hipStream_t)stream, out, p.drop_rowkey, H, Lq, Lk, p.drop_thresh);
+  hipLaunchKernelGGL(attn_drop_mask_kernel, dim3(Lq, H, B), dim3(256), 0, (hipStream_t)stream, out, p.drop_seed_lo, p.drop_seed_hi, H, Lq, Lk,
+                     p.drop_thresh);
   T2S_CHECK_LAUNCH("attn_dropout_mask");
   return 0;
 }
@@ -269,7 +262,8 @@ extern "C" int t2s_attn_fwd(const void* q, const void* k, const void* v, void* o
   if (int e = check_common(p, dtype)) return e;
   dim3 grid((Lq + BQ - 1) / BQ, H, B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (int e = attn_setup_dropout(p, drop_p, drop_seed, drop_ws, st, "attn_fwd")) return e;
+  (void)drop_ws;
+  if (int e = attn_setup_dropout(p, drop_p, drop_seed, st, "attn_fwd")) return e;
   if (dtype == T2S_BF16) {
     launch_attn_fwd_bf16(p, st);
   } else {

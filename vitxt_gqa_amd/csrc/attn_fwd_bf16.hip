@@ -36,6 +36,7 @@ template <bool USE_IDX, int QB, bool DROP, bool REPAIR>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   // [buf][K,V] double buffer, then one pre-scaled (32*QB)-row Q tile per wave
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES + 4 * QB * 32 * 128];
+  __shared__ uint32_t ck_s[2][32];                  // dropout: column keys of the tile's 32 key pairs (packed 16-bit halves)
   constexpr int BQ = 128 * QB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -89,15 +90,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 
   // Q -> LDS, pre-scaled: lane (q = lr, half lh) owns c * Q[q][16s + 8lh .. +7] and is the only reader of what it wrote
   int qdec[QB];             // decoder step of the lane's query row (negative: not a decoder row)
-  uint32_t rk[QB], dsel[QB];   // dropout: row hash key and byte selector of the lane's query row
+  uint32_t rk2[QB];            // dropout: the lane's row key in both 16-bit halves
+  const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int qrow = q0 + qb * 32 + lr;
     const int qr = qrow < p.Lq ? qrow : p.Lq - 1;
-    if (DROP) {
-      rk[qb] = p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qr >> 1)];
-      dsel[qb] = (qr & 1) ? attn_drop_sel(2, 3) : attn_drop_sel(0, 1);
-    }
+    if (DROP) rk2[qb] = attn_drop_rowkey16(salt, qr) * 0x10001u;
     const bf16_t* qp = Q + (int64_t)qr * p.q_rs + 8 * lh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -113,6 +112,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   // clamped loads, uniform 64-bit base + 32-bit lane offset (a sample's K/V rows span < 4 GB).
   const int sr = tid >> 3, sc = tid & 7;
   uint4 kr0, kr1, vr0, vr1;
+  uint32_t ckreg = 0;
+  // dropout: column keys of key pair `tid` of tile t_ (threads 0..31), staged beside the K/V tile
+#define CK_LOAD(t_)                                                                                 \
+  if (DROP && tid < 32) {                                                                           \
+    const int kp_ = (t_) * BK + 2 * tid;                                                            \
+    ckreg = attn_drop_colkey16(salt, kp_) | (attn_drop_colkey16(salt, kp_ + 1) << 16);              \
+  }
   // key-list lookups run one tile ahead of the row loads that depend on them (otherwise every tile waits out a full
   // index-load latency before its K/V loads can even be issued)
   uint32_t ri0, ri1;
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     *reinterpret_cast<uint4*>(kb_ + TILE_BYTES) = vr0;                                              \
     *reinterpret_cast<uint4*>(kb_ + 4096) = kr1;                                                    \
     *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + 4096) = vr1;                                       \
+    if (DROP && tid < 32) ck_s[buf_][tid] = ckreg;                                                  \
   }
 
   f32x16 oacc[QB][2], sacc[QB][2], negm[QB];
@@ -160,17 +167,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   }
 
   // P of (query block, key block, k-step pair s) -> bf16 operand fragment, dropout mask applied
-#define PACK_P(qb_, kbk_, s_, t_)                                                                   \
+#define PACK_P(qb_, kbk_, s_, cbuf_)                                                                \
   {                                                                                                 \
     bf16x8 f_ = acc_to_frag(sacc[qb_][kbk_], s_);                                                   \
-    if (DROP) { /* word i of the fragment = keys (2*kp2, 2*kp2 + 1) of this lane's query row */     \
+    if (DROP) { /* word i of the fragment = key pair kbk*16 + 8s + 4(i>>1) + (i&1) + 2lh of the tile, this lane's query row */ \
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                   \
       u32x4 w_ = __builtin_bit_cast(u32x4, f_);                                                     \
       const uint32_t th2_ = p.drop_thresh | (p.drop_thresh << 16);                                  \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-        const uint32_t kp2_ = (uint32_t)((t_) * 32 + (kbk_) * 16 + 8 * (s_) + 4 * (i >> 1) + (i & 1) + 2 * lh); \
-        w_[i] &= attn_drop_pair_mask(attn_drop_block(rk[qb_], kp2_), dsel[qb_], th2_);              \
-      }                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+        w_[i] = attn_drop_apply(w_[i], attn_drop_pair_dropped(rk2[qb_], ck_s[cbuf_][(kbk_) * 16 + 8 * (s_) + 4 * (i >> 1) + (i & 1) + 2 * lh], th2_)); \
       f_ = __builtin_bit_cast(bf16x8, w_);                                                          \
     }                                                                                               \
     pf[qb_][kbk_][s_] = f_;                                                                         \
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     const int t = g == 0 ? 0 : nedge0 + g - 1;
     __syncthreads();
     STAGE_LOAD(t);
+    CK_LOAD(t);
     STAGE_WRITE(0);
     __syncthreads();
 #pragma unroll
@@ -245,8 +251,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        PACK_P(qb, kbk, 0, t);
-        PACK_P(qb, kbk, 1, t);
+        PACK_P(qb, kbk, 0, 0);
+        PACK_P(qb, kbk, 1, 0);
       }
       PV_MFMAS(TILE_BYTES, kbk);
     }
@@ -256,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   if (nfast > 1) {
     __syncthreads();
     STAGE_LOAD(1);
+    CK_LOAD(1);
     STAGE_WRITE(1);
     IDX_LOAD(2);                                         // indices of tile 2 (clamped), consumed by the first iteration
     __syncthreads();
@@ -267,13 +274,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     const float a0_ = (sa_[0] + sa_[4]) + (sa_[8] + sa_[12]), a1_ = (sa_[1] + sa_[5]) + (sa_[9] + sa_[13]);   \
     const float a2_ = (sa_[2] + sa_[6]) + (sa_[10] + sa_[14]), a3_ = (sa_[3] + sa_[7]) + (sa_[11] + sa_[15]); \
     lsum[qb_] += (a0_ + a1_) + (a2_ + a3_);                                                         \
-    PACK_P(qb_, kbk_, 0, t_);                                                                       \
-    PACK_P(qb_, kbk_, 1, t_);                                                                       \
+    PACK_P(qb_, kbk_, 0, buf);                                                                      \
+    PACK_P(qb_, kbk_, 1, buf);                                                                      \
   }
     for (int t = 1; t < nfast; ++t) {
       const int buf = t & 1;
       STAGE_LOAD_ROWS();                                 // tile t+1 (after the last fast tile: an unused, harmless load)
       IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
+      CK_LOAD(t + 1);
       const int kb = buf * 2 * TILE_BYTES, vb = kb + TILE_BYTES;
       float lsum[QB];
 #pragma unroll
@@ -330,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #undef STAGE_LOAD
 #undef STAGE_LOAD_ROWS
 #undef IDX_LOAD
+#undef CK_LOAD
 #undef STAGE_WRITE
 
   // ---- epilogue: normalise, stage O through LDS (per-wave 32 x 64 tile, 144-B rows), store whole rows
