@@ -12,24 +12,25 @@ cd /tmp && export TMPDIR=/tmp
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
 # 2. kernel trace + stats of the same command (fewer steps, no CPU baseline: identical GPU work per step)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dropout0 > $OUT/stats.log 2>&1
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 python3 $REPO/tools/kstats.py $OUT/stats 3 14
 # 3. HBM traffic counters, one pass each
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropout0 > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropout0 > $OUT/write.log 2>&1
 python3 $REPO/tools/pmc_summary.py $OUT > $OUT/pmc_fetch_write.txt
 python3 - "$OUT" <<'EOF'
 import json, re, sys
 out = sys.argv[1]
 txt = open(out + "/pmc_fetch_write.txt").read()
 vals = {}
-sec = re.search(r"attn_fwd_bf16_kernel<true, 2, false, false>[^\n]*\n((?:\s+\w+\s+n=[^\n]*\n)+)", txt)
+sec = (re.search(r"attn_fwd_bf16_kernel<true, 2, true, false>[^\n]*\n((?:\s+\w+\s+n=[^\n]*\n)+)", txt)       # dropout on (bench default)
+       or re.search(r"attn_fwd_bf16_kernel<true, 2, false, false>[^\n]*\n((?:\s+\w+\s+n=[^\n]*\n)+)", txt))
 for m in re.finditer(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+ mean=([0-9.e+]+)", sec.group(1) if sec else ""):
     vals[m.group(1)] = float(m.group(2))
 if len(vals) == 2:
     b = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
-    json.dump({"_comment": "HBM bytes per launch of attn_fwd_bf16_kernel<true,2,false,false> in a B=64 train step: rocprofv3 PMC, separate "
+    json.dump({"_comment": "HBM bytes per launch of the 64-row-per-wave attn_fwd_bf16_kernel (steady-state launch) in a B=64 train step: rocprofv3 PMC, separate "
                "FETCH_SIZE / WRITE_SIZE passes over `bench.py --steps 1 --warmup 1`; FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md "
                "(gfx950 reports half of a wide coalesced stream), WRITE_SIZE (KB) as is: 2*%.4g*1024 + %.4g*1024" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]),
                "attn_fwd_bf16_kernel": b}, open(out + "/traffic.json", "w"), indent=1)

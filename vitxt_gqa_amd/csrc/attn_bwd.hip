@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   const int qdec = qrow - p.dec_q0;
   const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
   const uint32_t rk2 = DROP ? attn_drop_rowkey16(salt, qr) * 0x10001u : 0u;      // this lane's row key in both 16-bit halves
-  const uint32_t th2 = p.drop_thresh | (p.drop_thresh << 16);
+  const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
+  const uint32_t inv_bits = __builtin_bit_cast(uint32_t, p.drop_inv);
   uint32_t ckreg = 0;
   // column keys of key pair `tid` of tile t_ (threads 0..31), staged beside the K/V tile
 #define CK_LOAD(t_)                                                                                 \
@@ -195,10 +196,11 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
         pv = ok ? pv : 0.f;                                                                         \
       }                                                                                             \
       float dpv = dpacc[kbk_][r];                                                                   \
-      if (DROP) {   /* dA = dD * M / (1 - p): registers (r, r+1), r even, are the key pair (kbk*32 + acc_row(r, lh)) / 2 */ \
-        const uint32_t m_ = attn_drop_pair_dropped(rk2, ck_s[buf][(kbk_) * 16 + 4 * (r >> 2) + 2 * lh + ((r & 3) >> 1)], th2); \
-        const bool drop_ = (r & 1) ? (m_ >> 16) != 0u : (m_ & 0xFFFFu) != 0u;                       \
-        dpv = (drop_ ? 0.f : dpv * p.drop_inv) - del;                                               \
+      if (DROP) {   /* dA = dD * M / (1 - p): registers (r, r+1), r even, are the key pair (kbk*32 + acc_row(r, lh)) / 2;       \
+                       M / (1 - p) as a float that is 1/(1-p) or 0: the constant AND the sign of the pair's diff half */   \
+        const uint32_t d_ = attn_drop_pair_diff(rk2, ck_s[buf][(kbk_) * 16 + 4 * (r >> 2) + 2 * lh + ((r & 3) >> 1)], th2); \
+        const float g_ = __builtin_bit_cast(float, inv_bits & ~((r & 1) ? attn_drop_hi32(d_) : attn_drop_lo32(d_)));       \
+        dpv = __builtin_fmaf(dpv, g_, -del);                                                        \
       }                                                                                             \
       dpacc[kbk_][r] = pv * dpv;                                                                    \
     }                                                                                               \

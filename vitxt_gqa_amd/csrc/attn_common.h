@@ -52,15 +52,23 @@ constexpr uint32_t ATTN_DROP_MUL = 0x9E37u;
 __device__ __forceinline__ bool attn_drop_keep16(uint32_t rk16, uint32_t ck16, uint32_t thresh) {
   return ((((rk16 ^ ck16) * ATTN_DROP_MUL) & 0xFFFFu) >> 8) >= thresh;
 }
-// packed form: a2 ^ b2 holds (rowkey ^ colkey) of two scores in its 16-bit halves; returns 0xFFFF in every half whose
-// score is DROPPED (v_xor, v_pk_mul_lo_u16, v_pk_lshrrev_b16, v_pk_sub_i16, v_pk_ashrrev_i16)
-__device__ __forceinline__ uint32_t attn_drop_pair_dropped(uint32_t a2, uint32_t b2, uint32_t thresh2 /* thresh | thresh << 16 */) {
+// packed form: a2 ^ b2 holds (rowkey ^ colkey) of two scores in its 16-bit halves; returns per half a signed 16-bit
+// value that is NEGATIVE iff the score is dropped.  byte >= thresh  <=>  t16 >= thresh*256 (unsigned)  <=>
+// (t16 ^ 0x8000) >= (thresh*256 ^ 0x8000) (signed); the flip of the top bit is the +0x8000 of a multiply-add and the
+// comparison is a saturating subtract: v_xor, v_pk_mad_u16, v_pk_sub_i16 clamp - three instructions for two scores.
+__device__ __forceinline__ uint32_t attn_drop_pair_diff(uint32_t a2, uint32_t b2, uint32_t thresh2s /* attn_drop_thresh2s(thresh) */) {
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
-  u16x2 t = __builtin_bit_cast(u16x2, a2 ^ b2) * u16x2{(unsigned short)ATTN_DROP_MUL, (unsigned short)ATTN_DROP_MUL};
-  t >>= 8;
-  const s16x2 d = __builtin_bit_cast(s16x2, t) - __builtin_bit_cast(s16x2, thresh2);
-  const s16x2 m = d >> 15;
+  const u16x2 t = __builtin_bit_cast(u16x2, a2 ^ b2) * u16x2{(unsigned short)ATTN_DROP_MUL, (unsigned short)ATTN_DROP_MUL} +
+                  u16x2{(unsigned short)0x8000u, (unsigned short)0x8000u};
+  const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, thresh2s));
+  return __builtin_bit_cast(uint32_t, d);
+}
+__device__ __forceinline__ uint32_t attn_drop_thresh2s(uint32_t thresh) { return (((thresh << 8) ^ 0x8000u) & 0xFFFFu) * 0x10001u; }
+// 0xFFFF in every DROPPED half (v_pk_ashrrev_i16), for clearing halves of packed bf16 words
+__device__ __forceinline__ uint32_t attn_drop_pair_dropped(uint32_t a2, uint32_t b2, uint32_t thresh2s) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 m = __builtin_bit_cast(s16x2, attn_drop_pair_diff(a2, b2, thresh2s)) >> 15;
   return __builtin_bit_cast(uint32_t, m);
 }
 // word of two bf16 probabilities with the dropped halves cleared (v_bfi_b32)
@@ -68,8 +76,9 @@ __device__ __forceinline__ uint32_t attn_drop_apply(uint32_t w, uint32_t dropped
 
 // per-score 32-bit masks (all ones = dropped) of the two halves, and "zero the float if dropped" (v_bfe_i32 / v_ashrrev_i32,
 // v_bfi_b32): selects without compares
-__device__ __forceinline__ uint32_t attn_drop_lo32(uint32_t m) { return (uint32_t)((int32_t)(m << 16) >> 16); }
-__device__ __forceinline__ uint32_t attn_drop_hi32(uint32_t m) { return (uint32_t)((int32_t)m >> 16); }
+// (work on the diff word or on the 0xFFFF mask word alike: only the sign bit of each half is used)
+__device__ __forceinline__ uint32_t attn_drop_lo32(uint32_t m) { return (uint32_t)((int32_t)(m << 16) >> 31); }
+__device__ __forceinline__ uint32_t attn_drop_hi32(uint32_t m) { return (uint32_t)((int32_t)m >> 31); }
 __device__ __forceinline__ float attn_drop_zero(float x, uint32_t m32) {
   return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & ~m32);
 }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   // are hashed by threads 0..31 while the tile is staged
   const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
   const uint32_t ck2 = DROP ? attn_drop_colkey16(salt, kpos) * 0x10001u : 0u;
-  const uint32_t th2 = p.drop_thresh | (p.drop_thresh << 16);
+  const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
 #define STAGE_LOAD(qt_)                                                                         \
   {                                                                                             \
     const int r0_ = (qt_) * QROWS + sr, r1_ = r0_ + 32;                                         \
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
         dpacc[sb] = mfma_bf16(lds_row_frag(dob, sb * 32 + lr, s, lh), vf[s], dpacc[sb]);     // dP[q, key] - delta
       }
     }
+    uint32_t pfw[2][8], dsw[2][8];       // dropout variant: packed bf16 operand words of P (dropped) and dS
     if (!DROP) {
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
@@ -156,8 +157,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
         }
     } else {
       // dA = dD * M / (1 - p);  dS = P * (dA - delta) with the UNdropped P;  dV uses the dropped P.  Registers (r, r+1),
-      // r even, are the query rows (qi, qi + 1) of this lane's key: one packed mask word per pair, selects by AND.
+      // r even, are the query rows (qi, qi + 1) of this lane's key = one bf16x2 operand word: one packed mask word per
+      // pair clears the dropped halves of the packed P, and M/(1-p) enters dS as a float that is 1/(1-p) or 0
+      // (bit-and of the constant with the sign-extended mask half): exp, fma, mul per score plus the shared mask work.
       typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      const uint32_t inv_bits = __builtin_bit_cast(uint32_t, p.drop_inv);
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
@@ -170,20 +175,24 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
             pv1 = (kvalid && (kdec < 0 || qdec + 1 >= kdec)) ? pv1 : 0.f;
           }
           const uint32_t m = attn_drop_pair_dropped(rk_s[qi >> 1], ck2, th2);
-          const uint32_t m0 = attn_drop_lo32(m), m1 = attn_drop_hi32(m);
+          const float g0 = __builtin_bit_cast(float, inv_bits & ~attn_drop_lo32(m));
+          const float g1 = __builtin_bit_cast(float, inv_bits & ~attn_drop_hi32(m));
           const f32x2 nd = *reinterpret_cast<const f32x2*>(del_s + qi);
-          sacc[sb][r] = attn_drop_zero(pv0, m0);
-          sacc[sb][r + 1] = attn_drop_zero(pv1, m1);
-          dpacc[sb][r] = pv0 * (attn_drop_zero(dpacc[sb][r] * p.drop_inv, m0) + nd[0]);
-          dpacc[sb][r + 1] = pv1 * (attn_drop_zero(dpacc[sb][r + 1] * p.drop_inv, m1) + nd[1]);
+          const bf16x2_t pw = {(__bf16)pv0, (__bf16)pv1};
+          const bf16x2_t dw = {(__bf16)(pv0 * __builtin_fmaf(dpacc[sb][r], g0, nd[0])), (__bf16)(pv1 * __builtin_fmaf(dpacc[sb][r + 1], g1, nd[1]))};
+          pfw[sb][r >> 1] = attn_drop_apply(__builtin_bit_cast(uint32_t, pw), m);
+          dsw[sb][r >> 1] = __builtin_bit_cast(uint32_t, dw);
         }
     }
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = acc_to_frag(sacc[sb], s);
-        const bf16x8 dsf = acc_to_frag(dpacc[sb], s);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const bf16x8 pf = DROP ? __builtin_bit_cast(bf16x8, u32x4{pfw[sb][4 * s], pfw[sb][4 * s + 1], pfw[sb][4 * s + 2], pfw[sb][4 * s + 3]})
+                               : acc_to_frag(sacc[sb], s);
+        const bf16x8 dsf = DROP ? __builtin_bit_cast(bf16x8, u32x4{dsw[sb][4 * s], dsw[sb][4 * s + 1], dsw[sb][4 * s + 2], dsw[sb][4 * s + 3]})
+                                : acc_to_frag(dpacc[sb], s);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           dvacc[db] = mfma_bf16(lds_tr_frag(dob, sb * 32 + 16 * s, db, lane), pf, dvacc[db]);   // dV^T[d,key] += dO^T[d,q] P[q,key]

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     if (DROP) { /* word i of the fragment = key pair kbk*16 + 8s + 4(i>>1) + (i&1) + 2lh of the tile, this lane's query row */ \
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                   \
       u32x4 w_ = __builtin_bit_cast(u32x4, f_);                                                     \
-      const uint32_t th2_ = p.drop_thresh | (p.drop_thresh << 16);                                  \
+      const uint32_t th2_ = attn_drop_thresh2s(p.drop_thresh);                                  \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
         w_[i] = attn_drop_apply(w_[i], attn_drop_pair_dropped(rk2[qb_], ck_s[cbuf_][(kbk_) * 16 + 8 * (s_) + 4 * (i >> 1) + (i & 1) + 2 * lh], th2_)); \
       f_ = __builtin_bit_cast(bf16x8, w_);                                                          \

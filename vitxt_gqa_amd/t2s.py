@@ -343,6 +343,16 @@ class T2S(BaseModel):
                 p.requires_grad_(False)
         return self
 
+    def set_dropout(self, p):
+        """Set every dropout probability of the model (hidden, attention-probability, embedding, obj/ocr input) to ``p``:
+        the reference's config default is 0.1 everywhere; parity runs use 0."""
+        for m in self.modules():
+            if hasattr(m, "hidden_dropout"):
+                m.hidden_dropout = float(p)
+                m.attn_dropout = float(p)
+        self.obj_drop_p = self.ocr_drop_p = float(p)
+        return self
+
     def set_compute_dtype(self, dtype):
         assert dtype in (torch.float32, torch.bfloat16)
         self.compute_dtype = dtype
