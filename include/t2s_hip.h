@@ -59,10 +59,10 @@ int t2s_compact_keys(const uint8_t* valid, int32_t* out_idx, int32_t* out_cnt, i
  * query row r iff r - dec_q0 >= j.
  * lse: [B, H, Lq] fp32, natural-log-sum-exp of the scaled scores (saved for backward).
  * drop_p > 0: attention-probability dropout (BertSelfAttention: dropout(softmax(.)) before .V):
- * out = (softmax(.) * keep / (1 - p')) V, keep(b, h, q, list position) a stateless hash of drop_seed,
- * p' = round(256 p)/256 (one byte per score).  drop_ws: uint32 workspace of B*H*ceil(Lq/2) words
- * (row hash keys; written here).  The backward call regenerates the mask from the same seed;
- * t2s_attn_dropout_mask exports it. */
+ * out = (softmax(.) * keep / (1 - p')) V, keep(b, h, q, list position) a stateless function of drop_seed
+ * (vitxt_gqa_amd/csrc/attn_common.h), p' = round(256 p)/256 (one byte per score).  drop_ws: kept for ABI
+ * stability, unused (the mask needs no table) and may be NULL.  The backward call
+ * regenerates the mask from the same seed; t2s_attn_dropout_mask exports it. */
 int t2s_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                  const int32_t* kv_idx, const int32_t* kv_cnt,
                  int B, int H, int Lq, int idx_cap, int n_dec, int dec_q0,

@@ -50,7 +50,7 @@ def _attn_views(qkv):
 
 
 def _drop_ws(B, L, drop_p, device):
-    return torch.empty(B * HEADS * ((L + 1) // 2), dtype=torch.int32, device=device) if drop_p > 0 else None
+    return None      # the dropout mask is a stateless function of the seed: no workspace (include/t2s_hip.h)
 
 
 def attn_dropout_mask(B, Lq, Lk, drop_p, drop_seed, device):
