@@ -8,6 +8,8 @@
 //   S = Q K^T, dP = dO V^T            (A = row reads of the LDS tiles, B = register fragments)
 //   P = exp2(c S - LSE log2e), dS = P (dP - delta)
 //   dV^T += dO^T P, dK^T += Q^T dS    (A = ds_read_b64_tr_b16 reads of the same tiles, B = P / dS accumulators)
+#include <type_traits>
+
 #include "attn_common.h"
 
 namespace {
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) kf[s][j] = (bf16_t)((float)kf[s][j] * c);
   const int nqt = (p.Lq + QROWS - 1) / QROWS;
-  const bool edge = (kp0 + 128 > n_prefix);
+  const bool edge_wg = (kp0 + 128 > n_prefix);      // this workgroup holds decoder keys or the end of the list
 
   // staging: thread -> rows sr / sr+32, 16-B chunk sc of the Q and dO tiles; plain named registers and
   // unconditional clamped loads (keeps the staging out of scratch memory)
@@ -111,96 +113,19 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   STAGE_LOAD(0);
   STAGE_WRITE(0);
   __syncthreads();
-  for (int qt = 0; qt < nqt; ++qt) {
-    const int buf = qt & 1;
-    {
-      const int qn = qt + 1 < nqt ? qt + 1 : qt;          // last iteration re-loads its own tile (harmless)
-      STAGE_LOAD(qn);
-    }
-    const char* qb = smem + buf * STAGE;
-    const char* dob = qb + TILE;
-    const float* lse_s = reinterpret_cast<const float*>(qb + 2 * TILE);
-    const float* del_s = lse_s + QROWS;
-    const uint32_t* rk_s = reinterpret_cast<const uint32_t*>(del_s + QROWS);
-
-    f32x16 sacc[2], dpacc[2];
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      // initial accumulators = row constants (rows of this lane's registers: acc_row(r, lh) = 8g + 4lh + j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + sb * 32 + 8 * g + 4 * lh);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + sb * 32 + 8 * g + 4 * lh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sacc[sb][4 * g + j] = l4[j]; dpacc[sb][4 * g + j] = DROP ? 0.f : d4[j]; }
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sacc[sb] = mfma_bf16(lds_row_frag(qb, sb * 32 + lr, s, lh), kf[s], sacc[sb]);        // c*S[q, key] - LSE*log2e
-        dpacc[sb] = mfma_bf16(lds_row_frag(dob, sb * 32 + lr, s, lh), vf[s], dpacc[sb]);     // dP[q, key] - delta
-      }
-    }
-    uint32_t pfw[2][8], dsw[2][8];       // dropout variant: packed bf16 operand words of P (dropped) and dS
-    if (!DROP) {
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float pv = fast_exp2(sacc[sb][r]);
-          if (edge) {
-            const int qdec = qt * QROWS + sb * 32 + acc_row(r, lh) - p.dec_q0;
-            const bool ok = kvalid && (kdec < 0 || qdec >= kdec);
-            pv = ok ? pv : 0.f;
-          }
-          sacc[sb][r] = pv;
-          dpacc[sb][r] = pv * dpacc[sb][r];
-        }
-    } else {
-      // dA = dD * M / (1 - p);  dS = P * (dA - delta) with the UNdropped P;  dV uses the dropped P.  Registers (r, r+1),
-      // r even, are the query rows (qi, qi + 1) of this lane's key = one bf16x2 operand word: one packed mask word per
-      // pair clears the dropped halves of the packed P, and M/(1-p) enters dS as a float that is 1/(1-p) or 0
-      // (bit-and of the constant with the sign-extended mask half): exp, fma, mul per score plus the shared mask work.
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-      const uint32_t inv_bits = __builtin_bit_cast(uint32_t, p.drop_inv);
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int qi = sb * 32 + acc_row(r, lh);
-          float pv0 = fast_exp2(sacc[sb][r]), pv1 = fast_exp2(sacc[sb][r + 1]);
-          if (edge) {
-            const int qdec = qt * QROWS + qi - p.dec_q0;
-            pv0 = (kvalid && (kdec < 0 || qdec >= kdec)) ? pv0 : 0.f;
-            pv1 = (kvalid && (kdec < 0 || qdec + 1 >= kdec)) ? pv1 : 0.f;
-          }
-          const uint32_t m = attn_drop_pair_dropped(rk_s[qi >> 1], ck2, th2);
-          const float g0 = __builtin_bit_cast(float, inv_bits & ~attn_drop_lo32(m));
-          const float g1 = __builtin_bit_cast(float, inv_bits & ~attn_drop_hi32(m));
-          const f32x2 nd = *reinterpret_cast<const f32x2*>(del_s + qi);
-          const bf16x2_t pw = {(__bf16)pv0, (__bf16)pv1};
-          const bf16x2_t dw = {(__bf16)(pv0 * __builtin_fmaf(dpacc[sb][r], g0, nd[0])), (__bf16)(pv1 * __builtin_fmaf(dpacc[sb][r + 1], g1, nd[1]))};
-          pfw[sb][r >> 1] = attn_drop_apply(__builtin_bit_cast(uint32_t, pw), m);
-          dsw[sb][r >> 1] = __builtin_bit_cast(uint32_t, dw);
-        }
-    }
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const bf16x8 pf = DROP ? __builtin_bit_cast(bf16x8, u32x4{pfw[sb][4 * s], pfw[sb][4 * s + 1], pfw[sb][4 * s + 2], pfw[sb][4 * s + 3]})
-                               : acc_to_frag(sacc[sb], s);
-        const bf16x8 dsf = DROP ? __builtin_bit_cast(bf16x8, u32x4{dsw[sb][4 * s], dsw[sb][4 * s + 1], dsw[sb][4 * s + 2], dsw[sb][4 * s + 3]})
-                                : acc_to_frag(dpacc[sb], s);
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          dvacc[db] = mfma_bf16(lds_tr_frag(dob, sb * 32 + 16 * s, db, lane), pf, dvacc[db]);   // dV^T[d,key] += dO^T[d,q] P[q,key]
-          dkacc[db] = mfma_bf16(lds_tr_frag(qb, sb * 32 + 16 * s, db, lane), dsf, dkacc[db]);   // dK^T[d,key] += Q^T[d,q] dS[q,key]
-        }
-      }
-    STAGE_WRITE(buf ^ 1);
-    __syncthreads();
+  // With dropout the sweep is compiled in two forms selected by ONE workgroup-uniform branch: the decoder / validity rule
+  // if-converts into ~170 VALU instructions per iteration, paid by every workgroup although only the last key block of
+  // a sample needs it (535 -> 375 VALU per 32 MFMAs).  Without dropout the same split measured 5 % SLOWER (the
+  // compiler's schedule of the single loop with the run-time flag is better), so that form is kept as it was.
+  if (!DROP) {
+    const bool edge = edge_wg;
+#include "attn_dkdv_bf16_sweep.inc"
+  } else if (!edge_wg) {
+    constexpr bool edge = false;
+#include "attn_dkdv_bf16_sweep.inc"
+  } else {
+    constexpr bool edge = true;
+#include "attn_dkdv_bf16_sweep.inc"
   }
 #undef STAGE_LOAD
 #undef STAGE_WRITE
