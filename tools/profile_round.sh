@@ -11,6 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 # 1. the bench line (defaults: B=64 train step, with the bounded CPU baseline)
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
+# 1b. the other BASELINE configurations: forward-only (configs[1]) and the 300 x 200 long-sequence stress (configs[4])
+python3 $REPO/bench.py --forward-only --no-cpu-baseline > $OUT/forward_only.json 2>> $OUT/bench.err
+python3 $REPO/bench.py --batch 2 --frames 300 --ocr 200 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stress_b2_300x200.json 2>> $OUT/bench.err
+python3 $REPO/bench.py --no-cpu-baseline --no-dropout0 --host-inputs --compact-wire > $OUT/host_inputs_compact.json 2>> $OUT/bench.err
 # 2. kernel trace + stats of the same command (fewer steps, no CPU baseline: identical GPU work per step)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dropout0 > $OUT/stats.log 2>&1
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
