@@ -40,6 +40,66 @@ def _wgrad(dy2, x2, B):
     return part.sum(0, dtype=F32).to(dy2.dtype)
 
 
+def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute):
+    """One BERT layer on rows: x2 [B*L, 768] fp32 residual stream, xl its operand-dtype copy.  W = (w_qkv, b_qkv, w_ao, b_ao,
+    g1, be1, w_i, b_i, w_o, b_o, g2, be2).  Returns (y2 fp32, y2_lo or None, tensors to keep for backward)."""
+    w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2 = W
+    lo = w_qkv.dtype != F32
+    qkv = _mm_bias(xl, w_qkv, b_qkv).view(B, L, 3 * HID)
+    att, lse = ops.attn_fwd(qkv, keys, drop_p=attn_drop_p, drop_seed=seeds[2])
+    a = _mm_bias(att.view(B * L, HID), w_ao, b_ao)
+    y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[0])
+    del a
+    y1_op = y1_lo if lo else y1
+    u = _mm_bias(y1_op, w_i, b_i)
+    gact = ops.gelu_fwd(u)
+    o = _mm_bias(gact, w_o, b_o)
+    y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, y1, g2, be2, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[1])
+    if recompute:      # store less: GELU output and the LN1 operand copy are rebuilt in backward
+        gact = y1_op = None
+    return y2, (y2_lo if lo else None), (xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op)
+
+
+def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p):
+    """dy: [B*L, 768] gradient of the layer output (fp32 or the operand dtype).  Returns (dx [B*L, 768] in the operand
+    dtype, the 12 parameter gradients in the order of W)."""
+    xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op = saved
+    B, L, _ = qkv.shape
+    dt = w_qkv.dtype
+    lo = dt != F32
+    # ---- output LayerNorm + FFN
+    dz2, dz2x, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[1])
+    if gact is None:
+        gact = ops.gelu_fwd(u)
+    dw_o = _wgrad(dz2x, gact, B)
+    db_o = dz2x.sum(0)
+    dgact = dz2x @ w_o
+    del gact, dz2x
+    du, db_i = ops.gelu_bwd(dgact, u)
+    del dgact
+    if y1_op is None:                                                    # recompute the LN1 output
+        y1, y1_lo, _, _ = ops.add_layernorm_fwd(z1, None, g1, be1, save=False, stream_dtype=F32, want_lo=lo, want_y=not lo)
+        y1_op = y1_lo if lo else y1
+        del y1, y1_lo
+    dw_i = _wgrad(du, y1_op, B)
+    dy1 = torch.addmm(dz2, du, w_i)                                      # + residual branch of LN2
+    del du, y1_op, dz2
+    # ---- attention output LayerNorm + projection
+    dz1, dz1x, dg1, dbe1 = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[0])
+    del dy1
+    dw_ao = _wgrad(dz1x, att.view(B * L, HID), B)
+    db_ao = dz1x.sum(0)
+    datt = (dz1x @ w_ao).view(B, L, HID)
+    del dz1x
+    # ---- attention
+    dqkv = ops.attn_bwd(qkv, att, datt, lse, keys, drop_p=attn_drop_p, drop_seed=seeds[2]).view(B * L, 3 * HID)
+    del datt
+    dw_qkv = _wgrad(dqkv, xl, B)
+    db_qkv = dqkv.sum(0)
+    dx = torch.addmm(dz1, dqkv, w_qkv)                                   # + residual branch of LN1
+    return dx, (dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1, dw_i, db_i.to(dt), dw_o, db_o, dg2, dbe2)
+
+
 class BertLayerFn(torch.autograd.Function):
     """(y, y_lo) = BertLayer(x; keys).  x / y: fp32 residual stream; x_lo / y_lo: operand-dtype copies
     (y_lo is y itself in fp32 mode).  Weights arrive in the operand dtype; LayerNorm affine stays fp32."""
@@ -49,71 +109,70 @@ class BertLayerFn(torch.autograd.Function):
                 attn_drop_p=0.0):
         B, L, _ = x.shape
         dt = w_qkv.dtype
-        lo = dt != F32
         x2 = x.contiguous().view(B * L, HID)
         xl = (x_lo if x_lo is not None else x.to(dt)).contiguous().view(B * L, HID)
-        qkv = _mm_bias(xl, w_qkv, b_qkv).view(B, L, 3 * HID)
-        att, lse = ops.attn_fwd(qkv, keys, drop_p=attn_drop_p, drop_seed=seeds[2])
-        a = _mm_bias(att.view(B * L, HID), w_ao, b_ao)
-        y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[0])
-        del a
-        y1_op = y1_lo if lo else y1
-        u = _mm_bias(y1_op, w_i, b_i)
-        gact = ops.gelu_fwd(u)
-        o = _mm_bias(gact, w_o, b_o)
-        y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, y1, g2, be2, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[1])
+        y2, y2_lo, saved = _layer_forward(x2, xl, keys, B, L, (w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2),
+                                          drop_p, seeds, attn_drop_p, RECOMPUTE_ACTIVATIONS)
         ctx.keys = keys
         ctx.drop = (drop_p, seeds, attn_drop_p)
-        ctx.recompute = RECOMPUTE_ACTIVATIONS
-        if ctx.recompute:      # store less: GELU output and the LN1 operand copy are rebuilt in backward
-            gact = y1_op = None
-        ctx.save_for_backward(xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op)
+        ctx.save_for_backward(*saved)
         y2 = y2.view(B, L, HID)
-        y2_lo = y2_lo.view(B, L, HID) if lo else y2.detach()
+        y2_lo = y2_lo.view(B, L, HID) if y2_lo is not None else y2.detach()
         ctx.mark_non_differentiable(y2_lo)
         return y2, y2_lo
 
     @staticmethod
     def backward(ctx, dy, _dy_lo):
-        xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op = ctx.saved_tensors
-        keys = ctx.keys
-        B, L, _ = qkv.shape
-        dt = w_qkv.dtype
-        lo = dt != F32
-        dy = dy.contiguous().view(B * L, HID)
-        # ---- output LayerNorm + FFN
+        B, L, _ = dy.shape
         drop_p, seeds, attn_drop_p = ctx.drop
-        dz2, dz2x, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[1])
-        if gact is None:
-            gact = ops.gelu_fwd(u)
-        dw_o = _wgrad(dz2x, gact, B)
-        db_o = dz2x.sum(0)
-        dgact = dz2x @ w_o
-        del gact, dz2x
-        du, db_i = ops.gelu_bwd(dgact, u)
-        del dgact
-        if y1_op is None:                                                    # recompute the LN1 output
-            y1, y1_lo, _, _ = ops.add_layernorm_fwd(z1, None, g1, be1, save=False, stream_dtype=F32, want_lo=lo, want_y=not lo)
-            y1_op = y1_lo if lo else y1
-            del y1, y1_lo
-        dw_i = _wgrad(du, y1_op, B)
-        dy1 = torch.addmm(dz2, du, w_i)                                      # + residual branch of LN2
-        del du, y1_op, dz2
-        # ---- attention output LayerNorm + projection
-        dz1, dz1x, dg1, dbe1 = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[0])
-        del dy1
-        dw_ao = _wgrad(dz1x, att.view(B * L, HID), B)
-        db_ao = dz1x.sum(0)
-        datt = (dz1x @ w_ao).view(B, L, HID)
-        del dz1x
-        # ---- attention
-        dqkv = ops.attn_bwd(qkv, att, datt, lse, keys, drop_p=attn_drop_p, drop_seed=seeds[2]).view(B * L, 3 * HID)
-        del datt
-        dw_qkv = _wgrad(dqkv, xl, B)
-        db_qkv = dqkv.sum(0)
-        dx = torch.addmm(dz1, dqkv, w_qkv)                                   # + residual branch of LN1
-        return (dx.view(B, L, HID), None, None, dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1,
-                dw_i, db_i.to(dt), dw_o, db_o, dg2, dbe2, None, None, None)
+        dx, g = _layer_backward(ctx.saved_tensors, ctx.keys, dy.contiguous().view(B * L, HID), drop_p, seeds, attn_drop_p)
+        return (dx.view(B, L, HID), None, None) + g + (None, None, None)
+
+
+class BertEncoderFn(torch.autograd.Function):
+    """y = BertEncoder(x; keys) for a stack of layers as ONE autograd node.  Between layers the backward hands the
+    operand-dtype dx of layer l+1 straight to the LayerNorm-backward kernel of layer l; as separate nodes autograd casts
+    every layer's bf16 dx up to the fp32 dtype of that layer's input (a 2 GB cast kernel per layer at B=64) only for the
+    next kernel to read it back.  Same values either way."""
+
+    @staticmethod
+    def forward(ctx, x, keys, n_layers, drop_p, seeds, attn_drop_p, *flat_w):
+        B, L, _ = x.shape
+        dt = flat_w[0].dtype
+        x2 = x.contiguous().view(B * L, HID)
+        xl = x2.to(dt) if dt != F32 else x2
+        keep, counts = [], []
+        for l in range(n_layers):
+            x2, x_lo, saved = _layer_forward(x2, xl, keys, B, L, flat_w[12 * l:12 * l + 12], drop_p, seeds[l], attn_drop_p,
+                                             RECOMPUTE_ACTIVATIONS)
+            xl = x_lo if x_lo is not None else x2
+            counts.append([t is not None for t in saved])
+            keep.extend(t for t in saved if t is not None)
+        ctx.keys, ctx.drop, ctx.counts = keys, (drop_p, seeds, attn_drop_p), counts
+        ctx.save_for_backward(*keep)
+        return x2.view(B, L, HID)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, _ = dy.shape
+        drop_p, seeds, attn_drop_p = ctx.drop
+        flat = list(ctx.saved_tensors)
+        per_layer, pos = [], 0
+        for mask in ctx.counts:
+            cur = []
+            for present in mask:
+                cur.append(flat[pos] if present else None)
+                pos += present
+            per_layer.append(cur)
+        d = dy.contiguous().view(B * L, HID)
+        grads = [None] * len(per_layer)
+        for l in reversed(range(len(per_layer))):
+            d, grads[l] = _layer_backward(per_layer[l], ctx.keys, d, drop_p, seeds[l], attn_drop_p)
+            per_layer[l] = None
+        out = (d.view(B, L, HID).float(), None, None, None, None, None)
+        for g in grads:
+            out += g
+        return out
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -235,11 +294,14 @@ def bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout=0.0, attn_dropout=0.0):
 
 
 def bert_encoder(x, keys, layers, dtype, hidden_dropout=0.0, attn_dropout=0.0):
-    """x: fp32 [B, L, 768] -> fp32."""
-    x_lo = None
+    """x: fp32 [B, L, 768] -> fp32.  The whole stack is one autograd node (BertEncoderFn)."""
+    layers = list(layers)
+    flat = []
     for lp in layers:
-        x, x_lo = bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout, attn_dropout)
-    return x
+        flat.extend(_layer_weights(lp, dtype))
+    drop = hidden_dropout > 0 or attn_dropout > 0
+    seeds = tuple((_fresh_seed(), _fresh_seed(), _fresh_seed()) if drop else (0, 0, 0) for _ in layers)
+    return BertEncoderFn.apply(x, keys, len(layers), float(hidden_dropout), seeds, float(attn_dropout), *flat)
 
 
 # ------------------------------------------------------------------------------------------------
