@@ -1,0 +1,37 @@
+"""Reference-format checkpoint files (vitxt_gqa_amd/checkpoint.py; reference: pythia/utils/checkpoint.py:88-111,226-240):
+round trip through the file, DataParallel ``module.`` prefix, bare state_dict, key set equal to the reference schema."""
+import json
+import os
+
+import torch
+
+from vitxt_gqa_amd.checkpoint import load_checkpoint, normalize_state_dict, save_checkpoint
+from vitxt_gqa_amd.testing import make_model
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_round_trip_prefix_and_bare(tmp_path):
+    m1 = make_model(3, 4, 40, text_vocab=60, seed=1, dtype=torch.float32)
+    opt = torch.optim.Adam([p for p in m1.parameters() if p.requires_grad], lr=1e-3)
+    path = str(tmp_path / "model.ckpt")
+    save_checkpoint(path, m1, opt, best_iteration=7, best_metric_value=0.5)
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) == {"model", "optimizer", "best_iteration", "best_metric_value", "config"} and raw["best_iteration"] == 7
+    schema = json.load(open(os.path.join(HERE, "golden", "state_dict_schema.json")))
+    names = schema["keys"] if isinstance(schema, dict) and "keys" in schema else schema
+    assert set(raw["model"]) == set(names if not isinstance(names, dict) else names.keys())      # the reference's parameter names
+    m2 = make_model(3, 4, 40, text_vocab=60, seed=2, dtype=torch.float32)
+    assert not torch.equal(m2.classifier.module.weight, m1.classifier.module.weight)
+    load_checkpoint(path, m2)
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # a DataParallel checkpoint ("module." prefix) and a bare state_dict load the same way
+    wrapped = {"model": {"module." + k: v for k, v in m1.state_dict().items()}}
+    m3 = make_model(3, 4, 40, text_vocab=60, seed=3, dtype=torch.float32)
+    load_checkpoint(wrapped, m3)
+    m4 = make_model(3, 4, 40, text_vocab=60, seed=4, dtype=torch.float32)
+    load_checkpoint(dict(m1.state_dict()), m4)
+    for k, a in m1.state_dict().items():
+        assert torch.equal(a, m3.state_dict()[k]) and torch.equal(a, m4.state_dict()[k])
+    assert normalize_state_dict({"module.module.x": 1, "a.fa_history.b": 2}) == {"module.x": 1, "a.fa_context.b": 2}
