@@ -256,7 +256,7 @@ int main(int argc, char** argv) {
   p.lse = lse; p.delta = delta; p.kv_idx = nullptr; p.kv_cnt = nullptr;
   p.B = B; p.H = H; p.Lq = L; p.idx_cap = L; p.n_dec = ND; p.dec_q0 = L - ND;
   p.q_rs = 3 * 768; p.q_bs = (int64_t)L * 3 * 768; p.kv_rs = 3 * 768; p.kv_bs = p.q_bs; p.o_rs = 768; p.o_bs = (int64_t)L * 768;
-  p.scale = 0.125f; p.drop_thresh = 0; p.drop_inv = 1.f; p.drop_rowkey = nullptr;
+  p.scale = 0.125f; p.drop_thresh = 0; p.drop_inv = 1.f;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   launch_attn_dkdv_bf16(p, L, 0); CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));

@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   p.q = qkv; p.k = (char*)qkv + 768 * 2; p.v = (char*)qkv + 2 * 768 * 2;
   p.B = B; p.H = H; p.Lq = L; p.idx_cap = L; p.n_dec = ND; p.dec_q0 = L - ND;
   p.q_rs = 3 * 768; p.q_bs = (int64_t)L * 3 * 768; p.kv_rs = 3 * 768; p.kv_bs = p.q_bs; p.o_rs = 768; p.o_bs = (int64_t)L * 768;
-  p.scale = 0.125f; p.drop_thresh = 0; p.drop_inv = 1.f; p.drop_rowkey = nullptr;
+  p.scale = 0.125f; p.drop_thresh = 0; p.drop_inv = 1.f;
   if (useidx) {   // keep ~70 % of the prefix keys, ragged per sample
     std::vector<int32_t> hi((size_t)B * L), hc(B);
     for (int b = 0; b < B; ++b) {

@@ -21,7 +21,7 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "t2s_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -66,8 +66,9 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE64];   // [buf][K, V]
   __shared__ uint32_t ck_s[2][32];                  // dropout: column keys of the tile's 32 key pairs (packed 16-bit halves)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int qblk, h, b;
+  if (!attn_xcd_tile((p.Lq + 127) / 128, p.H, p.B, qblk, h, b)) return;         // workgroup-uniform
+  const int q0 = qblk * 128 + wave * 32;
   const int qrow = q0 + lr;
   const bool qvalid = qrow < p.Lq;
   const int qr = qvalid ? qrow : p.Lq - 1;
@@ -523,12 +524,13 @@ extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const v
   if (dtype == T2S_BF16) {
     hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, gd, blk, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, H, Lq, o_row_stride, o_batch_stride);
     launch_attn_dkdv_bf16(p, max_keys, st);
+    const dim3 gqx(attn_xcd_grid((Lq + 127) / 128, H, B));       // XCD-aware 1-D grid (attn_common.h)
     if (p.drop_thresh) {
-      if (kv_idx) hipLaunchKernelGGL((attn_dq_bf16_kernel<true, true>), gq, blk, 0, st, p);
-      else hipLaunchKernelGGL((attn_dq_bf16_kernel<false, true>), gq, blk, 0, st, p);
+      if (kv_idx) hipLaunchKernelGGL((attn_dq_bf16_kernel<true, true>), gqx, blk, 0, st, p);
+      else hipLaunchKernelGGL((attn_dq_bf16_kernel<false, true>), gqx, blk, 0, st, p);
     } else {
-      if (kv_idx) hipLaunchKernelGGL((attn_dq_bf16_kernel<true, false>), gq, blk, 0, st, p);
-      else hipLaunchKernelGGL((attn_dq_bf16_kernel<false, false>), gq, blk, 0, st, p);
+      if (kv_idx) hipLaunchKernelGGL((attn_dq_bf16_kernel<true, false>), gqx, blk, 0, st, p);
+      else hipLaunchKernelGGL((attn_dq_bf16_kernel<false, false>), gqx, blk, 0, st, p);
     }
   } else {
     hipLaunchKernelGGL(attn_delta_kernel<float>, gd, blk, 0, st, (const float*)out, (const float*)dout, delta, B, H, Lq, o_row_stride, o_batch_stride);

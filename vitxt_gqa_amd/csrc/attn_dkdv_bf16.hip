@@ -22,10 +22,11 @@ template <bool USE_IDX, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int kblk, h, b;
+  if (!attn_xcd_tile(p.kblocks, p.H, p.B, kblk, h, b)) return;                    // workgroup-uniform (attn_common.h)
   const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
   const int nk = n_prefix + p.n_dec;
-  const int kp0 = blockIdx.x * 128;
+  const int kp0 = kblk * 128;
   if (kp0 >= nk) return;                                   // uniform per workgroup
   const int kpos = kp0 + wave * 32 + lr;                   // this lane's key position (column)
   const bool kvalid = kpos < nk;
@@ -151,8 +152,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
 
 }  // namespace
 
-void launch_attn_dkdv_bf16(const AttnParams& p, int max_keys, hipStream_t st) {
-  dim3 grid((max_keys + 127) / 128, p.H, p.B), block(256);
+void launch_attn_dkdv_bf16(const AttnParams& p_in, int max_keys, hipStream_t st) {
+  AttnParams p = p_in;
+  p.kblocks = (max_keys + 127) / 128;
+  dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256);      // XCD-aware 1-D grid (attn_common.h)
   if (p.drop_thresh) {
     if (p.kv_idx) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, true>), grid, block, 0, st, p);

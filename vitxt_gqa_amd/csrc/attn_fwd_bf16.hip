@@ -39,12 +39,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   __shared__ uint32_t ck_s[2][32];                  // dropout: column keys of the tile's 32 key pairs (packed 16-bit halves)
   constexpr int BQ = 128 * QB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * BQ + wave * (32 * QB);
+  int qblk, h, b;
+  if (!attn_xcd_tile((p.Lq + BQ - 1) / BQ, p.H, p.B, qblk, h, b)) return;       // workgroup-uniform
+  const int q0 = qblk * BQ + wave * (32 * QB);
   if (REPAIR) {   // only workgroups holding a poisoned row (LSE = NaN) do anything
     int bad = 0;
     for (int r = tid; r < BQ; r += 256) {
-      const int row = blockIdx.x * BQ + r;
+      const int row = qblk * BQ + r;
       if (row < p.Lq) { const float l = p.lse[((int64_t)b * p.H + h) * p.Lq + row]; bad |= !(l == l); }
     }
     if (!__syncthreads_or(bad)) return;
@@ -383,11 +384,11 @@ void launch_fwd(const AttnParams& p, hipStream_t st) {
   const bool wide = p.Lq > 256;       // 64 rows per wave once there is more than one workgroup of queries
   dim3 block(256);
   if (wide) {
-    dim3 grid((p.Lq + 255) / 256, p.H, p.B);
+    dim3 grid(attn_xcd_grid((p.Lq + 255) / 256, p.H, p.B));
     if (p.kv_idx) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, 2, DROP, REPAIR>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, 2, DROP, REPAIR>), grid, block, 0, st, p);
   } else {
-    dim3 grid((p.Lq + 127) / 128, p.H, p.B);
+    dim3 grid(attn_xcd_grid((p.Lq + 127) / 128, p.H, p.B));
     if (p.kv_idx) hipLaunchKernelGGL((attn_fwd_bf16_kernel<true, 1, DROP, REPAIR>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((attn_fwd_bf16_kernel<false, 1, DROP, REPAIR>), grid, block, 0, st, p);
   }
