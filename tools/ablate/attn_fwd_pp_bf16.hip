@@ -44,8 +44,9 @@ constexpr int TILE_BYTES = BK * 128;       // one 64-row bf16 tile
 constexpr int NBUF = 3;
 constexpr float BIG = 1.0995116e12f;       // 2^40: P stays far inside the bf16 / fp32 range
 
-template <bool USE_IDX, bool DROP>
+template <bool USE_IDX>
 __global__ __launch_bounds__(512, 2) void attn_fwd_pp_bf16_kernel(AttnParams p) {
+  constexpr bool DROP = false;         // the experiment has no dropout path
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][K,V] ring, then one pre-scaled 64-row Q tile per wave
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   const int role = PP_ROLE(wave);
@@ -94,15 +95,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_bf16_kernel(AttnParams p) 
   // live in LDS (each lane re-reads exactly the 16-byte chunks it wrote), not in 32 registers: the M phase already
   // holds O (64), S (64), the seeds (32) and the staged tile.
   int qdec[2];
-  uint32_t rk[2], dsel[2];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int qrow = q0 + qb * 32 + lr;
     const int qr = qrow < p.Lq ? qrow : p.Lq - 1;
-    if (DROP) {
-      rk[qb] = p.drop_rowkey[((int64_t)b * p.H + h) * ((p.Lq + 1) >> 1) + (qr >> 1)];
-      dsel[qb] = (qr & 1) ? attn_drop_sel(2, 3) : attn_drop_sel(0, 1);
-    }
     const bf16_t* qp = Q + (int64_t)qr * p.q_rs + 8 * lh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -162,16 +158,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_bf16_kernel(AttnParams p) 
   _Pragma("unroll") for (int kbk = 0; kbk < 2; ++kbk)                                               \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
     bf16x8 f = acc_to_frag(sacc[qb][kbk], s);                                                       \
-    if (DROP) { /* word i of the fragment = keys (2*kp2, 2*kp2 + 1) of this lane's query row */     \
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                   \
-      u32x4 w = __builtin_bit_cast(u32x4, f);                                                       \
-      const uint32_t th2 = p.drop_thresh | (p.drop_thresh << 16);                                   \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-        const uint32_t kp2 = (uint32_t)((t_) * 32 + kbk * 16 + 8 * s + 4 * (i >> 1) + (i & 1) + 2 * lh); \
-        w[i] &= attn_drop_pair_mask(attn_drop_block(rk[qb], kp2), dsel[qb], th2);                   \
-      }                                                                                             \
-      f = __builtin_bit_cast(bf16x8, w);                                                            \
-    }                                                                                               \
     pf[qb][kbk][s] = f;                                                                             \
   }
   // O^T[d, q] += V^T[d, key] P^T[key, q] with V in tile image vb_
@@ -299,17 +285,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_bf16_kernel(AttnParams p) 
             a2 += sa[8 * s + 2] + sa[8 * s + 6];
             a3 += sa[8 * s + 3] + sa[8 * s + 7];
             bf16x8 f = acc_to_frag(sa, s);
-            if (DROP) {     // word i of the fragment = keys (2*kp2, 2*kp2 + 1) of this lane's query row
-              typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-              u32x4 w = __builtin_bit_cast(u32x4, f);
-              const uint32_t th2 = p.drop_thresh | (p.drop_thresh << 16);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const uint32_t kp2 = (uint32_t)(t * 32 + kbk * 16 + 8 * s + 4 * (i >> 1) + (i & 1) + 2 * lh);
-                w[i] &= attn_drop_pair_mask(attn_drop_block(rk[qb], kp2), dsel[qb], th2);
-              }
-              f = __builtin_bit_cast(bf16x8, w);
-            }
             {   // pin the fragment here: a value with one use in the M phase would otherwise be SUNK across the barrier
               typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
               u32x4 w = __builtin_bit_cast(u32x4, f);
@@ -394,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_bf16_kernel(AttnParams p) 
   for (int qb = 0; qb < 2; ++qb) {
     const int qrow = q0_e + qb * 32 + lr_e;
     const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-    const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (DROP ? p.drop_inv : 1.f);   // normaliser uses the UNdropped sum
+    const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * 1.f;   // normaliser uses the UNdropped sum
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -426,17 +401,17 @@ constexpr int PP_LDS_BYTES_PLACEHOLDER = 0;
 
 constexpr int PP_LDS_BYTES = NBUF * 2 * TILE_BYTES + 8 * 64 * 128;      // 48 KB ring + 64 KB Q = 112 KB of the CU's 160 KB
 
-template <bool USE_IDX, bool DROP>
+template <bool USE_IDX>
 static hipError_t launch_pp(const AttnParams& p, hipStream_t st) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pp_bf16_kernel<USE_IDX, DROP>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pp_bf16_kernel<USE_IDX>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   if (attr != hipSuccess) return attr;
   dim3 grid((p.Lq + 511) / 512, p.H, p.B), block(512);
-  hipLaunchKernelGGL((attn_fwd_pp_bf16_kernel<USE_IDX, DROP>), grid, block, PP_LDS_BYTES, st, p);
+  hipLaunchKernelGGL((attn_fwd_pp_bf16_kernel<USE_IDX>), grid, block, PP_LDS_BYTES, st, p);
   return hipGetLastError();
 }
 
 hipError_t launch_attn_fwd_pp_bf16(const AttnParams& p, hipStream_t st) {
-  if (p.drop_thresh) return p.kv_idx ? launch_pp<true, true>(p, st) : launch_pp<false, true>(p, st);
-  return p.kv_idx ? launch_pp<true, false>(p, st) : launch_pp<false, false>(p, st);
+  if (p.drop_thresh) return hipErrorInvalidValue;      // no dropout path in this experiment
+  return p.kv_idx ? launch_pp<true>(p, st) : launch_pp<false>(p, st);
 }
