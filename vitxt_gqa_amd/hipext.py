@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt2s_hip.so")
+LIB_PATH = os.environ.get("T2S_HIP_LIB") or os.path.join(_HERE, "libt2s_hip.so")      # override: kernel build experiments only
 ABI_VERSION = 1
 
 T2S_F32, T2S_BF16 = 0, 1
