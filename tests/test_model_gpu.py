@@ -194,3 +194,31 @@ def test_no_cpu_fallback():
     from vitxt_gqa_amd import ops
     with pytest.raises(RuntimeError):
         ops.gelu_fwd(torch.zeros(8, 8))
+
+
+def test_batched_mmt_passes_equal_separate_passes():
+    """MMT.forward_passes (the three passes stacked along the batch, one encoder call) against the reference's three
+    separate calls: same scores and same parameter gradients (fp32 mode, dropout 0)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vitxt_gqa_amd.synth import make_batch, make_noise
+    from vitxt_gqa_amd.testing import make_model, to_device
+    F, P, V, B = 7, 9, 40, 3
+    model = make_model(F, P, V, text_vocab=50, dtype=torch.float32, attn_gain=4.0).to(DEV).train()
+    s = to_device(make_batch(B, F, P, V=V, seed=3, text_vocab=50), DEV)
+    s.grounding_noise = tuple(t.to(DEV) for t in make_noise(B, F, P, seed=3))
+    res = {}
+    for mode in (False, True):
+        model.batch_mmt_passes = mode
+        model.zero_grad(set_to_none=True)
+        out = model(s)
+        sum(l.mean() for l in out["losses"].values()).backward()
+        res[mode] = ({k: out[k].detach().clone() for k in ("ref_scores", "pos_scores", "neg_scores")},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    model.batch_mmt_passes = False
+    for k in res[False][0]:
+        assert (res[False][0][k] - res[True][0][k]).abs().max().item() < 1e-4, k
+    assert res[False][1].keys() == res[True][1].keys()
+    for n, g in res[False][1].items():
+        d = (g - res[True][1][n]).abs().max().item()
+        assert d <= 1e-4 * max(1.0, g.abs().max().item()), (n, d)

@@ -90,25 +90,25 @@ int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, hipStrea
 // its own 4 MB L2.  The workgroups that share operands - the query blocks of one (sample, head), which all stream the same
 // K/V rows (forward, dQ), or its key blocks, which all stream the same Q/dO rows (dK/dV) - must therefore NOT have
 // consecutive ids, or every XCD's L2 fetches every (sample, head)'s K/V from HBM (measured: 8.5 GB per launch against
-// 4 GB algorithmic).  A 1-D grid of 8 * ceil(total / 8) workgroups is launched; workgroup id L runs on XCD L % 8 as its
-// (L / 8)-th workgroup and takes tile v = (L % 8) * ceil(total / 8) + L / 8: each XCD walks its own contiguous range of
-// (sample, head) pairs, block after block.  Returns false for the padding ids.
+// 4 GB algorithmic).  A 1-D grid is launched; workgroup id L runs on XCD L % 8 as its (L / 8)-th workgroup: that XCD walks
+// the (sample, head) pairs  xcd, xcd + 8, xcd + 16, ...  block after block.  Taking every 8th pair (rather than a
+// contiguous eighth of them) keeps the XCDs balanced when the samples of a batch differ in work - e.g. the stacked
+// ref / pos / neg passes, whose visible key counts differ by two orders of magnitude.  Returns false for padding ids.
 constexpr int T2S_XCDS = 8;
 __device__ __forceinline__ bool attn_xcd_tile(int nblk, int H, int B, int& blk, int& h, int& b) {
-  const int total = nblk * H * B;
-  const int per = (total + T2S_XCDS - 1) / T2S_XCDS;
   const int L = (int)blockIdx.x;
-  const int v = (L % T2S_XCDS) * per + L / T2S_XCDS;
-  if (v >= total) return false;
-  const int bh = v / nblk;
-  blk = v - bh * nblk;
+  const int slot = L / T2S_XCDS;
+  const int g = slot / nblk;
+  const int bh = g * T2S_XCDS + L % T2S_XCDS;
+  if (bh >= H * B) return false;
+  blk = slot - g * nblk;
   b = bh / H;
   h = bh - b * H;
   return true;
 }
 inline unsigned attn_xcd_grid(int nblk, int H, int B) {
-  const long total = (long)nblk * H * B;
-  return (unsigned)(((total + T2S_XCDS - 1) / T2S_XCDS) * T2S_XCDS);
+  const long groups = ((long)H * B + T2S_XCDS - 1) / T2S_XCDS;
+  return (unsigned)(groups * T2S_XCDS * nblk);
 }
 
 // ---- LDS tile image shared by every bf16 tile (K, V, Q, dO): rows of 64 bf16 = 128 B = eight

@@ -267,6 +267,25 @@ class MMT(nn.Module):
         out = FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd, pa)
         return out[:, T + Fn:L1], out[:, L1:]
 
+    def forward_passes(self, txt_emb, txt_mask, obj_emb, obj_masks, ocr_emb, ocr_masks, fixed_ans_emb, prev_inds, dtype):
+        """The reference's three MMT calls of one train step (ref / pos / neg masks, t2s.py:293-313) as ONE encoder call on
+        a 3B batch: the passes share every weight and differ only in their key lists (and in the dropout draw of the
+        decoder-step embeddings, kept per pass), so stacking them along the batch is the same arithmetic per sample with
+        one gradient per weight instead of three accumulated ones and a third of the launches.  Returns one
+        (ocr_out, dec_out) pair per pass."""
+        pd, pa = _train_dropout(self)
+        B, T, Fn, N = txt_emb.size(0), txt_emb.size(1), obj_emb.size(1), ocr_emb.size(1)
+        L1 = T + Fn + N
+        xs, valids = [], []
+        for om, cm in zip(obj_masks, ocr_masks):
+            dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd)
+            xs.append(torch.cat([txt_emb, obj_emb, ocr_emb, dec_emb], dim=1))
+            valids.append(torch.cat([txt_mask > 0, om > 0, cm > 0], dim=1))
+        D = xs[0].size(1) - L1
+        keys = ops.compact_keys(torch.cat(valids, dim=0), n_dec=D, dec_row0=L1)
+        out = FN.bert_encoder(torch.cat(xs, dim=0), keys, self.encoder.layer, dtype, pd, pa)
+        return [(out[i * B:(i + 1) * B, T + Fn:L1], out[i * B:(i + 1) * B, L1:]) for i in range(len(xs))]
+
 
 class OcrPtrNet(nn.Module):
     """t2s.py:636-670 (Q12: the RAW 0/1 mask is added to the scores)."""
@@ -338,6 +357,7 @@ class T2S(BaseModel):
         self.classifier = _Classifier(HID, num_choices)
         self.answer_processor = registry.get(self._datasets[0] + "_answer_processor")
         self.decode_with_prefix_cache = True      # eval: reuse the step-invariant prefix K/V (False = reference's loop)
+        self.batch_mmt_passes = False             # train: True = the three MMT passes as one 3B-batch encoder call (MMT.forward_passes)
         for n, p in self.named_parameters():
             if is_dead_param(n):
                 p.requires_grad_(False)
@@ -414,9 +434,16 @@ class T2S(BaseModel):
         bounds = {"ref": None,
                   "pos": T + g.frame_topk + g.ocr_topk * g.frame_num + D,
                   "neg": T + g.frame_topk + g.ocr_topk * g.frame_topk + D}
-        for name, om, cm in (("ref", fwd["obj_mask"], fwd["ocr_mask"]),
-                             ("pos", fwd["pos_obj_mask"], fwd["pos_ocr_mask"]),
-                             ("neg", fwd["neg_obj_mask"], fwd["neg_ocr_mask"])):
+        passes = (("ref", fwd["obj_mask"], fwd["ocr_mask"]),
+                  ("pos", fwd["pos_obj_mask"], fwd["pos_ocr_mask"]),
+                  ("neg", fwd["neg_obj_mask"], fwd["neg_ocr_mask"]))
+        if self.training and self.batch_mmt_passes:
+            outs = self.mmt.forward_passes(fwd["txt_emb"], fwd["txt_mask"], fwd["obj_mmt_in"], [p[1] for p in passes],
+                                           fwd["ocr_mmt_in"], [p[2] for p in passes], self.classifier.module.weight, prev_inds, dt)
+            for (name, _, cm), (ocr_out, dec_out) in zip(passes, outs):
+                fwd[name + "_scores"] = self._forward_output(ocr_out, dec_out, cm, dt)
+            return
+        for name, om, cm in passes:
             ocr_out, dec_out = self.mmt(fwd["txt_emb"], fwd["txt_mask"], fwd["obj_mmt_in"], om, fwd["ocr_mmt_in"], cm,
                                         self.classifier.module.weight, prev_inds, dt, max_keys=bounds[name])
             fwd[name + "_scores"] = self._forward_output(ocr_out, dec_out, cm, dt)
