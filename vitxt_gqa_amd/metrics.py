@@ -11,8 +11,13 @@ Mirrors, with the reference's quirks kept (they change the numbers):
 * metric wrappers ``stvqa_anls`` / ``IOU@t`` pythia/modules/metrics.py:224-339: the decoding of ``pos_scores`` into answer
   strings (argmax, OCR-copy indices >= vocabulary size, stop at EOS) and the per-question grounding entries.  The
   reference reads the grounding annotation from a hard-coded .npy path; here it is handed to the constructor.
-``textvqa_accuracy`` (EvalAI answer normalisation tables, m4c_evaluators.py:5-259) is not rebuilt.
+* ``EvalAIAnswerProcessor`` / ``TextVQAAccuracyEvaluator`` / ``STVQAAccuracyEvaluator`` :5-274 and the ``textvqa_accuracy``
+  wrapper metrics.py:175-222: the VQA-challenge answer normalisation (lower-case, punctuation, number words, articles,
+  contractions) and the leave-one-out soft accuracy over 10 human answers.  The contraction table is generated from its
+  rule (see ``_contractions``) instead of being listed; ``tests/golden/evalai.json`` pins table and outputs.
 """
+import re
+
 import torch
 
 
@@ -105,6 +110,99 @@ class BoxGroundAccuracyEvaluator:
         return pred_scores, sum(pred_scores) / len(pred_scores)
 
 
+# ---- VQA-challenge ("EvalAI") answer normalisation and accuracies --------------------------------------------------------
+def _contractions():
+    """Misspelt -> apostrophised contraction (m4c_evaluators.py:12-133).  The table follows one rule: a form with ONE
+    apostrophe is looked up without it ("dont" -> "don't"); a form with several is looked up with exactly one of them
+    missing ("couldnt've", "couldn'tve" -> "couldn't've").  Three entries of the original table break the rule and are
+    kept as they are (identity for let's / she's, and the inverted somebody'd -> somebodyd)."""
+    single = ("'twas I'm I've ain't aren't can't could've couldn't didn't doesn't don't hadn't hasn't haven't he'd he's how'd "
+              "how'll how's isn't it'd it'll ma'am might've mightn't must've mustn't needn't not've o'clock oughtn't shan't "
+              "should've shouldn't somebody'll somebody's someone'd someone'll someone's something'd something'll that's "
+              "there'd there're there's they'd they'll they're they've wasn't we've weren't what'll what're what's what've "
+              "when's where'd where's where've who'd who'll who's who've why'll why're why's won't would've wouldn't y'all "
+              "you'd you'll you're you've").split()
+    several = ("couldn't've hadn't've he'd've I'd've it'd've mightn't've she'd've shouldn't've somebody'd've someone'd've "
+               "something'd've there'd've they'd've we'd've who'd've wouldn't've you'd've y'all'll y'all'd've 'ow's'at").split()
+    table = {w.replace("'", ""): w for w in single}
+    for w in several:
+        for m in re.finditer("'", w):
+            table[w[:m.start()] + w[m.end():]] = w
+    table.update({"let's": "let's", "she's": "she's", "somebody'd": "somebodyd"})
+    return table
+
+
+class EvalAIAnswerProcessor:
+    """``processor(answer) -> normalised answer``; quirks of the original kept because they change scores: the period
+    rule strips at most 32 periods (``re.UNICODE`` passed in the ``count`` slot, :192), the punctuation tests look at the
+    INPUT string while replacing in the output (:186-191), and the capitalised contraction keys can never match the
+    lower-cased words."""
+    CONTRACTIONS = _contractions()
+    NUMBER_MAP = dict(zip("none zero one two three four five six seven eight nine ten".split(), "0 0 1 2 3 4 5 6 7 8 9 10".split()))
+    ARTICLES = ("a", "an", "the")
+    PUNCTUATIONS = tuple(';/[]"{}()=+\\_-><@`,?!')
+    _period = re.compile(r"\.(?!\d)")                 # ":135" is "(?!<=\d)(\.)(?!\d)": its first group can never fail
+    _digit_comma = re.compile(r"(?<=\d)(\,)+(?=\d)")
+
+    def word_tokenize(self, word):
+        word = word.lower().replace(",", "").replace("?", "").replace("'s", " 's")
+        return word.strip()
+
+    def process_punctuation(self, text):
+        out = text
+        number_comma = self._digit_comma.search(text) is not None
+        for p in self.PUNCTUATIONS:
+            glued = (p + " " in text) or (" " + p in text) or number_comma
+            out = out.replace(p, "" if glued else " ")
+        return self._period.sub("", out, 32)
+
+    def process_digit_article(self, text):
+        words = [self.NUMBER_MAP.get(w, w) for w in text.lower().split()]
+        return " ".join(self.CONTRACTIONS.get(w, w) for w in words if w not in self.ARTICLES)
+
+    def __call__(self, item):
+        item = self.word_tokenize(item).replace("\n", " ").replace("\t", " ").strip()
+        return self.process_digit_article(self.process_punctuation(item))
+
+
+class TextVQAAccuracyEvaluator:
+    """Soft accuracy against 10 human answers: a predicted answer scores the mean over the 10 leave-one-out subsets of
+    min(1, matches / 3) (m4c_evaluators.py:223-259)."""
+
+    def __init__(self):
+        self.answer_processor = EvalAIAnswerProcessor()
+
+    def _compute_answer_scores(self, raw_answers):
+        answers = [self.answer_processor(a) for a in raw_answers]
+        assert len(answers) == 10
+        scores = {}
+        for ua in set(answers):
+            n = answers.count(ua)
+            # leaving out one of the n matching answers leaves n - 1 matches, leaving out another leaves n
+            accs = [min(1, float(n - (a == ua)) / 3) for a in answers]
+            scores[ua] = sum(accs) / len(accs)
+        return scores
+
+    def eval_pred_list(self, pred_scores, pred_list):
+        for entry in pred_list:
+            pred = self.answer_processor(entry["pred_answer"])
+            pred_scores.append(self._compute_answer_scores(entry["gt_answers"]).get(pred, 0.))
+        return pred_scores, sum(pred_scores) / len(pred_scores)
+
+
+class STVQAAccuracyEvaluator:
+    """1 if the normalised prediction equals any normalised ground truth (m4c_evaluators.py:262-274)."""
+
+    def __init__(self):
+        self.answer_processor = EvalAIAnswerProcessor()
+
+    def eval_pred_list(self, pred_scores, pred_list):
+        for entry in pred_list:
+            pred = self.answer_processor(entry["pred_answer"])
+            pred_scores.append(1. if pred in [self.answer_processor(a) for a in entry["gt_answers"]] else 0.)
+        return pred_scores, sum(pred_scores) / len(pred_scores)
+
+
 # ---- metric wrappers over (sample_list, model_output) ----------------------------------------------------------------
 def decode_answers(pred_inds, context_tokens, answer_vocab, vocab_size, eos_idx, word_tokenize=lambda w: w):
     """Indices [B, T] -> answer strings: ids >= vocab_size copy OCR token ``id - vocab_size``; decoding stops at EOS;
@@ -123,12 +221,13 @@ def decode_answers(pred_inds, context_tokens, answer_vocab, vocab_size, eos_idx,
     return out
 
 
-class STVQAANLS:
-    name = "stvqa_anls"
+class TextVQAAccuracy:
+    """``textvqa_accuracy`` (metrics.py:175-222): decode ``pos_scores`` and score against the 10 human answers."""
+    name = "textvqa_accuracy"
 
     def __init__(self, answer_vocab, eos_idx, word_tokenize=lambda w: w):
         self.vocab, self.eos, self.tok = answer_vocab, eos_idx, word_tokenize
-        self.evaluator = STVQAANLSEvaluator()
+        self.evaluator = TextVQAAccuracyEvaluator()
 
     def calculate(self, sample_list, model_output):
         pred = model_output["pos_scores"].argmax(dim=-1)
@@ -136,6 +235,15 @@ class STVQAANLS:
         entries = [{"pred_answer": a, "gt_answers": g} for a, g in zip(answers, sample_list["gt_answers"])]
         _, acc = self.evaluator.eval_pred_list([], entries)
         return torch.tensor(acc, device=model_output["pos_scores"].device)
+
+
+class STVQAANLS(TextVQAAccuracy):
+    """``stvqa_anls`` (metrics.py:224-231): the same decoding, scored by ANLS."""
+    name = "stvqa_anls"
+
+    def __init__(self, answer_vocab, eos_idx, word_tokenize=lambda w: w):
+        super().__init__(answer_vocab, eos_idx, word_tokenize)
+        self.evaluator = STVQAANLSEvaluator()
 
 
 class BoxGroundAccuracy:
