@@ -136,11 +136,12 @@ def test_cached_decode_equals_reference_loop(case, dtype, tol):
         assert torch.equal(a["pos_scores"].argmax(-1).cpu(), fx["eval_argmax"])
 
 
-@pytest.mark.parametrize("B,F,P,V", [(1, 5, 5, 11), (3, 7, 9, 40), (2, 33, 6, 300)])
+@pytest.mark.parametrize("B,F,P,V", [(1, 5, 5, 11), (3, 7, 9, 40), (2, 33, 6, 300), (2, 12, 1, 30), (2, 9, 3, 30)])
 def test_ragged_inputs_match_oracle(B, F, P, V):
     """Edge cases the dataset produces (Appendix B): text_len 1 and 20, padded frames (frame_mask 0, frame_id 0),
-    a sample whose OCR slots are all padding, minimum (F, P) = (frame_topk, ocr_topk), odd sizes that do not divide
-    any tile.  Whole model (own selection, noise injected) vs the CPU oracle with the same tie rule, fp32 mode."""
+    a sample whose OCR slots are all padding, minimum (F, P) = (frame_topk, ocr_topk), P < ocr_topk (the reference's
+    slice then keeps all P slots of a frame: the "100 OCR tokens in total" reading of BASELINE's shape is F=100, P=1),
+    odd sizes that do not divide any tile.  Whole model (own selection, noise injected) vs the CPU oracle with the same tie rule, fp32 mode."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle import t2s_oracle as O

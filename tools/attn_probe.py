@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the attention kernels (fwd, bwd) in isolation at a given shape with HIP events.
-usage: python tools/attn_probe.py [B L keep n_dec iters]"""
+usage: python tools/attn_probe.py [B L keep n_dec iters drop_p]"""
 import sys
 import time
 
@@ -18,6 +18,8 @@ def main():
     keep = float(a[2]) if len(a) > 2 else 1.0
     n_dec = int(a[3]) if len(a) > 3 else 12
     iters = int(a[4]) if len(a) > 4 else 5
+    dp = float(a[5]) if len(a) > 5 else 0.0
+    kw = dict(drop_p=dp, drop_seed=1234) if dp > 0 else {}
     L = L1 + n_dec
     dev = "cuda:0"
     torch.manual_seed(0)
@@ -27,24 +29,25 @@ def main():
     valid[:, 0] = True
     keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
     nk = float(keys.cnt.float().mean().item()) + n_dec
-    out, lse = ops.attn_fwd(qkv, keys)
+    out, lse = ops.attn_fwd(qkv, keys, **kw)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     ev[0].record()
     for _ in range(iters):
-        out, lse = ops.attn_fwd(qkv, keys)
+        out, lse = ops.attn_fwd(qkv, keys, **kw)
     ev[1].record()
-    dq = ops.attn_bwd(qkv, out, dout, lse, keys)
+    dq = ops.attn_bwd(qkv, out, dout, lse, keys, **kw)
     torch.cuda.synchronize()
     ev[2].record()
     for _ in range(iters):
-        dq = ops.attn_bwd(qkv, out, dout, lse, keys)
+        dq = ops.attn_bwd(qkv, out, dout, lse, keys, **kw)
     ev[3].record()
     torch.cuda.synchronize()
     tf = ev[0].elapsed_time(ev[1]) / iters
     tb = ev[2].elapsed_time(ev[3]) / iters
     dense = 4.0 * B * 12 * L * L * 64
     execd = 4.0 * B * 12 * L * nk * 64
+    print("drop=%.2f " % dp, end="")
     print("B=%d L=%d keys=%.0f  fwd %.3f ms: %.1f TF/s dense-equivalent, %.1f TF/s executed | bwd %.3f ms: %.1f TF/s (2.5x fwd flops) executed %.1f"
           % (B, L, nk, tf, dense / tf / 1e9, execd / tf / 1e9, tb, 2.5 * dense / tb / 1e9, 2.5 * execd / tb / 1e9))
 

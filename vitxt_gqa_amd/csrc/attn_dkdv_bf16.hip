@@ -12,6 +12,13 @@
 
 #include "attn_common.h"
 
+// sweep form: -DT2S_DKDV_STAGED selects the staged wavefront (attn_dkdv_bf16_sweep_staged.inc)
+#ifdef T2S_DKDV_STAGED
+#define T2S_DKDV_SWEEP "attn_dkdv_bf16_sweep_staged.inc"
+#else
+#define T2S_DKDV_SWEEP "attn_dkdv_bf16_sweep.inc"
+#endif
+
 namespace {
 
 constexpr int QROWS = 64;                         // query rows per iteration
@@ -120,13 +127,13 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   // compiler's schedule of the single loop with the run-time flag is better), so that form is kept as it was.
   if (!DROP) {
     const bool edge = edge_wg;
-#include "attn_dkdv_bf16_sweep.inc"
+#include T2S_DKDV_SWEEP
   } else if (!edge_wg) {
     constexpr bool edge = false;
-#include "attn_dkdv_bf16_sweep.inc"
+#include T2S_DKDV_SWEEP
   } else {
     constexpr bool edge = true;
-#include "attn_dkdv_bf16_sweep.inc"
+#include T2S_DKDV_SWEEP
   }
 #undef STAGE_LOAD
 #undef STAGE_WRITE

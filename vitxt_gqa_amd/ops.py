@@ -230,9 +230,13 @@ def attention_score(q, k, mask):
 
 def ground_select(frame_score, frame_mask, expo_frame, frame_id, q_global, ocr_feat, expo_ocr, temporal_id, bbox,
                   F, P, frame_topk, ocr_topk):
-    """Temporal + spatial grounding selection (see include/t2s_hip.h).  Returns a dict of masks / outputs."""
+    """Temporal + spatial grounding selection (see include/t2s_hip.h).  Returns a dict of masks / outputs.
+    With fewer than ``ocr_topk`` OCR slots per frame the reference's slice ``sorted[:, :, :o_topk]``
+    (spatio_temporal_grounding.py:104,112) simply takes all P of them, so ``ground_box`` is [B, F * min(P, ocr_topk), 4];
+    ``frame_topk > F`` fails there too (``torch.topk``) and is refused by the kernel."""
     B = frame_score.shape[0]
     N = F * P
+    ocr_topk = min(int(ocr_topk), int(P))
     dev = frame_score.device
     f32 = dict(dtype=torch.float32, device=dev)
     assert frame_score.shape == (B, F) and frame_mask.shape == (B, F) and expo_frame.shape == (B, 2, F)
