@@ -44,10 +44,15 @@ __device__ __forceinline__ uint32_t attn_hash32(uint32_t x) {
 __device__ __forceinline__ uint32_t attn_drop_salt(uint32_t seed_lo, uint32_t seed_hi, uint32_t bh) {
   return attn_hash32(seed_lo ^ attn_hash32(seed_hi ^ (bh * 0x9E3779B1u)));
 }
+#ifdef T2S_ABL_NOHASH   // timing-only ablation (tools/ablate): key generation without its cost; never defined in a product build
+__device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q) { return (salt + (uint32_t)q) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) { return (salt ^ (uint32_t)kpos) & 0xFFFFu; }
+#else
 __device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q) { return attn_hash32(salt + (uint32_t)q * 0x85EBCA6Bu) >> 16; }
 __device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) {
   return attn_hash32((salt ^ 0xC2B2AE35u) + (uint32_t)kpos * 0x27D4EB2Fu) >> 16;
 }
+#endif
 constexpr uint32_t ATTN_DROP_MUL = 0x9E37u;
 // generic per-element form (fp32 kernels, mask export)
 __device__ __forceinline__ bool attn_drop_keep16(uint32_t rk16, uint32_t ck16, uint32_t thresh) {

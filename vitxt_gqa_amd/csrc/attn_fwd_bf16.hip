@@ -32,8 +32,13 @@ constexpr int BK = 64;                     // keys per tile
 constexpr int TILE_BYTES = BK * 128;       // one 64-row bf16 tile image
 constexpr float BIG = 1.2089258e24f;       // 2^80
 
+// experiment switches (tools/ablate/README.md): T2S_FWD_OCC = waves per SIMD the register budget is sized for,
+// T2S_FWD_QREG = keep the pre-scaled Q fragments in registers instead of re-reading them from LDS every tile
+#ifndef T2S_FWD_OCC
+#define T2S_FWD_OCC 2
+#endif
 template <bool USE_IDX, int QB, bool DROP, bool REPAIR>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnParams p) {
   // [buf][K,V] double buffer, then one pre-scaled (32*QB)-row Q tile per wave
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES + 4 * QB * 32 * 128];
   __shared__ uint32_t ck_s[2][32];                  // dropout: column keys of the tile's 32 key pairs (packed 16-bit halves)
@@ -155,6 +160,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     if (DROP && tid < 32) ck_s[buf_][tid] = ckreg;                                                  \
   }
 
+#ifdef T2S_FWD_QREG
+  bf16x8 qreg[QB][4];
+  __syncthreads();
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qreg[qb][s] = ROW_FRAG(qoff, qb, s);
+#define Q_FRAG(qb_, s_) qreg[qb_][s_]
+#else
+#define Q_FRAG(qb_, s_) ROW_FRAG(qoff, qb_, s_)
+#endif
   f32x16 oacc[QB][2], sacc[QB][2], negm[QB];
   bf16x8 pf[QB][2][2];
   float m_run[QB], l_run[QB];
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       for (int s = 0; s < 4; ++s) {
         const bf16x8 kf = ROW_FRAG(0, kbk, s);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) sacc[qb][kbk] = mfma_bf16(kf, ROW_FRAG(qoff, qb, s), sacc[qb][kbk]);
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][kbk] = mfma_bf16(kf, Q_FRAG(qb, s), sacc[qb][kbk]);
       }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -293,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       for (int s = 0; s < 4; ++s) {
         const bf16x8 kf = ROW_FRAG(kb, 0, s);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) sacc[qb][0] = mfma_bf16(kf, ROW_FRAG(qoff, qb, s), s == 0 ? negm[qb] : sacc[qb][0]);
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][0] = mfma_bf16(kf, Q_FRAG(qb, s), s == 0 ? negm[qb] : sacc[qb][0]);
       }
       __builtin_amdgcn_sched_barrier(0);
       // stage B: S(key block 1) beside the softmax of key block 0
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       for (int s = 0; s < 4; ++s) {
         const bf16x8 kf = ROW_FRAG(kb, 1, s);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) sacc[qb][1] = mfma_bf16(kf, ROW_FRAG(qoff, qb, s), s == 0 ? negm[qb] : sacc[qb][1]);
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][1] = mfma_bf16(kf, Q_FRAG(qb, s), s == 0 ? negm[qb] : sacc[qb][1]);
       }
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) SOFTMAX_BLOCK(qb, 0, t);
@@ -336,6 +352,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #undef PACK_P
 #undef PV_MFMAS
 #undef ROW_FRAG
+#undef Q_FRAG
 #undef STAGE_LOAD
 #undef STAGE_LOAD_ROWS
 #undef IDX_LOAD
