@@ -106,6 +106,17 @@ int t2s_add_layernorm_fwd(const void* x, const void* res, const float* gamma, co
                           int x_dtype, int stream_dtype, float drop_p, uint64_t drop_seed,
                           t2s_stream_t stream);
 
+/* The same with the residual given in NORMALISED form: res_z is the pre-LayerNorm sum z of the PREVIOUS
+ * residual+LayerNorm block (what that call wrote to z_out), res_stats its (mean, rstd) rows and res_gamma /
+ * res_beta its affine; the kernel adds LN(res_z) computed on the fly.  Inside a BERT layer stack the fp32 stream value
+ * y is then never written to or re-read from HBM between blocks (y may be NULL when y_lo is given): 12 instead of 16
+ * bytes per element of the forward pass.  Replaces the same reference lines as t2s_add_layernorm_fwd. */
+int t2s_add_layernorm_fwd_nres(const void* x, const void* res_z, const float* res_stats,
+                               const float* res_gamma, const float* res_beta, const float* gamma,
+                               const float* beta, void* y, void* y_lo, void* z_out, float* stats,
+                               int64_t rows, float eps, int x_dtype, int stream_dtype, float drop_p,
+                               uint64_t drop_seed, t2s_stream_t stream);
+
 /* dz = LN backward wrt z (= grad of both x and res); dgamma_part/dbeta_part: [n_part, 768] fp32
  * partial sums (n_part = t2s_layernorm_bwd_parts(rows)); the caller reduces over dim 0.
  * Supported (dy, z, dz) dtypes: (f32,f32,f32), (f32,f32,bf16), (bf16,f32,bf16), (bf16,bf16,bf16).
@@ -116,6 +127,13 @@ int t2s_add_layernorm_bwd(const void* dy, const void* z, const float* stats, con
                           void* dz, void* dzx, float* dgamma_part, float* dbeta_part, int64_t rows,
                           int dy_dtype, int z_dtype, int dz_dtype, float drop_p, uint64_t drop_seed,
                           t2s_stream_t stream);
+/* The same plus dbias_part [n_part, 768] fp32: per-column partial sums of the branch-input gradient (dzx with
+ * dropout, dz without) = the bias gradient of the dense layer that produced x (BertSelfOutput.dense /
+ * BertOutput.dense), which the reference gets from a separate reduction over all rows. */
+int t2s_add_layernorm_bwd_bias(const void* dy, const void* z, const float* stats, const float* gamma,
+                               void* dz, void* dzx, float* dgamma_part, float* dbeta_part,
+                               float* dbias_part, int64_t rows, int dy_dtype, int z_dtype, int dz_dtype,
+                               float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 /* keep mask (0/1 bytes) of the dropout above for element indices 0..n-1 (test / debugging aid). */
 int t2s_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 

@@ -238,3 +238,32 @@ def test_bert_layer_fn(dtype, tol):
             assert a.abs().max().item() < (1e-3 if dtype == torch.float32 else 0.5)
             continue
         assert rel < (2e-4 if dtype == torch.float32 else 4e-2), "%s rel err %.3e" % (n, rel)
+
+
+@pytest.mark.parametrize("rows,drop_p", [(5, 0.0), (1030, 0.0), (1030, 0.1)])
+def test_add_layernorm_normalised_residual_and_bias_sums(rows, drop_p):
+    """t2s_add_layernorm_fwd_nres: the residual handed over as (z, stats, gamma, beta) of the previous block gives the
+    same output as handing over that block's materialised fp32 output; t2s_add_layernorm_bwd_bias: the extra partial sums
+    are the column sums of the branch-input gradient."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    torch.manual_seed(rows)
+    x0 = torch.randn(rows, 768, device=DEV).to(torch.bfloat16)
+    r0 = torch.randn(rows, 768, device=DEV)
+    g0, b0 = torch.rand(768, device=DEV) + 0.5, torch.randn(768, device=DEV) * 0.1
+    y0, _, z0, st0 = ops.add_layernorm_fwd(x0, r0, g0, b0, stream_dtype=torch.float32, want_lo=True)
+    x1 = torch.randn(rows, 768, device=DEV).to(torch.bfloat16)
+    g1, b1 = torch.rand(768, device=DEV) + 0.5, torch.randn(768, device=DEV) * 0.1
+    kw = dict(stream_dtype=torch.float32, want_lo=True, drop_p=drop_p, drop_seed=99)
+    ya, ya_lo, za, sta = ops.add_layernorm_fwd(x1.clone(), y0, g1, b1, **kw)
+    yb, yb_lo, zb, stb = ops.add_layernorm_fwd(x1.clone(), ops.NormRes(z0, st0, g0, b0), g1, b1, **kw)
+    assert (ya - yb).abs().max().item() < 2e-6 and (za - zb).abs().max().item() < 2e-6 and (sta - stb).abs().max().item() < 1e-5
+    assert torch.equal(ya_lo, yb_lo) or (ya_lo.float() - yb_lo.float()).abs().max().item() < 0.04       # a bf16 ulp at |y| ~ 4
+    yc, yc_lo, _, _ = ops.add_layernorm_fwd(x1.clone(), ops.NormRes(z0, st0, g0, b0), g1, b1, want_y=False, **kw)
+    assert yc is None and torch.equal(yc_lo, yb_lo)
+    dy = torch.randn(rows, 768, device=DEV).to(torch.bfloat16)
+    dz, dzx, dg, db = ops.add_layernorm_bwd(dy, za, sta, g1, out_dtype=torch.bfloat16, drop_p=drop_p, drop_seed=99)
+    dz2, dzx2, dg2, db2, dbias = ops.add_layernorm_bwd(dy, za, sta, g1, out_dtype=torch.bfloat16, drop_p=drop_p, drop_seed=99, want_bias=True)
+    assert torch.equal(dz, dz2) and torch.equal(dzx, dzx2) and torch.allclose(dg, dg2) and torch.allclose(db, db2)
+    ref = dzx.double().sum(0)
+    assert (dbias.double() - ref).abs().max().item() < 2e-3 * (1 + ref.abs().max().item()) + 4e-3 * rows ** 0.5   # ref sums bf16-ROUNDED values

@@ -38,12 +38,19 @@ template <typename TX, typename TS>
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const TX* __restrict__ x, const TS* __restrict__ res,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 TS* __restrict__ y, bf16_t* __restrict__ y_lo, TS* z_out,
-                                                                float* __restrict__ stats, int64_t rows, float eps, DropCfg drop) {
+                                                                float* __restrict__ stats, int64_t rows, float eps, DropCfg drop,
+                                                                const float* __restrict__ res_stats, const float* __restrict__ res_gamma,
+                                                                const float* __restrict__ res_beta) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
   f32x4 v[3];
   float s = 0.f;
+  // normalised residual: `res` holds the previous block's pre-LayerNorm sum and is normalised on the fly with that
+  // block's statistics and affine (the same expression that block's own output used), so the fp32 stream value never
+  // makes a round trip through HBM
+  float rmean = 0.f, rrstd = 1.f;
+  if (res_stats) { rmean = res_stats[row * 2]; rrstd = res_stats[row * 2 + 1]; }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int e = (i * 64 + lane) * 4;
@@ -53,7 +60,13 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const TX* __rest
       for (int j = 0; j < 4; ++j) v[i][j] *= drop_keep_scale(drop, (uint32_t)(row * H + e + j));
     }
     if (res) {
-      const f32x4 r = Vec4<TS>::load(res + row * H + e);
+      f32x4 r = Vec4<TS>::load(res + row * H + e);
+      if (res_stats) {
+        const f32x4 rg = *reinterpret_cast<const f32x4*>(res_gamma + e);
+        const f32x4 rb = *reinterpret_cast<const f32x4*>(res_beta + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = (r[j] - rmean) * rrstd * rg[j] + rb[j];
+      }
       v[i] += r;
     }
     s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
@@ -97,15 +110,16 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const TDY* __res
                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                 TDZ* __restrict__ dz, TDZ* __restrict__ dzx,
                                                                 float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
-                                                                int64_t rows, DropCfg drop) {
-  __shared__ float red[2][4][H];
+                                                                float* __restrict__ dbias_part, int64_t rows, DropCfg drop) {
+  __shared__ float red[3][4][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 g[3], dg[3], db[3];
+  f32x4 g[3], dg[3], db[3], dbi[3];      // dbi: column sums of the branch-input gradient (= bias gradient of the dense layer before)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     g[i] = *reinterpret_cast<const f32x4*>(gamma + (i * 64 + lane) * 4);
     dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dbi[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
@@ -140,6 +154,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const TDY* __res
         for (int j = 0; j < 4; ++j) o[j] *= drop_keep_scale(drop, (uint32_t)(row * H + (i * 64 + lane) * 4 + j));
         Vec4<TDZ>::store(dzx + row * H + (i * 64 + lane) * 4, o);
       }
+      if (dbias_part) dbi[i] += o;
     }
   }
 #pragma unroll
@@ -148,11 +163,13 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const TDY* __res
     for (int j = 0; j < 4; ++j) {
       red[0][wave][(i * 64 + lane) * 4 + j] = dg[i][j];
       red[1][wave][(i * 64 + lane) * 4 + j] = db[i][j];
+      red[2][wave][(i * 64 + lane) * 4 + j] = dbi[i][j];
     }
   __syncthreads();
   for (int cix = threadIdx.x; cix < H; cix += 256) {
     dgamma_part[(int64_t)blockIdx.x * H + cix] = red[0][0][cix] + red[0][1][cix] + red[0][2][cix] + red[0][3][cix];
     dbeta_part[(int64_t)blockIdx.x * H + cix] = red[1][0][cix] + red[1][1][cix] + red[1][2][cix] + red[1][3][cix];
+    if (dbias_part) dbias_part[(int64_t)blockIdx.x * H + cix] = red[2][0][cix] + red[2][1][cix] + red[2][2][cix] + red[2][3][cix];
   }
 }
 
@@ -179,9 +196,10 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
 
 }  // namespace
 
-extern "C" int t2s_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* y_lo,
-                                     void* z_out, float* stats, int64_t rows, float eps, int x_dtype, int stream_dtype,
-                                     float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
+static int add_layernorm_fwd_impl(const void* x, const void* res, const float* res_stats, const float* res_gamma, const float* res_beta,
+                                  const float* gamma, const float* beta, void* y, void* y_lo,
+                                  void* z_out, float* stats, int64_t rows, float eps, int x_dtype, int stream_dtype,
+                                  float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
   T2S_CHECK_ARG(x && gamma && beta && (y || y_lo), "add_layernorm_fwd: null pointer");
   T2S_CHECK_ARG(rows > 0 && rows < ((int64_t)1 << 33), "add_layernorm_fwd: bad rows %lld", (long long)rows);
   T2S_CHECK_ARG(is_dt(x_dtype) && is_dt(stream_dtype), "add_layernorm_fwd: bad dtype %d/%d", x_dtype, stream_dtype);
@@ -193,22 +211,38 @@ extern "C" int t2s_add_layernorm_fwd(const void* x, const void* res, const float
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype == T2S_BF16 && stream_dtype == T2S_BF16)
     hipLaunchKernelGGL((add_layernorm_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)res, gamma, beta,
-                       (bf16_t*)y, (bf16_t*)y_lo, (bf16_t*)z_out, stats, rows, eps, drop);
+                       (bf16_t*)y, (bf16_t*)y_lo, (bf16_t*)z_out, stats, rows, eps, drop, res_stats, res_gamma, res_beta);
   else if (x_dtype == T2S_BF16)
     hipLaunchKernelGGL((add_layernorm_fwd_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)x, (const float*)res, gamma, beta,
-                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps, drop);
+                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps, drop, res_stats, res_gamma, res_beta);
   else
     hipLaunchKernelGGL((add_layernorm_fwd_kernel<float, float>), grid, block, 0, st, (const float*)x, (const float*)res, gamma, beta,
-                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps, drop);
+                       (float*)y, (bf16_t*)y_lo, (float*)z_out, stats, rows, eps, drop, res_stats, res_gamma, res_beta);
   T2S_CHECK_LAUNCH("add_layernorm_fwd");
   return 0;
 }
 
+extern "C" int t2s_add_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* y_lo,
+                                     void* z_out, float* stats, int64_t rows, float eps, int x_dtype, int stream_dtype,
+                                     float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
+  return add_layernorm_fwd_impl(x, res, nullptr, nullptr, nullptr, gamma, beta, y, y_lo, z_out, stats, rows, eps, x_dtype, stream_dtype,
+                                drop_p, drop_seed, stream);
+}
+
+extern "C" int t2s_add_layernorm_fwd_nres(const void* x, const void* res_z, const float* res_stats, const float* res_gamma,
+                                          const float* res_beta, const float* gamma, const float* beta, void* y, void* y_lo,
+                                          void* z_out, float* stats, int64_t rows, float eps, int x_dtype, int stream_dtype,
+                                          float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
+  T2S_CHECK_ARG(res_z && res_stats && res_gamma && res_beta, "add_layernorm_fwd_nres: null pointer in the normalised residual");
+  return add_layernorm_fwd_impl(x, res_z, res_stats, res_gamma, res_beta, gamma, beta, y, y_lo, z_out, stats, rows, eps, x_dtype,
+                                stream_dtype, drop_p, drop_seed, stream);
+}
+
 extern "C" int t2s_layernorm_bwd_parts(int64_t rows) { return bwd_parts(rows); }
 
-extern "C" int t2s_add_layernorm_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* dz, void* dzx,
-                                     float* dgamma_part, float* dbeta_part, int64_t rows, int dy_dtype, int z_dtype, int dz_dtype,
-                                     float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
+static int add_layernorm_bwd_impl(const void* dy, const void* z, const float* stats, const float* gamma, void* dz, void* dzx,
+                                  float* dgamma_part, float* dbeta_part, float* dbias_part, int64_t rows, int dy_dtype, int z_dtype,
+                                  int dz_dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
   T2S_CHECK_ARG(dy && z && stats && gamma && dz && dgamma_part && dbeta_part, "add_layernorm_bwd: null pointer");
   T2S_CHECK_ARG(rows > 0, "add_layernorm_bwd: bad rows");
   T2S_CHECK_ARG(is_dt(dy_dtype) && is_dt(z_dtype) && is_dt(dz_dtype), "add_layernorm_bwd: bad dtype");
@@ -219,7 +253,7 @@ extern "C" int t2s_add_layernorm_bwd(const void* dy, const void* z, const float*
   const int combo = dy_dtype * 4 + z_dtype * 2 + dz_dtype;
 #define LN_BWD(TDY, TZ, TDZ)                                                                                                   \
   hipLaunchKernelGGL((add_layernorm_bwd_kernel<TDY, TZ, TDZ>), grid, block, 0, st, (const TDY*)dy, (const TZ*)z, stats, gamma, \
-                     (TDZ*)dz, (TDZ*)dzx, dgamma_part, dbeta_part, rows, drop)
+                     (TDZ*)dz, (TDZ*)dzx, dgamma_part, dbeta_part, dbias_part, rows, drop)
   switch (combo) {
     case 0: LN_BWD(float, float, float); break;
     case 1: LN_BWD(float, float, bf16_t); break;
@@ -232,6 +266,21 @@ extern "C" int t2s_add_layernorm_bwd(const void* dy, const void* z, const float*
 #undef LN_BWD
   T2S_CHECK_LAUNCH("add_layernorm_bwd");
   return 0;
+}
+
+extern "C" int t2s_add_layernorm_bwd(const void* dy, const void* z, const float* stats, const float* gamma, void* dz, void* dzx,
+                                     float* dgamma_part, float* dbeta_part, int64_t rows, int dy_dtype, int z_dtype, int dz_dtype,
+                                     float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
+  return add_layernorm_bwd_impl(dy, z, stats, gamma, dz, dzx, dgamma_part, dbeta_part, nullptr, rows, dy_dtype, z_dtype, dz_dtype, drop_p,
+                                drop_seed, stream);
+}
+
+extern "C" int t2s_add_layernorm_bwd_bias(const void* dy, const void* z, const float* stats, const float* gamma, void* dz, void* dzx,
+                                          float* dgamma_part, float* dbeta_part, float* dbias_part, int64_t rows, int dy_dtype,
+                                          int z_dtype, int dz_dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
+  T2S_CHECK_ARG(dbias_part, "add_layernorm_bwd_bias: null dbias_part");
+  return add_layernorm_bwd_impl(dy, z, stats, gamma, dz, dzx, dgamma_part, dbeta_part, dbias_part, rows, dy_dtype, z_dtype, dz_dtype,
+                                drop_p, drop_seed, stream);
 }
 
 extern "C" int t2s_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, t2s_stream_t stream) {

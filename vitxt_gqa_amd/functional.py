@@ -40,21 +40,29 @@ def _wgrad(dy2, x2, B):
     return part.sum(0, dtype=F32).to(dy2.dtype)
 
 
-def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute):
-    """One BERT layer on rows: x2 [B*L, 768] fp32 residual stream, xl its operand-dtype copy.  W = (w_qkv, b_qkv, w_ao, b_ao,
-    g1, be1, w_i, b_i, w_o, b_o, g2, be2).  Returns (y2 fp32, y2_lo or None, tensors to keep for backward)."""
+def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute, materialise=True):
+    """One BERT layer on rows: x2 the fp32 residual stream entering the layer ([B*L, 768] tensor, or an ``ops.NormRes`` left
+    by the previous layer), xl its operand-dtype copy.  W = (w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2,
+    be2).  Returns (y2, y2_lo or None, tensors to keep for backward).  In the bf16 operand mode the fp32 stream value
+    between two residual+LayerNorm blocks exists only in normalised form (pre-LN sum + statistics, both kept for backward
+    anyway): the next block's kernel re-normalises it on the fly, so it is never written to HBM; y2 is then an
+    ``ops.NormRes`` unless ``materialise`` (last layer of a stack)."""
     w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2 = W
     lo = w_qkv.dtype != F32
     qkv = _mm_bias(xl, w_qkv, b_qkv).view(B, L, 3 * HID)
     att, lse = ops.attn_fwd(qkv, keys, drop_p=attn_drop_p, drop_seed=seeds[2])
     a = _mm_bias(att.view(B * L, HID), w_ao, b_ao)
-    y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[0])
+    y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo, want_y=not lo, drop_p=drop_p, drop_seed=seeds[0])
     del a
     y1_op = y1_lo if lo else y1
+    res1 = ops.NormRes(z1, st1, g1, be1) if lo else y1
     u = _mm_bias(y1_op, w_i, b_i)
     gact = ops.gelu_fwd(u)
     o = _mm_bias(gact, w_o, b_o)
-    y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, y1, g2, be2, stream_dtype=F32, want_lo=lo, drop_p=drop_p, drop_seed=seeds[1])
+    keep_y2 = materialise or not lo
+    y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, res1, g2, be2, stream_dtype=F32, want_lo=lo, want_y=keep_y2, drop_p=drop_p, drop_seed=seeds[1])
+    if not keep_y2:
+        y2 = ops.NormRes(z2, st2, g2, be2)
     if recompute:      # store less: GELU output and the LN1 operand copy are rebuilt in backward
         gact = y1_op = None
     return y2, (y2_lo if lo else None), (xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op)
@@ -62,17 +70,17 @@ def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute)
 
 def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p):
     """dy: [B*L, 768] gradient of the layer output (fp32 or the operand dtype).  Returns (dx [B*L, 768] in the operand
-    dtype, the 12 parameter gradients in the order of W)."""
+    dtype, the 12 parameter gradients in the order of W).  The bias gradients of the two projections that feed a
+    residual+LayerNorm block come out of that block's backward kernel (column sums in the same pass)."""
     xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op = saved
     B, L, _ = qkv.shape
     dt = w_qkv.dtype
     lo = dt != F32
     # ---- output LayerNorm + FFN
-    dz2, dz2x, dg2, dbe2 = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[1])
+    dz2, dz2x, dg2, dbe2, db_o = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[1], want_bias=True)
     if gact is None:
         gact = ops.gelu_fwd(u)
     dw_o = _wgrad(dz2x, gact, B)
-    db_o = dz2x.sum(0)
     dgact = dz2x @ w_o
     del gact, dz2x
     du, db_i = ops.gelu_bwd(dgact, u)
@@ -85,10 +93,9 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p):
     dy1 = torch.addmm(dz2, du, w_i)                                      # + residual branch of LN2
     del du, y1_op, dz2
     # ---- attention output LayerNorm + projection
-    dz1, dz1x, dg1, dbe1 = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[0])
+    dz1, dz1x, dg1, dbe1, db_ao = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[0], want_bias=True)
     del dy1
     dw_ao = _wgrad(dz1x, att.view(B * L, HID), B)
-    db_ao = dz1x.sum(0)
     datt = (dz1x @ w_ao).view(B, L, HID)
     del dz1x
     # ---- attention
@@ -97,7 +104,7 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p):
     dw_qkv = _wgrad(dqkv, xl, B)
     db_qkv = dqkv.sum(0)
     dx = torch.addmm(dz1, dqkv, w_qkv)                                   # + residual branch of LN1
-    return dx, (dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1, dw_i, db_i.to(dt), dw_o, db_o, dg2, dbe2)
+    return dx, (dw_qkv, db_qkv, dw_ao, db_ao.to(dt), dg1, dbe1, dw_i, db_i.to(dt), dw_o, db_o.to(dt), dg2, dbe2)
 
 
 class BertLayerFn(torch.autograd.Function):
@@ -144,7 +151,7 @@ class BertEncoderFn(torch.autograd.Function):
         keep, counts = [], []
         for l in range(n_layers):
             x2, x_lo, saved = _layer_forward(x2, xl, keys, B, L, flat_w[12 * l:12 * l + 12], drop_p, seeds[l], attn_drop_p,
-                                             RECOMPUTE_ACTIVATIONS)
+                                             RECOMPUTE_ACTIVATIONS, materialise=(l == n_layers - 1))
             xl = x_lo if x_lo is not None else x2
             counts.append([t is not None for t in saved])
             keep.extend(t for t in saved if t is not None)

@@ -24,8 +24,10 @@ _SIGS = {
     "t2s_attn_dropout_mask": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_uint64, c_void_p, c_void_p]),
     "t2s_attn_bwd": (c_int, [c_void_p] * 12 + [c_int] * 7 + [c_int64] * 6 + [c_float, c_int, c_float, c_uint64, c_void_p, c_void_p]),
     "t2s_add_layernorm_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_float, c_int, c_int, c_float, c_uint64, c_void_p]),
+    "t2s_add_layernorm_fwd_nres": (c_int, [c_void_p] * 11 + [c_int64, c_float, c_int, c_int, c_float, c_uint64, c_void_p]),
     "t2s_layernorm_bwd_parts": (c_int, [c_int64]),
     "t2s_add_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_float, c_uint64, c_void_p]),
+    "t2s_add_layernorm_bwd_bias": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_int, c_int, c_float, c_uint64, c_void_p]),
     "t2s_dropout_mask": (c_int, [c_void_p, c_int64, c_float, c_uint64, c_void_p]),
     "t2s_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "t2s_gelu_bwd_parts": (c_int, [c_int64]),

@@ -127,43 +127,71 @@ def _check_keys(keys, B, L):
     assert keys.dec_q0 + keys.n_dec <= L or keys.n_dec == 0, "decoder rows must lie inside the sequence"
 
 
+class NormRes:
+    """A residual-stream value kept in NORMALISED form: ``LN(z)`` with the statistics and affine of the block that produced
+    ``z``.  The next residual+LayerNorm kernel normalises it on the fly (t2s_add_layernorm_fwd_nres), so the fp32 stream
+    value is never written to HBM between two blocks of a layer stack."""
+    __slots__ = ("z", "stats", "gamma", "beta")
+
+    def __init__(self, z, stats, gamma, beta):
+        self.z, self.stats, self.gamma, self.beta = z, stats, gamma, beta
+
+    @property
+    def shape(self):
+        return self.z.shape
+
+
 def add_layernorm_fwd(x, res, gamma, beta, eps=1e-12, save=True, inplace_z=True, stream_dtype=None, want_lo=False,
                       want_y=True, drop_p=0.0, drop_seed=0):
     """y = LN(x + res).  x: GEMM-output dtype; res / y / z: residual-stream dtype (``stream_dtype``, default
     x.dtype).  Returns (y, y_lo, z, stats): y_lo = bf16 copy of y (if want_lo), z = x + res kept for backward
-    (written over x when the dtypes match and inplace_z), stats [rows, 2] = (mean, rstd).  res may be None."""
+    (written over x when the dtypes match and inplace_z), stats [rows, 2] = (mean, rstd).  res may be None, a tensor, or
+    a ``NormRes`` (the previous block's output in normalised form)."""
     rows = _rows768(x)
     sdt = stream_dtype or x.dtype
-    if res is not None:
+    nres = isinstance(res, NormRes)
+    if nres:
+        assert res.z.shape == x.shape and res.z.is_contiguous() and res.z.dtype == sdt and res.stats.shape == (rows, 2)
+        assert res.gamma.dtype == torch.float32 and res.beta.dtype == torch.float32 and res.gamma.numel() == HID
+    elif res is not None:
         assert res.shape == x.shape and res.is_contiguous() and res.dtype == sdt
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == HID
+    assert want_y or want_lo
     y = torch.empty(x.shape, dtype=sdt, device=x.device) if want_y else None
     y_lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lo else None
     z = None
     if save:
         z = x if (inplace_z and sdt == x.dtype) else torch.empty(x.shape, dtype=sdt, device=x.device)
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save else None
-    X.check(X.lib().t2s_add_layernorm_fwd(X.ptr(x), X.ptr(res), X.ptr(gamma), X.ptr(beta), X.ptr(y), X.ptr(y_lo), X.ptr(z),
-                                          X.ptr(stats), rows, eps, X.dtype_code(x), X.T2S_F32 if sdt == torch.float32 else X.T2S_BF16,
-                                          float(drop_p), int(drop_seed), X.stream()),
-            "t2s_add_layernorm_fwd")
+    tail = (X.ptr(gamma), X.ptr(beta), X.ptr(y), X.ptr(y_lo), X.ptr(z), X.ptr(stats), rows, eps, X.dtype_code(x),
+            X.T2S_F32 if sdt == torch.float32 else X.T2S_BF16, float(drop_p), int(drop_seed), X.stream())
+    if nres:
+        X.check(X.lib().t2s_add_layernorm_fwd_nres(X.ptr(x), X.ptr(res.z), X.ptr(res.stats), X.ptr(res.gamma), X.ptr(res.beta), *tail),
+                "t2s_add_layernorm_fwd_nres")
+    else:
+        X.check(X.lib().t2s_add_layernorm_fwd(X.ptr(x), X.ptr(res), *tail), "t2s_add_layernorm_fwd")
     return y, y_lo, z, stats
 
 
-def add_layernorm_bwd(dy, z, stats, gamma, out_dtype=None, drop_p=0.0, drop_seed=0):
+def add_layernorm_bwd(dy, z, stats, gamma, out_dtype=None, drop_p=0.0, drop_seed=0, want_bias=False):
     """Returns (dz [out_dtype, default dy.dtype], dzx, dgamma, dbeta); dzx = gradient of the dropped branch input
-    (dz itself when drop_p == 0)."""
+    (dz itself when drop_p == 0).  ``want_bias`` appends dbias [768] fp32 = column sums of dzx: the bias gradient of the
+    dense layer that fed this block, accumulated in the same pass."""
     rows = _rows768(dy)
     assert z.shape == dy.shape and z.is_contiguous() and stats.shape == (rows, 2)
     parts = X.lib().t2s_layernorm_bwd_parts(rows)
     dz = torch.empty(dy.shape, dtype=out_dtype or dy.dtype, device=dy.device)
     dzx = torch.empty_like(dz) if drop_p > 0 else None
-    dgp = torch.empty(parts, HID, dtype=torch.float32, device=dy.device)
-    dbp = torch.empty(parts, HID, dtype=torch.float32, device=dy.device)
-    X.check(X.lib().t2s_add_layernorm_bwd(X.ptr(dy), X.ptr(z), X.ptr(stats), X.ptr(gamma), X.ptr(dz), X.ptr(dzx), X.ptr(dgp),
-                                          X.ptr(dbp), rows, X.dtype_code(dy), X.dtype_code(z), X.dtype_code(dz),
-                                          float(drop_p), int(drop_seed), X.stream()), "t2s_add_layernorm_bwd")
-    return dz, (dzx if dzx is not None else dz), dgp.sum(0), dbp.sum(0)
+    part = torch.empty(3 if want_bias else 2, parts, HID, dtype=torch.float32, device=dy.device)
+    head = (X.ptr(dy), X.ptr(z), X.ptr(stats), X.ptr(gamma), X.ptr(dz), X.ptr(dzx), X.ptr(part[0]), X.ptr(part[1]))
+    tail = (rows, X.dtype_code(dy), X.dtype_code(z), X.dtype_code(dz), float(drop_p), int(drop_seed), X.stream())
+    if want_bias:
+        X.check(X.lib().t2s_add_layernorm_bwd_bias(*head, X.ptr(part[2]), *tail), "t2s_add_layernorm_bwd_bias")
+    else:
+        X.check(X.lib().t2s_add_layernorm_bwd(*head, *tail), "t2s_add_layernorm_bwd")
+    sums = part.sum(1)                          # one reduction launch for all partial-sum tables
+    out = (dz, (dzx if dzx is not None else dz), sums[0], sums[1])
+    return out + (sums[2],) if want_bias else out
 
 
 def dropout_mask(n, drop_p, drop_seed, device):
