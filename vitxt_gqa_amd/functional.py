@@ -12,6 +12,9 @@ only what a flash-style backward needs is kept: the operand copy of the layer in
 attention output, log-sum-exp, the two pre-LayerNorm sums (+ statistics) and the FFN pre-activation.
 LayerNorm outputs and GELU outputs are recomputed in backward (HBM-cheap) instead of stored.
 """
+import contextlib
+import threading
+
 import torch
 
 from . import ops
@@ -32,12 +35,12 @@ def _wgrad(dy2, x2, B):
     """dW[out, in] = dy2[rows, out]^T @ x2[rows, in] with rows = B * L.  The contraction runs over ALL rows (648 k at
     B=64, L=10132) into a tiny output, which the library runs at 0.4-0.8 PFLOP/s as one GEMM; as a batched GEMM per
     sample (contraction L) followed by an fp32 sum over the B partial products it runs at 0.8-1.1 PFLOP/s
-    (tools/wgrad_probe.py), and the partials are summed in fp32 instead of inside a bf16-output GEMM."""
+    (tools/wgrad_probe.py), and the partials are summed in fp32 instead of inside a bf16-output GEMM.  Returns fp32."""
     rows = dy2.size(0)
     if B < 2 or rows // B < 1024 or dy2.dtype == F32:
-        return dy2.t() @ x2
+        return (dy2.t() @ x2).float()
     part = torch.bmm(dy2.view(B, rows // B, -1).transpose(1, 2), x2.view(B, rows // B, -1))     # [B, out, in]
-    return part.sum(0, dtype=F32).to(dy2.dtype)
+    return part.sum(0, dtype=F32)           # fp32: it goes straight into the fp32 gradient of the master weight
 
 
 def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute, materialise=True):
@@ -70,7 +73,7 @@ def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute,
 
 def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p):
     """dy: [B*L, 768] gradient of the layer output (fp32 or the operand dtype).  Returns (dx [B*L, 768] in the operand
-    dtype, the 12 parameter gradients in the order of W).  The bias gradients of the two projections that feed a
+    dtype, the 12 parameter gradients in the order of W, all fp32: they are gradients of the fp32 master parameters).  The bias gradients of the two projections that feed a
     residual+LayerNorm block come out of that block's backward kernel (column sums in the same pass)."""
     xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op = saved
     B, L, _ = qkv.shape
@@ -102,24 +105,73 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p):
     dqkv = ops.attn_bwd(qkv, att, datt, lse, keys, drop_p=attn_drop_p, drop_seed=seeds[2]).view(B * L, 3 * HID)
     del datt
     dw_qkv = _wgrad(dqkv, xl, B)
-    db_qkv = dqkv.sum(0)
+    db_qkv = dqkv.sum(0, dtype=F32)
     dx = torch.addmm(dz1, dqkv, w_qkv)                                   # + residual branch of LN1
-    return dx, (dw_qkv, db_qkv, dw_ao, db_ao.to(dt), dg1, dbe1, dw_i, db_i.to(dt), dw_o, db_o.to(dt), dg2, dbe2)
+    return dx, (dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1, dw_i, db_i, dw_o, db_o, dg2, dbe2)
+
+
+# ---- operand copies of the master parameters.  The autograd functions below take the fp32 MASTER parameters (16 per layer,
+# reference names) and hand back fp32 gradients; the operand-dtype copies the GEMMs read (fused [2304, 768] QKV weight, bf16
+# casts) are made inside forward, so no gradient makes a bf16 round trip or passes through a cast / cat node of the autograd
+# graph.  Inside a ``shared_operands()`` scope (one model forward) the copies are made once per layer and shared by every
+# call on that layer - the three MMT passes of a train step; outside a scope nothing is cached, so a parameter edited
+# between two calls (optimizer step, ``.data`` surgery, load_state_dict) can never meet a stale copy.
+_SCOPE = threading.local()
+MASTERS_PER_LAYER = 16
+
+
+@contextlib.contextmanager
+def shared_operands():
+    prev = getattr(_SCOPE, "cache", None)
+    _SCOPE.cache = {} if prev is None else prev           # nested scopes share the outer one
+    try:
+        yield
+    finally:
+        _SCOPE.cache = prev
+
+
+def layer_masters(lp):
+    """The 16 master parameters of one BERT layer (module tree of t2s.BertLayerParams), in the order the functions expect."""
+    a, so = lp.attention.self, lp.attention.output
+    return (a.query.weight, a.key.weight, a.value.weight, a.query.bias, a.key.bias, a.value.bias,
+            so.dense.weight, so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias,
+            lp.intermediate.dense.weight, lp.intermediate.dense.bias,
+            lp.output.dense.weight, lp.output.dense.bias, lp.output.LayerNorm.weight, lp.output.LayerNorm.bias)
+
+
+@torch.no_grad()
+def operand_weights(m, dtype):
+    """16 masters -> the 12-tuple W of _layer_forward in ``dtype`` (LayerNorm affine stays fp32)."""
+    cache = getattr(_SCOPE, "cache", None)
+    key = (id(m[0]), dtype)
+    if cache is not None and key in cache:
+        return cache[key][1]
+    wq, wk, wv, bq, bk, bv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2 = m
+    c = (lambda t: t.detach().to(dtype))
+    W = (torch.cat([wq, wk, wv], 0).to(dtype), torch.cat([bq, bk, bv], 0).to(dtype), c(w_ao), c(b_ao), g1.detach(), be1.detach(),
+         c(w_i), c(b_i), c(w_o), c(b_o), g2.detach(), be2.detach())
+    if cache is not None:
+        cache[key] = (m[0], W)                            # holding m[0] keeps its id() from being reused inside the scope
+    return W
+
+
+def _master_grads(g):
+    """12 gradients in the order of W -> 16 in the order of the masters (views of the fused QKV gradients)."""
+    dw_qkv, db_qkv = g[0], g[1]
+    return (dw_qkv[:HID], dw_qkv[HID:2 * HID], dw_qkv[2 * HID:], db_qkv[:HID], db_qkv[HID:2 * HID], db_qkv[2 * HID:]) + tuple(g[2:])
 
 
 class BertLayerFn(torch.autograd.Function):
     """(y, y_lo) = BertLayer(x; keys).  x / y: fp32 residual stream; x_lo / y_lo: operand-dtype copies
-    (y_lo is y itself in fp32 mode).  Weights arrive in the operand dtype; LayerNorm affine stays fp32."""
+    (y_lo is y itself in fp32 mode).  ``masters``: the layer's 16 fp32 parameters (layer_masters)."""
 
     @staticmethod
-    def forward(ctx, x, x_lo, keys, w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2, drop_p=0.0, seeds=(0, 0, 0),
-                attn_drop_p=0.0):
+    def forward(ctx, x, x_lo, keys, dt, drop_p, seeds, attn_drop_p, *masters):
         B, L, _ = x.shape
-        dt = w_qkv.dtype
+        W = operand_weights(masters, dt)
         x2 = x.contiguous().view(B * L, HID)
         xl = (x_lo if x_lo is not None else x.to(dt)).contiguous().view(B * L, HID)
-        y2, y2_lo, saved = _layer_forward(x2, xl, keys, B, L, (w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2),
-                                          drop_p, seeds, attn_drop_p, RECOMPUTE_ACTIVATIONS)
+        y2, y2_lo, saved = _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, RECOMPUTE_ACTIVATIONS)
         ctx.keys = keys
         ctx.drop = (drop_p, seeds, attn_drop_p)
         ctx.save_for_backward(*saved)
@@ -133,7 +185,7 @@ class BertLayerFn(torch.autograd.Function):
         B, L, _ = dy.shape
         drop_p, seeds, attn_drop_p = ctx.drop
         dx, g = _layer_backward(ctx.saved_tensors, ctx.keys, dy.contiguous().view(B * L, HID), drop_p, seeds, attn_drop_p)
-        return (dx.view(B, L, HID), None, None) + g + (None, None, None)
+        return (dx.view(B, L, HID).float(), None, None, None, None, None, None) + _master_grads(g)
 
 
 class BertEncoderFn(torch.autograd.Function):
@@ -143,9 +195,11 @@ class BertEncoderFn(torch.autograd.Function):
     next kernel to read it back.  Same values either way."""
 
     @staticmethod
-    def forward(ctx, x, keys, n_layers, drop_p, seeds, attn_drop_p, *flat_w):
+    def forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, *masters):
         B, L, _ = x.shape
-        dt = flat_w[0].dtype
+        flat_w = []
+        for l in range(n_layers):
+            flat_w.extend(operand_weights(masters[MASTERS_PER_LAYER * l:MASTERS_PER_LAYER * (l + 1)], dt))
         x2 = x.contiguous().view(B * L, HID)
         xl = x2.to(dt) if dt != F32 else x2
         keep, counts = [], []
@@ -176,9 +230,9 @@ class BertEncoderFn(torch.autograd.Function):
         for l in reversed(range(len(per_layer))):
             d, grads[l] = _layer_backward(per_layer[l], ctx.keys, d, drop_p, seeds[l], attn_drop_p)
             per_layer[l] = None
-        out = (d.view(B, L, HID).float(), None, None, None, None, None)
+        out = (d.view(B, L, HID).float(), None, None, None, None, None, None)
         for g in grads:
-            out += g
+            out += _master_grads(g)
         return out
 
 
@@ -285,30 +339,20 @@ def bert_layer(x, x_lo, keys, lp, dtype, hidden_dropout=0.0, attn_dropout=0.0):
     hidden_dropout: p of the dropout after the attention-output and FFN-output dense layers (training only);
     attn_dropout: p of the attention-probability dropout.
     Returns (y fp32, y_lo operand dtype)."""
-    att = lp.attention
-    w_qkv = torch.cat([att.self.query.weight, att.self.key.weight, att.self.value.weight], 0).to(dtype)
-    b_qkv = torch.cat([att.self.query.bias, att.self.key.bias, att.self.value.bias], 0).to(dtype)
-    return BertLayerFn.apply(
-        x, x_lo, keys, w_qkv, b_qkv,
-        att.output.dense.weight.to(dtype), att.output.dense.bias.to(dtype),
-        att.output.LayerNorm.weight, att.output.LayerNorm.bias,
-        lp.intermediate.dense.weight.to(dtype), lp.intermediate.dense.bias.to(dtype),
-        lp.output.dense.weight.to(dtype), lp.output.dense.bias.to(dtype),
-        lp.output.LayerNorm.weight, lp.output.LayerNorm.bias,
-        float(hidden_dropout),
-        (_fresh_seed(), _fresh_seed(), _fresh_seed()) if (hidden_dropout > 0 or attn_dropout > 0) else (0, 0, 0),
-        float(attn_dropout))
+    drop = hidden_dropout > 0 or attn_dropout > 0
+    seeds = (_fresh_seed(), _fresh_seed(), _fresh_seed()) if drop else (0, 0, 0)
+    return BertLayerFn.apply(x, x_lo, keys, dtype, float(hidden_dropout), seeds, float(attn_dropout), *layer_masters(lp))
 
 
 def bert_encoder(x, keys, layers, dtype, hidden_dropout=0.0, attn_dropout=0.0):
     """x: fp32 [B, L, 768] -> fp32.  The whole stack is one autograd node (BertEncoderFn)."""
     layers = list(layers)
-    flat = []
+    masters = []
     for lp in layers:
-        flat.extend(_layer_weights(lp, dtype))
+        masters.extend(layer_masters(lp))
     drop = hidden_dropout > 0 or attn_dropout > 0
     seeds = tuple((_fresh_seed(), _fresh_seed(), _fresh_seed()) if drop else (0, 0, 0) for _ in layers)
-    return BertEncoderFn.apply(x, keys, len(layers), float(hidden_dropout), seeds, float(attn_dropout), *flat)
+    return BertEncoderFn.apply(x, keys, len(layers), dtype, float(hidden_dropout), seeds, float(attn_dropout), *masters)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -318,14 +362,7 @@ def bert_encoder(x, keys, layers, dtype, hidden_dropout=0.0, attn_dropout=0.0):
 # runs the full sequence once and keeps each layer's fused QKV buffer; later steps recompute only the 12
 # decoder rows against the cached K/V (the reference recomputes the whole [L2 x L2] pass 12 times).
 def _layer_weights(lp, dtype):
-    att = lp.attention
-    return (torch.cat([att.self.query.weight, att.self.key.weight, att.self.value.weight], 0).to(dtype),
-            torch.cat([att.self.query.bias, att.self.key.bias, att.self.value.bias], 0).to(dtype),
-            att.output.dense.weight.to(dtype), att.output.dense.bias.to(dtype),
-            att.output.LayerNorm.weight, att.output.LayerNorm.bias,
-            lp.intermediate.dense.weight.to(dtype), lp.intermediate.dense.bias.to(dtype),
-            lp.output.dense.weight.to(dtype), lp.output.dense.bias.to(dtype),
-            lp.output.LayerNorm.weight, lp.output.LayerNorm.bias)
+    return operand_weights(layer_masters(lp), dtype)
 
 
 def _layer_tail(att2, res32, w, dtype):

@@ -382,12 +382,13 @@ class T2S(BaseModel):
     def forward(self, sample_list):
         dt = self.compute_dtype
         fwd = {}
-        self._forward_txt_encoding(sample_list, fwd, dt)
-        self._forward_obj_encoding(sample_list, fwd, dt)
-        self._forward_ocr_encoding(sample_list, fwd, dt)
-        self.TransLayer(fwd, dt)
-        self.Grounding_Module(sample_list, fwd)
-        self._forward_mmt_and_output(sample_list, fwd, dt)
+        with FN.shared_operands():          # one set of operand-dtype weight copies per layer for the whole forward (3 MMT passes)
+            self._forward_txt_encoding(sample_list, fwd, dt)
+            self._forward_obj_encoding(sample_list, fwd, dt)
+            self._forward_ocr_encoding(sample_list, fwd, dt)
+            self.TransLayer(fwd, dt)
+            self.Grounding_Module(sample_list, fwd)
+            self._forward_mmt_and_output(sample_list, fwd, dt)
         self._last_fwd = fwd
         return {"ref_scores": fwd["ref_scores"], "pos_scores": fwd["pos_scores"], "neg_scores": fwd["neg_scores"],
                 "ground_box": fwd["ground_bbox"], "ground_frame": fwd["ground_frame"],
