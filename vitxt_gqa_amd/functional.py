@@ -329,6 +329,37 @@ def ptr_logits(fixed, q, k, mask01):
     return PtrLogitsFn.apply(fixed, q, k, mask01)
 
 
+class SplitRowsFn(torch.autograd.Function):
+    """(x[:, a:b], x[:, b:]) of a [B, L, 768] encoder output (the OCR rows and the decoder rows of an MMT pass,
+    t2s.py:628-631).  As two plain slices autograd builds the input gradient as zeros + copy, zeros + copy, add (three
+    passes over a 2 GB tensor per MMT pass at B=64); here it is ONE buffer written once."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        ctx.a, ctx.b, ctx.shape = a, b, x.shape
+        return x[:, a:b], x[:, b:]
+
+    @staticmethod
+    def backward(ctx, g_mid, g_tail):
+        a, b = ctx.a, ctx.b
+        ref = g_mid if g_mid is not None else g_tail
+        g = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        g[:, :a].zero_()
+        if g_mid is not None:
+            g[:, a:b].copy_(g_mid)
+        else:
+            g[:, a:b].zero_()
+        if g_tail is not None:
+            g[:, b:].copy_(g_tail)
+        else:
+            g[:, b:].zero_()
+        return g, None, None
+
+
+def split_rows(x, a, b):
+    return SplitRowsFn.apply(x, a, b)
+
+
 def _fresh_seed():
     """64-bit seed from torch's CPU generator (follows torch.manual_seed; no device sync)."""
     return int(torch.randint(0, 2 ** 62, (1,)).item())

@@ -265,7 +265,7 @@ class MMT(nn.Module):
         # decoder keys: step j visible to decoder row i iff i >= j; prefix rows never see them (t2s.py:574-618)
         keys = ops.compact_keys(valid, n_dec=D, dec_row0=L1, cap_hint=max_keys)
         out = FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd, pa)
-        return out[:, T + Fn:L1], out[:, L1:]
+        return FN.split_rows(out, T + Fn, L1)
 
     def forward_passes(self, txt_emb, txt_mask, obj_emb, obj_masks, ocr_emb, ocr_masks, fixed_ans_emb, prev_inds, dtype):
         """The reference's three MMT calls of one train step (ref / pos / neg masks, t2s.py:293-313) as ONE encoder call on
