@@ -21,7 +21,6 @@ namespace {
 
 constexpr int BK = 64;
 constexpr int TILE64 = 64 * 128;    // bytes of a 64-row bf16 tile
-constexpr int TILE32 = 32 * 128;    // bytes of a 32-row bf16 tile
 
 // ---------------------------------------------------------------------------------------------
 // delta[b, h, q] = sum_d dO[b, q, h, d] * O[b, q, h, d].  One wave per token row (768 elements).

@@ -25,15 +25,24 @@ constexpr int QROWS = 64;                         // query rows per iteration
 constexpr int TILE = QROWS * 128;                 // bytes of a 64-row bf16 tile
 constexpr int STAGE = 2 * TILE + 2 * QROWS * 4 + (QROWS / 2) * 4;   // Q | dO | -lse | -delta | dropout row keys
 
-template <bool USE_IDX, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
+// NW = waves per workgroup (4 or 8): a workgroup owns 32 * NW keys and its waves share every staged Q / dO tile, so with
+// NW = 8 each thread stages half as much per MFMA (one row chunk of Q and of dO per tile instead of two) and the tiles are
+// fetched from L2 half as often; occupancy is the same two waves per SIMD (one 8-wave workgroup per CU instead of two
+// 4-wave ones).
+#ifndef T2S_DKDV_NW
+#define T2S_DKDV_NW 4
+#endif
+template <bool USE_IDX, bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  constexpr int KEYS = 32 * NW;                    // keys per workgroup
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   int kblk, h, b;
   if (!attn_xcd_tile(p.kblocks, p.H, p.B, kblk, h, b)) return;                    // workgroup-uniform (attn_common.h)
   const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
   const int nk = n_prefix + p.n_dec;
-  const int kp0 = kblk * 128;
+  const int kp0 = kblk * KEYS;
   if (kp0 >= nk) return;                                   // uniform per workgroup
   const int kpos = kp0 + wave * 32 + lr;                   // this lane's key position (column)
   const bool kvalid = kpos < nk;
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) kf[s][j] = (bf16_t)((float)kf[s][j] * c);
   const int nqt = (p.Lq + QROWS - 1) / QROWS;
-  const bool edge_wg = (kp0 + 128 > n_prefix);      // this workgroup holds decoder keys or the end of the list
+  const bool edge_wg = (kp0 + KEYS > n_prefix);      // this workgroup holds decoder keys or the end of the list
 
   // staging: thread -> rows sr / sr+32, 16-B chunk sc of the Q and dO tiles; plain named registers and
   // unconditional clamped loads (keeps the staging out of scratch memory)
@@ -86,10 +95,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
     const int c0_ = r0_ < p.Lq ? r0_ : p.Lq - 1, c1_ = r1_ < p.Lq ? r1_ : p.Lq - 1;             \
     q0r = *reinterpret_cast<const uint4*>(Q + (int64_t)c0_ * p.q_rs + sc * 8);                  \
     d0r = *reinterpret_cast<const uint4*>(DO + (int64_t)c0_ * p.o_rs + sc * 8);                 \
-    q1r = *reinterpret_cast<const uint4*>(Q + (int64_t)c1_ * p.q_rs + sc * 8);                  \
-    d1r = *reinterpret_cast<const uint4*>(DO + (int64_t)c1_ * p.o_rs + sc * 8);                 \
     if (r0_ >= p.Lq) d0r = make_uint4(0, 0, 0, 0);                                              \
-    if (r1_ >= p.Lq) d1r = make_uint4(0, 0, 0, 0);                                              \
+    if (NW == 4) {      /* 256 threads: a second row per thread */                              \
+      q1r = *reinterpret_cast<const uint4*>(Q + (int64_t)c1_ * p.q_rs + sc * 8);                \
+      d1r = *reinterpret_cast<const uint4*>(DO + (int64_t)c1_ * p.o_rs + sc * 8);               \
+      if (r1_ >= p.Lq) d1r = make_uint4(0, 0, 0, 0);                                            \
+    }                                                                                           \
     const int r2_ = (qt_) * QROWS + lrow;                                                       \
     const int r2c_ = r2_ < p.Lq ? r2_ : p.Lq - 1;                                               \
     const float l_ = LSE[r2c_] * LOG2E, dl_ = DELTA[r2c_];                                      \
@@ -105,8 +116,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
     char* base_ = smem + (buf_) * STAGE;                                                        \
     *reinterpret_cast<uint4*>(base_ + tile_off(sr, sc)) = q0r;                                  \
     *reinterpret_cast<uint4*>(base_ + TILE + tile_off(sr, sc)) = d0r;                           \
-    *reinterpret_cast<uint4*>(base_ + tile_off(sr + 32, sc)) = q1r;                             \
-    *reinterpret_cast<uint4*>(base_ + TILE + tile_off(sr + 32, sc)) = d1r;                      \
+    if (NW == 4) {                                                                              \
+      *reinterpret_cast<uint4*>(base_ + tile_off(sr + 32, sc)) = q1r;                           \
+      *reinterpret_cast<uint4*>(base_ + TILE + tile_off(sr + 32, sc)) = d1r;                    \
+    }                                                                                           \
     if (tid < QROWS) {                                                                          \
       reinterpret_cast<float*>(base_ + 2 * TILE)[tid] = lreg;                                   \
       reinterpret_cast<float*>(base_ + 2 * TILE + QROWS * 4)[tid] = dreg;                       \
@@ -160,14 +173,15 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
 }  // namespace
 
 void launch_attn_dkdv_bf16(const AttnParams& p_in, int max_keys, hipStream_t st) {
+  constexpr int NW = T2S_DKDV_NW;
   AttnParams p = p_in;
-  p.kblocks = (max_keys + 127) / 128;
-  dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256);      // XCD-aware 1-D grid (attn_common.h)
+  p.kblocks = (max_keys + 32 * NW - 1) / (32 * NW);
+  dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(64 * NW);      // XCD-aware 1-D grid (attn_common.h)
   if (p.drop_thresh) {
-    if (p.kv_idx) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, true>), grid, block, 0, st, p);
+    if (p.kv_idx) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, true, NW>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, true, NW>), grid, block, 0, st, p);
   } else {
-    if (p.kv_idx) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, false>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, false>), grid, block, 0, st, p);
+    if (p.kv_idx) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, false, NW>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, false, NW>), grid, block, 0, st, p);
   }
 }
