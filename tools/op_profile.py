@@ -38,8 +38,21 @@ def step():
 
 step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=40,
                                                          max_shapes_column_width=70))
+
+# where the big copies / adds / fills come from: python stacks of the ops on [B, ~N, 768]-sized operands
+big = {}
+for e in prof.events():
+    if e.name in ("aten::copy_", "aten::add_", "aten::add", "aten::fill_", "aten::cat", "aten::_to_copy", "aten::mul", "aten::tanh") and e.device_time_total > 200:
+        st = [f for f in (e.stack or []) if "vitxt_gqa_amd" in f or "bench" in f or "op_profile" in f][:3]
+        key = (e.name, str(e.input_shapes)[:60], " <- ".join(s.split("/")[-1] for s in st))
+        t = big.setdefault(key, [0, 0.0])
+        t[0] += 1
+        t[1] += e.device_time_total
+print("\nbig glue ops by call site (count, device ms):")
+for k, (n, t) in sorted(big.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("%3d %8.2f ms  %-12s %-60s %s" % (n, t / 1e3, k[0], k[1], k[2]))

@@ -93,7 +93,7 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p):
         y1_op = y1_lo if lo else y1
         del y1, y1_lo
     dw_i = _wgrad(du, y1_op, B)
-    dy1 = torch.addmm(dz2, du, w_i)                                      # + residual branch of LN2
+    dy1 = dz2.addmm_(du, w_i)          # + residual branch of LN2, accumulated IN PLACE (out-of-place addmm first copies C)
     del du, y1_op, dz2
     # ---- attention output LayerNorm + projection
     dz1, dz1x, dg1, dbe1, db_ao = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[0], want_bias=True)
@@ -106,7 +106,7 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p):
     del datt
     dw_qkv = _wgrad(dqkv, xl, B)
     db_qkv = dqkv.sum(0, dtype=F32)
-    dx = torch.addmm(dz1, dqkv, w_qkv)                                   # + residual branch of LN1
+    dx = dz1.addmm_(dqkv, w_qkv)                                         # + residual branch of LN1 (in place, as above)
     return dx, (dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1, dw_i, db_i, dw_o, db_o, dg2, dbe2)
 
 
