@@ -89,6 +89,18 @@ int t2s_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
                  int64_t o_row_stride, int64_t o_batch_stride,
                  float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws,
                  t2s_stream_t stream);
+/* The same for the self-attention layout (Lq == idx_cap: query rows = prefix rows + decoder rows; bf16), with
+ * the zero-fill done here: row_valid [B, idx_cap - n_dec] bytes is the mask the key list was compacted from
+ * (t2s_compact_keys' input); the dQ kernel, which visits every (row, head) anyway, writes the zero dK / dV
+ * slices of the rows no list entry points at, so dq/dk/dv may be uninitialised memory on entry. */
+int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                      const float* lse, float* delta, void* dq, void* dk, void* dv,
+                      const int32_t* kv_idx, const int32_t* kv_cnt, const uint8_t* row_valid,
+                      int B, int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys,
+                      int64_t q_row_stride, int64_t q_batch_stride,
+                      int64_t kv_row_stride, int64_t kv_batch_stride,
+                      int64_t o_row_stride, int64_t o_batch_stride,
+                      float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 
 /* ---- residual + LayerNorm (BertSelfOutput / BertOutput / BertLayerNorm; also
  * t2s.py:87-88,116-117,685-687): z = x + res (res may be NULL); y = (z-mean)/sqrt(var+eps)*g+b,

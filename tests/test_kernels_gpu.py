@@ -267,3 +267,32 @@ def test_add_layernorm_normalised_residual_and_bias_sums(rows, drop_p):
     assert torch.equal(dz, dz2) and torch.equal(dzx, dzx2) and torch.allclose(dg, dg2) and torch.allclose(db, db2)
     ref = dzx.double().sum(0)
     assert (dbias.double() - ref).abs().max().item() < 2e-3 * (1 + ref.abs().max().item()) + 4e-3 * rows ** 0.5   # ref sums bf16-ROUNDED values
+
+
+@pytest.mark.parametrize("keep,drop_p", [(0.6, 0.0), (0.05, 0.1), (1.0, 0.0)])
+def test_attention_bwd_fills_unlisted_rows_in_kernel(keep, drop_p):
+    """t2s_attn_bwd_fill (the dQ kernel writes the zero dK / dV rows of keys that are in no list) against t2s_attn_bwd on a
+    zero-filled buffer: bit-equal, and no element of the uninitialised buffer survives."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    torch.manual_seed(3)
+    B, L1, n_dec = 3, 700, 12
+    L = L1 + n_dec
+    qkv = torch.randn(B, L, 2304, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, device=DEV).to(torch.bfloat16)
+    valid = torch.rand(B, L1, device=DEV) < keep
+    valid[:, 5] = True
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
+    assert keys.valid8 is not None
+    kw = dict(drop_p=drop_p, drop_seed=17) if drop_p else {}
+    out, lse = ops.attn_fwd(qkv, keys, **kw)
+    # poison the allocator's free list so that a missed row shows up as NaN
+    junk = torch.full((B, L, 2304), float("nan"), device=DEV, dtype=torch.bfloat16)
+    del junk
+    a = ops.attn_bwd(qkv, out, dout, lse, keys, **kw)
+    plain = ops.KeyList(keys.idx, keys.cnt, keys.n_dec, keys.dec_q0, keys.cap_hint, None)
+    b = ops.attn_bwd(qkv, out, dout, lse, plain, **kw)
+    assert torch.isfinite(a.float()).all()
+    assert torch.equal(a, b)
+    unlisted = ~valid
+    assert a[:, :L1, 768:][unlisted].abs().max().item() == 0.0 if unlisted.any() else True

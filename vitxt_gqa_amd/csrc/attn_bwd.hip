@@ -269,11 +269,20 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
     }
   __syncthreads();
   bf16_t* __restrict__ DQ = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.q_bs + h * 64;
+  bf16_t* __restrict__ DK = reinterpret_cast<bf16_t*>(p.dk) + (int64_t)b * p.kv_bs + h * 64;
+  bf16_t* __restrict__ DV = reinterpret_cast<bf16_t*>(p.dv) + (int64_t)b * p.kv_bs + h * 64;
+  const uint8_t* __restrict__ rv = p.row_valid ? p.row_valid + (int64_t)b * p.valid_len : nullptr;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int id = i * 64 + lane, r = id >> 3, cc = id & 7;
-    if (q0 + r < p.Lq)
-      *reinterpret_cast<uint4*>(DQ + (int64_t)(q0 + r) * p.q_rs + cc * 8) = *reinterpret_cast<const uint4*>(ob + r * 144 + cc * 16);
+    const int row = q0 + r;
+    if (row < p.Lq) {
+      *reinterpret_cast<uint4*>(DQ + (int64_t)row * p.q_rs + cc * 8) = *reinterpret_cast<const uint4*>(ob + r * 144 + cc * 16);
+      if (rv && row < p.valid_len && !rv[row]) {           // a row no key list entry points at: its dK / dV are exact zeros
+        *reinterpret_cast<uint4*>(DK + (int64_t)row * p.kv_rs + cc * 8) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(DV + (int64_t)row * p.kv_rs + cc * 8) = make_uint4(0, 0, 0, 0);
+      }
+    }
   }
 }
 
@@ -494,11 +503,12 @@ __global__ __launch_bounds__(256, 2) void attn_dq_f32_kernel(AttnParams p) {
 
 }  // namespace
 
-extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
-                            float* delta, void* dq, void* dk, void* dv, const int32_t* kv_idx, const int32_t* kv_cnt, int B,
-                            int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys, int64_t q_row_stride, int64_t q_batch_stride,
-                            int64_t kv_row_stride, int64_t kv_batch_stride, int64_t o_row_stride, int64_t o_batch_stride,
-                            float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, t2s_stream_t stream) {
+static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                         float* delta, void* dq, void* dk, void* dv, const int32_t* kv_idx, const int32_t* kv_cnt, int B,
+                         int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys, int64_t q_row_stride, int64_t q_batch_stride,
+                         int64_t kv_row_stride, int64_t kv_batch_stride, int64_t o_row_stride, int64_t o_batch_stride,
+                         float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, const uint8_t* row_valid,
+                         t2s_stream_t stream) {
   T2S_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
   T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "attn_bwd: bad dtype %d", dtype);
   T2S_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && idx_cap > 0 && n_dec >= 0 && n_dec <= idx_cap, "attn_bwd: bad shape");
@@ -514,6 +524,7 @@ extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const v
   p.B = B; p.H = H; p.Lq = Lq; p.idx_cap = idx_cap; p.n_dec = n_dec; p.dec_q0 = dec_q0;
   p.q_rs = q_row_stride; p.q_bs = q_batch_stride; p.kv_rs = kv_row_stride; p.kv_bs = kv_batch_stride;
   p.o_rs = o_row_stride; p.o_bs = o_batch_stride; p.scale = scale;
+  p.row_valid = row_valid; p.valid_len = idx_cap - n_dec;
   hipStream_t st = (hipStream_t)stream;
   (void)drop_ws;
   if (int e = attn_setup_dropout(p, drop_p, drop_seed, st, "attn_bwd")) return e;
@@ -543,4 +554,28 @@ extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const v
   }
   T2S_CHECK_LAUNCH("attn_bwd");
   return 0;
+}
+
+extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                            float* delta, void* dq, void* dk, void* dv, const int32_t* kv_idx, const int32_t* kv_cnt, int B,
+                            int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys, int64_t q_row_stride, int64_t q_batch_stride,
+                            int64_t kv_row_stride, int64_t kv_batch_stride, int64_t o_row_stride, int64_t o_batch_stride,
+                            float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, t2s_stream_t stream) {
+  return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
+                       q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed, drop_ws,
+                       nullptr, stream);
+}
+
+extern "C" int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                                 float* delta, void* dq, void* dk, void* dv, const int32_t* kv_idx, const int32_t* kv_cnt,
+                                 const uint8_t* row_valid, int B, int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys,
+                                 int64_t q_row_stride, int64_t q_batch_stride, int64_t kv_row_stride, int64_t kv_batch_stride,
+                                 int64_t o_row_stride, int64_t o_batch_stride, float scale, int dtype, float drop_p,
+                                 uint64_t drop_seed, t2s_stream_t stream) {
+  T2S_CHECK_ARG(row_valid && kv_idx, "attn_bwd_fill: row_valid and the key list are required");
+  T2S_CHECK_ARG(dtype == T2S_BF16, "attn_bwd_fill: bf16 only (the fp32 kernels leave unlisted rows to the caller)");
+  T2S_CHECK_ARG(Lq == idx_cap, "attn_bwd_fill: self-attention layout expected (query rows = prefix rows + decoder rows)");
+  return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
+                       q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed, nullptr,
+                       row_valid, stream);
 }

@@ -24,6 +24,11 @@ struct AttnParams {
   uint32_t drop_seed_lo, drop_seed_hi;
   uint32_t drop_thresh;          // drop iff byte < thresh, thresh = round(p * 256)
   float drop_inv;                // 1 / (1 - thresh/256)
+  // backward, optional: row_valid [B, valid_len] bytes, 0 = the prefix row is NOT in the key list.  The dQ kernel, which
+  // visits every (row, head) anyway, then writes the zeros of that row's dK / dV slices, so the caller need not zero-fill
+  // the gradient buffer (rows >= valid_len, the decoder rows, are always listed)
+  const uint8_t* row_valid;
+  int valid_len;
 };
 
 // ---- attention-probability dropout.  keep(q, kpos) is a stateless function of (seed, sample, head, q, kpos) so that

@@ -22,8 +22,9 @@ def _rows768(t):
 class KeyList:
     """Compacted visible-key list of a batch (replaces the [B,1,L,L] additive mask, t2s.py:413-419,609-618)."""
 
-    def __init__(self, idx, cnt, n_dec, dec_q0, cap_hint=None):
+    def __init__(self, idx, cnt, n_dec, dec_q0, cap_hint=None, valid8=None):
         self.idx, self.cnt, self.n_dec, self.dec_q0 = idx, cnt, n_dec, dec_q0
+        self.valid8 = valid8        # [B, L] uint8 mask the list was compacted from (lets the backward skip its zero fill)
         # static upper bound on (#valid prefix keys + n_dec): lets the dK/dV grid skip empty key blocks
         self.cap_hint = cap_hint if cap_hint is not None else idx.shape[1]
 
@@ -40,7 +41,7 @@ def compact_keys(valid, n_dec=0, dec_row0=0, cap_hint=None):
             "t2s_compact_keys")
     if cap_hint is not None:
         cap_hint = min(cap, cap_hint)
-    return KeyList(idx, cnt, n_dec, dec_row0, cap_hint)
+    return KeyList(idx, cnt, n_dec, dec_row0, cap_hint, v8)
 
 
 def _attn_views(qkv):
@@ -85,17 +86,22 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     assert out.is_contiguous() and dout.is_contiguous() and out.shape == (B, L, HID) and dout.shape == (B, L, HID)
     assert lse.shape == (B, HEADS, L) and lse.is_contiguous()
     _check_keys(keys, B, L)
-    dqkv = torch.zeros_like(qkv)
+    cap = keys.idx.shape[1]
+    fill_in_kernel = qkv.dtype == torch.bfloat16 and keys.valid8 is not None and cap == L and keys.valid8.shape == (B, L - keys.n_dec)
+    # rows outside the key list have exactly zero dK / dV: written by the dQ kernel when it is handed the mask (bf16 path),
+    # otherwise by a zero fill of the whole buffer (3 GB at B=64) before the launch
+    dqkv = torch.empty_like(qkv) if fill_in_kernel else torch.zeros_like(qkv)
     dq, dk, dv = _attn_views(dqkv)
     delta = torch.empty_like(lse)
-    cap = keys.idx.shape[1]
-    X.check(X.lib().t2s_attn_bwd(
-        X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(dout), X.ptr(lse), X.ptr(delta),
-        X.ptr(dq), X.ptr(dk), X.ptr(dv), X.ptr(keys.idx), X.ptr(keys.cnt),
-        B, HEADS, L, cap, keys.n_dec, keys.dec_q0, keys.cap_hint,
-        qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
-        scale, X.dtype_code(qkv), float(drop_p), int(drop_seed), X.ptr(_drop_ws(B, L, drop_p, qkv.device)), X.stream()),
-        "t2s_attn_bwd")
+    head = (X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(dout), X.ptr(lse), X.ptr(delta),
+            X.ptr(dq), X.ptr(dk), X.ptr(dv), X.ptr(keys.idx), X.ptr(keys.cnt))
+    dims = (B, HEADS, L, cap, keys.n_dec, keys.dec_q0, keys.cap_hint,
+            qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
+            scale, X.dtype_code(qkv), float(drop_p), int(drop_seed))
+    if fill_in_kernel:
+        X.check(X.lib().t2s_attn_bwd_fill(*head, X.ptr(keys.valid8), *dims, X.stream()), "t2s_attn_bwd_fill")
+    else:
+        X.check(X.lib().t2s_attn_bwd(*head, *dims, X.ptr(_drop_ws(B, L, drop_p, qkv.device)), X.stream()), "t2s_attn_bwd")
     return dqkv
 
 
