@@ -518,6 +518,11 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
                     kv_batch_stride % al == 0 && o_batch_stride % al == 0, "attn_bwd: strides must be multiples of 16 bytes");
   T2S_CHECK_ARG(B <= 65535 && H <= 65535, "attn_bwd: B/H exceed grid limits");
   T2S_CHECK_ARG(max_keys > 0 && max_keys <= idx_cap, "attn_bwd: max_keys %d outside (0, idx_cap=%d]", max_keys, idx_cap);
+  {   // the bf16 kernels address a sample's rows with 32-bit byte offsets from a per-sample base
+    const int64_t widest = q_row_stride > o_row_stride ? (q_row_stride > kv_row_stride ? q_row_stride : kv_row_stride)
+                                                       : (o_row_stride > kv_row_stride ? o_row_stride : kv_row_stride);
+    T2S_CHECK_ARG(dtype != T2S_BF16 || ((int64_t)Lq + 128) * widest * 2 < ((int64_t)1 << 32), "attn_bwd: a sample's rows must span < 4 GB");
+  }
   AttnParams p = {};
   p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta;
   p.dq = dq; p.dk = dk; p.dv = dv; p.kv_idx = kv_idx; p.kv_cnt = kv_cnt;

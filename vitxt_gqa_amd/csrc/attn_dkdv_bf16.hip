@@ -77,39 +77,51 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_dkdv_bf16_kernel(AttnParams p
   const int nqt = (p.Lq + QROWS - 1) / QROWS;
   const bool edge_wg = (kp0 + KEYS > n_prefix);      // this workgroup holds decoder keys or the end of the list
 
-  // staging: thread -> rows sr / sr+32, 16-B chunk sc of the Q and dO tiles; plain named registers and
-  // unconditional clamped loads (keeps the staging out of scratch memory)
+  // staging: thread -> rows sr / sr+32, 16-B chunk sc of the Q and dO tiles; plain named registers and unconditional
+  // clamped loads (keeps the staging out of scratch memory).  Addresses are a workgroup-uniform 64-bit base plus a 32-bit
+  // per-thread byte offset that ADVANCES by a uniform step per tile (the first form of this macro recomputed
+  // row * stride in 64 bits for every load: 8 v_mul_lo_u32 + 4 v_mad_u64_u32 + 6 v_lshl_add_u64 per tile, all multi-pass
+  // instructions, ~13 % of the kernel); rows past Lq clamp to the last row by a v_min on the offset and get P = 0 through
+  // lse = -inf, so their (finite) Q / dO values never reach a sum.  A sample's rows span < 4 GB (checked by the host).
   const int sr = tid >> 3, sc = tid & 7;
   const int lrow = tid & 63;
   uint4 q0r, q1r, d0r, d1r;
   float lreg, dreg;
   uint32_t rkreg = 0;
+  const char* __restrict__ Qb = reinterpret_cast<const char*>(Q);
+  const char* __restrict__ DOb = reinterpret_cast<const char*>(DO);
+  const uint32_t q_step = (uint32_t)(QROWS * p.q_rs * 2), o_step = (uint32_t)(QROWS * p.o_rs * 2);       // bytes per tile
+  const uint32_t q_max = (uint32_t)((p.Lq - 1) * p.q_rs * 2) + (uint32_t)sc * 16u, o_max = (uint32_t)((p.Lq - 1) * p.o_rs * 2) + (uint32_t)sc * 16u;
+  uint32_t qo0 = (uint32_t)(sr * p.q_rs * 2) + (uint32_t)sc * 16u, oo0 = (uint32_t)(sr * p.o_rs * 2) + (uint32_t)sc * 16u;
+  uint32_t qo1 = qo0 + (uint32_t)(32 * p.q_rs * 2), oo1 = oo0 + (uint32_t)(32 * p.o_rs * 2);
+  int ld_row = lrow;            // query row whose lse / delta this thread fetches for the tile being loaded
+  int ld_row0 = 0;              // first query row of that tile (uniform)
   // dropout (attn_common.h): this lane's column key in both 16-bit halves; the row keys of the tile's 32 query pairs
   // are hashed by threads 0..31 while the tile is staged
   const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
   const uint32_t ck2 = DROP ? attn_drop_colkey16(salt, kpos) * 0x10001u : 0u;
   const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
-#define STAGE_LOAD(qt_)                                                                         \
+  // loads the NEXT tile in sequence (tile 0 first; past the last tile: clamped copies of the last row, harmless)
+#define STAGE_LOAD(qt_unused_)                                                                  \
   {                                                                                             \
-    const int r0_ = (qt_) * QROWS + sr, r1_ = r0_ + 32;                                         \
-    const int c0_ = r0_ < p.Lq ? r0_ : p.Lq - 1, c1_ = r1_ < p.Lq ? r1_ : p.Lq - 1;             \
-    q0r = *reinterpret_cast<const uint4*>(Q + (int64_t)c0_ * p.q_rs + sc * 8);                  \
-    d0r = *reinterpret_cast<const uint4*>(DO + (int64_t)c0_ * p.o_rs + sc * 8);                 \
-    if (r0_ >= p.Lq) d0r = make_uint4(0, 0, 0, 0);                                              \
+    const uint32_t a0_ = qo0 < q_max ? qo0 : q_max, b0_ = oo0 < o_max ? oo0 : o_max;            \
+    q0r = *reinterpret_cast<const uint4*>(Qb + a0_);                                            \
+    d0r = *reinterpret_cast<const uint4*>(DOb + b0_);                                           \
     if (NW == 4) {      /* 256 threads: a second row per thread */                              \
-      q1r = *reinterpret_cast<const uint4*>(Q + (int64_t)c1_ * p.q_rs + sc * 8);                \
-      d1r = *reinterpret_cast<const uint4*>(DO + (int64_t)c1_ * p.o_rs + sc * 8);               \
-      if (r1_ >= p.Lq) d1r = make_uint4(0, 0, 0, 0);                                            \
+      const uint32_t a1_ = qo1 < q_max ? qo1 : q_max, b1_ = oo1 < o_max ? oo1 : o_max;          \
+      q1r = *reinterpret_cast<const uint4*>(Qb + a1_);                                          \
+      d1r = *reinterpret_cast<const uint4*>(DOb + b1_);                                         \
     }                                                                                           \
-    const int r2_ = (qt_) * QROWS + lrow;                                                       \
-    const int r2c_ = r2_ < p.Lq ? r2_ : p.Lq - 1;                                               \
+    const int r2c_ = ld_row < p.Lq ? ld_row : p.Lq - 1;                                         \
     const float l_ = LSE[r2c_] * LOG2E, dl_ = DELTA[r2c_];                                      \
-    lreg = r2_ < p.Lq ? -l_ : -INFINITY; /* -inf => P = exp2(-inf) = 0 for rows past Lq */       \
-    dreg = r2_ < p.Lq ? -dl_ : 0.f;                                                             \
+    lreg = ld_row < p.Lq ? -l_ : -INFINITY; /* -inf => P = exp2(-inf) = 0 for rows past Lq */    \
+    dreg = ld_row < p.Lq ? -dl_ : 0.f;                                                          \
     if (DROP && tid < QROWS / 2) {                                                              \
-      const int qa_ = (qt_) * QROWS + 2 * tid, qb_ = qa_ + 1;                                   \
+      const int qa_ = ld_row0 + 2 * tid, qb_ = qa_ + 1;                                         \
       rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1) | (attn_drop_rowkey16(salt, qb_ < p.Lq ? qb_ : p.Lq - 1) << 16); \
     }                                                                                           \
+    qo0 += q_step; oo0 += o_step; qo1 += q_step; oo1 += o_step;                                 \
+    ld_row += QROWS; ld_row0 += QROWS;                                                          \
   }
 #define STAGE_WRITE(buf_)                                                                       \
   {                                                                                             \
