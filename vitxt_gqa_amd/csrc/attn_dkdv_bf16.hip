@@ -148,8 +148,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_dkdv_bf16_kernel(AttnParams p
   __syncthreads();
   // With dropout the sweep is compiled in two forms selected by ONE workgroup-uniform branch: the decoder / validity rule
   // if-converts into ~170 VALU instructions per iteration, paid by every workgroup although only the last key block of
-  // a sample needs it (535 -> 375 VALU per 32 MFMAs).  Without dropout the same split measured 5 % SLOWER (the
-  // compiler's schedule of the single loop with the run-time flag is better), so that form is kept as it was.
+  // a sample needs it (535 -> 375 VALU per 32 MFMAs).  Without dropout the whole-loop split measured 5 % slower; there the
+  // rule sits behind a uniform branch INSIDE the one loop (see the sweep).
   if (!DROP) {
     const bool edge = edge_wg;
 #include T2S_DKDV_SWEEP
