@@ -75,6 +75,17 @@ __device__ __forceinline__ uint32_t attn_drop_pair_diff(uint32_t a2, uint32_t b2
   const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, thresh2s));
   return __builtin_bit_cast(uint32_t, d);
 }
+// The same value with (x * M + 0x8000) forced into ONE v_pk_mad_u16: the compiler emits v_pk_mul_lo_u16 + v_xor for the
+// expression above (the add of 0x8000 rewritten as a flip of the top bit).  Used by the forward kernel only (2.37 -> 2.32 ms
+// at B=8); in the two backward kernels the inline asm cost more in scheduling freedom than the instruction saved
+// (7.72 -> 7.98 ms), so they keep the plain form.
+__device__ __forceinline__ uint32_t attn_drop_pair_diff_mad(uint32_t a2, uint32_t b2, uint32_t thresh2s) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  uint32_t t;
+  asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(t) : "v"(a2 ^ b2), "v"(ATTN_DROP_MUL * 0x10001u), "s"(0x80008000u));
+  const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, thresh2s));
+  return __builtin_bit_cast(uint32_t, d);
+}
 __device__ __forceinline__ uint32_t attn_drop_thresh2s(uint32_t thresh) { return (((thresh << 8) ^ 0x8000u) & 0xFFFFu) * 0x10001u; }
 // 0xFFFF in every DROPPED half (v_pk_ashrrev_i16), for clearing halves of packed bf16 words
 __device__ __forceinline__ uint32_t attn_drop_pair_dropped(uint32_t a2, uint32_t b2, uint32_t thresh2s) {
@@ -83,6 +94,11 @@ __device__ __forceinline__ uint32_t attn_drop_pair_dropped(uint32_t a2, uint32_t
   return __builtin_bit_cast(uint32_t, m);
 }
 // word of two bf16 probabilities with the dropped halves cleared (v_bfi_b32)
+__device__ __forceinline__ uint32_t attn_drop_pair_dropped_mad(uint32_t a2, uint32_t b2, uint32_t thresh2s) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 m = __builtin_bit_cast(s16x2, attn_drop_pair_diff_mad(a2, b2, thresh2s)) >> 15;
+  return __builtin_bit_cast(uint32_t, m);
+}
 __device__ __forceinline__ uint32_t attn_drop_apply(uint32_t w, uint32_t dropped) { return w & ~dropped; }
 
 // per-score 32-bit masks (all ones = dropped) of the two halves, and "zero the float if dropped" (v_bfe_i32 / v_ashrrev_i32,
