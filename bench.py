@@ -168,10 +168,18 @@ def main():
         cpu_res = cpu_baseline(args.vocab)          # host-only; runs before any GPU call
         print("[bench] cpu_baseline:", json.dumps(cpu_res), file=sys.stderr, flush=True)
     import torch.distributed as dist
+    # rehearsal hooks (never set by the driver): T2S_BENCH_BACKEND=gloo and T2S_BENCH_ONE_GPU=1 run the multi-rank path with
+    # every rank on cuda:0, so the N > 1 control flow (buckets, barriers, MAX over ranks) can be exercised on a 1-GPU box
+    backend = os.environ.get("T2S_BENCH_BACKEND", "nccl")
+    if os.environ.get("T2S_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
