@@ -86,3 +86,17 @@ def test_lr_schedule_and_clip_semantics():
     lin.bias.grad = torch.zeros(4)
     n = clip_gradients(lin, cfg)
     assert float(n) == pytest.approx(4.0) and float(lin.weight.grad.norm()) == pytest.approx(0.25, rel=1e-4)
+
+
+def test_bench_flop_model_matches_survey_table():
+    """bench.py's FLOP model against the figures of SURVEY section 8 (fwd FLOPs per sample, attention-GEMM share)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for (F, P), total, attn in (((20, 30), 1.20e11, 1.43e10), ((64, 15), 2.08e11, 3.75e10), ((100, 100), 5.10e12, 3.47e12),
+                                ((100, 1), 3.95e10, 1.79e9), ((300, 200), 1.33e14, 1.23e14)):
+        t, a = bench.flops_per_sample_fwd(F, P, 5000)
+        assert abs(t - total) / total < 0.01, (F, P, t)
+        assert abs(a - attn) / attn < 0.01, (F, P, a)
