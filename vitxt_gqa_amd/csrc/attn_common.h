@@ -34,13 +34,13 @@ struct AttnParams {
 // ---- attention-probability dropout.  keep(q, kpos) is a stateless function of (seed, sample, head, q, kpos) so that
 // the forward, dQ and dK/dV kernels regenerate the same mask in their different register layouts; kpos is the POSITION
 // in the compacted key list.  The function is built to cost ~3 VALU instructions per score in kernels that are VALU
-// bound:   byte(q, kpos) = high byte of ((rowkey16(q) ^ colkey16(kpos)) * 0x9E37 mod 2^16),   keep iff byte >= thresh
+// bound:   t(q, kpos) = ((rowkey16(q) ^ colkey16(kpos)) * 0x9E37 mod 2^16) read as int16,   keep iff t >= thresh * 256 - 32768
 // where rowkey16 / colkey16 are 16 bits of full-quality 32-bit hashes of (seed, sample, head, q) and (seed, sample, head,
 // kpos).  Those hashes are per-lane constants on the stationary axis and are computed once per tile (32 threads, one
 // key pair each, staged in LDS) on the streamed axis, so the per-score work is xor + multiply + compare - and it is
 // done on TWO scores per instruction with packed 16-bit math: a bf16x2 word of P holds two consecutive keys of the
 // lane's query (forward, dQ) or two consecutive queries of the lane's key (dK/dV), exactly the two 16-bit halves.
-// For a fixed row the bytes are independent over keys and vice versa (colkey16 / rowkey16 are independent uniform
+// For a fixed row the values t are independent over keys and vice versa (colkey16 / rowkey16 are independent uniform
 // 16-bit values and x -> x * odd is a bijection); two rows share a mask only if their 16-bit keys collide (2^-16).
 __device__ __forceinline__ uint32_t attn_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -59,33 +59,24 @@ __device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) 
 }
 #endif
 constexpr uint32_t ATTN_DROP_MUL = 0x9E37u;
-// generic per-element form (fp32 kernels, mask export)
+// generic per-element form (fp32 kernels, mask export).  The 16-bit product is read as a SIGNED number and compared with
+// thresh * 256 - 32768: the same drop probability thresh / 256 as an unsigned byte compare, without the flip of the top
+// bit the unsigned form needs before a signed saturating subtract (one VALU instruction per score pair in VALU-bound loops).
 __device__ __forceinline__ bool attn_drop_keep16(uint32_t rk16, uint32_t ck16, uint32_t thresh) {
-  return ((((rk16 ^ ck16) * ATTN_DROP_MUL) & 0xFFFFu) >> 8) >= thresh;
+  const int t = (int)(short)(((rk16 ^ ck16) * ATTN_DROP_MUL) & 0xFFFFu);
+  return t >= (int)(thresh << 8) - 32768;
 }
 // packed form: a2 ^ b2 holds (rowkey ^ colkey) of two scores in its 16-bit halves; returns per half a signed 16-bit
-// value that is NEGATIVE iff the score is dropped.  byte >= thresh  <=>  t16 >= thresh*256 (unsigned)  <=>
-// (t16 ^ 0x8000) >= (thresh*256 ^ 0x8000) (signed); the flip of the top bit is the +0x8000 of a multiply-add and the
-// comparison is a saturating subtract: v_xor, v_pk_mad_u16, v_pk_sub_i16 clamp - three instructions for two scores.
+// value that is NEGATIVE iff the score is dropped: v_xor, v_pk_mul_lo_u16, v_pk_sub_i16 clamp - three instructions for two
+// scores.
 __device__ __forceinline__ uint32_t attn_drop_pair_diff(uint32_t a2, uint32_t b2, uint32_t thresh2s /* attn_drop_thresh2s(thresh) */) {
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const u16x2 t = __builtin_bit_cast(u16x2, a2 ^ b2) * u16x2{(unsigned short)ATTN_DROP_MUL, (unsigned short)ATTN_DROP_MUL} +
-                  u16x2{(unsigned short)0x8000u, (unsigned short)0x8000u};
+  const u16x2 t = __builtin_bit_cast(u16x2, a2 ^ b2) * u16x2{(unsigned short)ATTN_DROP_MUL, (unsigned short)ATTN_DROP_MUL};
   const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, thresh2s));
   return __builtin_bit_cast(uint32_t, d);
 }
-// The same value with (x * M + 0x8000) forced into ONE v_pk_mad_u16: the compiler emits v_pk_mul_lo_u16 + v_xor for the
-// expression above (the add of 0x8000 rewritten as a flip of the top bit).  Used by the forward kernel only (2.37 -> 2.32 ms
-// at B=8); in the two backward kernels the inline asm cost more in scheduling freedom than the instruction saved
-// (7.72 -> 7.98 ms), so they keep the plain form.
-__device__ __forceinline__ uint32_t attn_drop_pair_diff_mad(uint32_t a2, uint32_t b2, uint32_t thresh2s) {
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  uint32_t t;
-  asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(t) : "v"(a2 ^ b2), "v"(ATTN_DROP_MUL * 0x10001u), "s"(0x80008000u));
-  const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, thresh2s));
-  return __builtin_bit_cast(uint32_t, d);
-}
+// thresh * 256 - 32768 as a 16-bit pattern, in both halves
 __device__ __forceinline__ uint32_t attn_drop_thresh2s(uint32_t thresh) { return (((thresh << 8) ^ 0x8000u) & 0xFFFFu) * 0x10001u; }
 // 0xFFFF in every DROPPED half (v_pk_ashrrev_i16), for clearing halves of packed bf16 words
 __device__ __forceinline__ uint32_t attn_drop_pair_dropped(uint32_t a2, uint32_t b2, uint32_t thresh2s) {
@@ -94,11 +85,6 @@ __device__ __forceinline__ uint32_t attn_drop_pair_dropped(uint32_t a2, uint32_t
   return __builtin_bit_cast(uint32_t, m);
 }
 // word of two bf16 probabilities with the dropped halves cleared (v_bfi_b32)
-__device__ __forceinline__ uint32_t attn_drop_pair_dropped_mad(uint32_t a2, uint32_t b2, uint32_t thresh2s) {
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const s16x2 m = __builtin_bit_cast(s16x2, attn_drop_pair_diff_mad(a2, b2, thresh2s)) >> 15;
-  return __builtin_bit_cast(uint32_t, m);
-}
 __device__ __forceinline__ uint32_t attn_drop_apply(uint32_t w, uint32_t dropped) { return w & ~dropped; }
 
 // per-score 32-bit masks (all ones = dropped) of the two halves, and "zero the float if dropped" (v_bfe_i32 / v_ashrrev_i32,

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
       u32x4 w_ = __builtin_bit_cast(u32x4, f_);                                                     \
       const uint32_t th2_ = attn_drop_thresh2s(p.drop_thresh);                                  \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-        w_[i] = attn_drop_apply(w_[i], attn_drop_pair_dropped_mad(rk2[qb_], ck_s[cbuf_][(kbk_) * 16 + 8 * (s_) + 4 * (i >> 1) + (i & 1) + 2 * lh], th2_)); \
+        w_[i] = attn_drop_apply(w_[i], attn_drop_pair_dropped(rk2[qb_], ck_s[cbuf_][(kbk_) * 16 + 8 * (s_) + 4 * (i >> 1) + (i & 1) + 2 * lh], th2_)); \
       f_ = __builtin_bit_cast(bf16x8, w_);                                                          \
     }                                                                                               \
     pf[qb_][kbk_][s_] = f_;                                                                         \
