@@ -6,9 +6,10 @@
 A step = forward (TextBert, embeds, QTV, grounding, 3 x MMT + heads) + pos_bce_loss + 1000*InfoNCE +
 backward + global-norm clip 0.25 + Adam, batch 64 per GPU (BASELINE.json configs[2]; weak scaling:
 per-GPU batch fixed, questions sharded across ranks, one RCCL gradient all-reduce per step).
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (attention forward
-kernel, HIP-event timed inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle restatement
-of the reference timed on this box's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (the dominant kernel group of the
+step: the attention backward, HIP-event timed inside the timed region; `roofline_fwd` = the attention forward kernel)
+and, at N=1, `cpu_baseline` (the CPU oracle restatement of the reference timed on this box's host cores on a bounded
+sample).  `python bench.py --gpus N` without a launcher starts the N ranks itself (spawn_ranks).
 """
 import argparse
 import json
@@ -37,48 +38,68 @@ def flops_per_sample_fwd(F, P, V):
     return total, attn
 
 
-class AttnFwdTimer:
-    """Wraps ops.attn_fwd with HIP events on the launch stream (torch's current stream is the stream the
-    kernel is enqueued on); accumulates algorithmic (dense-mask) FLOPs and device time per launch."""
+class AttnTimer:
+    """Wraps ops.attn_fwd / ops.attn_bwd with HIP events on the launch stream (torch's current stream is the stream the
+    kernels are enqueued on); accumulates FLOPs and device time per launch."""
 
     def __init__(self):
         from vitxt_gqa_amd import ops
-        self.ops, self.orig = ops, ops.attn_fwd
-        self.events, self.enabled = [], False
+        self.ops, self.orig_f, self.orig_b = ops, ops.attn_fwd, ops.attn_bwd
+        self.fwd, self.bwd, self.enabled = [], [], False
 
-    def __enter__(self):
-        def timed(qkv, keys, *args, **kwargs):
+    def _timed(self, orig, store, prods):
+        def f(qkv, *args, **kwargs):
             if not self.enabled:
-                return self.orig(qkv, keys, *args, **kwargs)
+                return orig(qkv, *args, **kwargs)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = self.orig(qkv, keys, *args, **kwargs)
+            r = orig(qkv, *args, **kwargs)
             e1.record()
+            keys = args[0] if prods == 2 else args[3]
             B, L, _ = qkv.shape
-            self.events.append((e0, e1, 4.0 * B * 12 * L * L * 64, L, keys.cnt, keys.n_dec))
+            store.append((e0, e1, B, L, keys.cnt, keys.n_dec))
             return r
-        self.ops.attn_fwd = timed
+        return f
+
+    def __enter__(self):
+        self.ops.attn_fwd = self._timed(self.orig_f, self.fwd, 2)
+        self.ops.attn_bwd = self._timed(self.orig_b, self.bwd, 5)
         return self
 
     def __exit__(self, *a):
-        self.ops.attn_fwd = self.orig
+        self.ops.attn_fwd, self.ops.attn_bwd = self.orig_f, self.orig_b
 
-    def summary(self, min_flops=1e9):
-        big = [(a.elapsed_time(b) * 1e-3, f, 4.0 * 12 * 64 * L * float((cnt.sum() + cnt.numel() * nd).item()))
-               for a, b, f, L, cnt, nd in self.events if f >= min_flops]
+    @staticmethod
+    def _summary(events, products, min_flops=1e9):
+        """products: matrix products per (query, key) pair counted as algorithmic work (forward 2, backward 5)."""
+        big = []
+        for a, b, B, L, cnt, nd in events:
+            dense = 2.0 * products * B * 12 * L * L * 64
+            if dense >= min_flops:
+                vis = float((cnt.sum() + cnt.numel() * nd).item())
+                big.append((a.elapsed_time(b) * 1e-3, dense, 2.0 * products * 12 * 64 * L * vis))
         if not big:
             return None
         t, f, fx = sum(x[0] for x in big), sum(x[1] for x in big), sum(x[2] for x in big)
-        return dict(launches=len(big), avg_ms=1e3 * t / len(big), tflops=f / t / 1e12, tflops_executed=fx / t / 1e12)
+        return dict(launches=len(big), avg_ms=1e3 * t / len(big), tflops_dense=f / t / 1e12, tflops=fx / t / 1e12, total_ms=1e3 * t)
+
+    def summary_fwd(self):
+        return self._summary(self.fwd, 2)
+
+    def summary_bwd(self):
+        return self._summary(self.bwd, 5)
 
 
 class _Budget(Exception):
     pass
 
 
-def cpu_baseline(V, seed=0, budget_s=150):
-    """Reference semantics (CPU oracle) timed on the host cores on a bounded sample of the workload, scaled to
-    the full 100x100 shape by the FLOP model.  Runs BEFORE the GPU is touched, under a hard wall-clock budget."""
+def cpu_baseline(V, seed=0, budget_s=240):
+    """Reference semantics (CPU oracle) timed on the host cores on a bounded sample of the workload: the full train step at
+    B=1, 100 frames x {20, 50} OCR tokens per frame (two MEASURED points; the larger one only where the host has the memory
+    for the eager [12, L, L] score tensors and the time budget allows), scaled to the 100 x 100 shape by the FLOP model;
+    the measured scaling exponent in L is reported beside the model's.  Runs BEFORE the GPU is touched, under a hard
+    wall-clock budget."""
     import signal
     from oracle import t2s_oracle as O
     from vitxt_gqa_amd.init import make_state_dict
@@ -90,49 +111,96 @@ def cpu_baseline(V, seed=0, budget_s=150):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 64))
     torch.set_num_threads(cores)
+    try:
+        import psutil
+        free_gb = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        free_gb = 0.0
     Fs, Bs = 100, 1
     f_full, _ = flops_per_sample_fwd(100, 100, V)
     sd = make_state_dict(state_dict_schema(V), seed=seed)
     for k, v in sd.items():
         v.requires_grad_(not O.is_dead(k))
     result = {"value": None, "unit": "samples/s", "cores": cores, "kind": "port", "sample": "not measured (budget exceeded)"}
+    points = []
 
     def on_alarm(signum, frame):
         raise _Budget()
 
     old = signal.signal(signal.SIGALRM, on_alarm)
     signal.alarm(int(budget_s))
+    t_start = time.time()
     try:
-        for Ps, min_steps in ((5, 1), (20, 2)):
+        for Ps, min_steps, max_steps in ((5, 1, 3), (20, 2, 3), (50, 1, 1)):
+            L = T_Q + Fs + Fs * Ps + DEC
+            f_s, _ = flops_per_sample_fwd(Fs, Ps, V)
+            if points:
+                est = points[-1]["s_per_step"] * f_s / points[-1]["flops"]              # FLOP-model estimate of one step here
+                need_gb = 11 * 5 * 12 * L * L * 4 / 2 ** 30                            # ~5 live [12, L, L] fp32 tensors x 11 layers
+                if (time.time() - t_start) + est * (1 + min_steps) > budget_s * 0.9 or need_gb > 0.5 * free_gb:
+                    result["skipped_point"] = "B=1 x 100 x %d (L=%d): est. %.0f s/step, ~%.0f GB of autograd state vs %.0f GB free" % (Ps, L, est, need_gb, free_gb)
+                    break
             batch = make_batch(Bs, Fs, Ps, V=V, seed=seed)
             e1, e2 = make_noise(Bs, Fs, Ps, seed)
             cfg = dict(frame_topk=5, ocr_topk=5, frame_num=Fs, ocr_frame_num=Ps)
             st = {}
-            t0 = time.time()
             O.train_step(sd, batch, cfg, st, 1, expo_frame=e1, expo_ocr=e2)        # warm-up
-            warm = time.time() - t0
             t0 = time.time()
             n = 0
-            while n < min_steps or (time.time() - t0 < 8 and n < 6):
+            while n < min_steps or (time.time() - t0 < 8 and n < max_steps):
                 O.train_step(sd, batch, cfg, st, n + 2, expo_frame=e1, expo_ocr=e2)
                 n += 1
             dt = (time.time() - t0) / n
-            f_s, _ = flops_per_sample_fwd(Fs, Ps, V)
-            sps = Bs / dt
-            result.update(value=sps * f_s / f_full, measured_samples_per_s_at_sample_shape=sps,
-                          sample="oracle (plain-torch CPU restatement of the reference) full train step, fp32, %d threads, "
-                                 "B=%d x %d frames x %d OCR/frame (L=%d): %.2f s/step over %d steps = %.3f samples/s "
-                                 "measured; scaled by the FLOP model (x%.4f) to the 100x100 workload"
-                                 % (cores, Bs, Fs, Ps, T_Q + Fs + Fs * Ps + DEC, dt, n, sps, f_s / f_full))
-            f_next, _ = flops_per_sample_fwd(Fs, 20, V)
-            if Ps == 5 and dt * f_next / f_s > 12:       # the larger sample would not fit the budget
-                break
+            points.append({"frames": Fs, "ocr_per_frame": Ps, "L": L, "s_per_step": dt, "steps": n, "flops": f_s,
+                           "samples_per_s": Bs / dt})
     except _Budget:
-        result["sample"] += " [stopped by the %ds wall-clock budget]" % budget_s
+        result["sample"] = "stopped by the %ds wall-clock budget" % budget_s
     finally:
         signal.alarm(0)
         signal.signal(signal.SIGALRM, old)
+    if points:
+        big = points[-1]
+        result.update(value=big["samples_per_s"] * big["flops"] / f_full, measured_samples_per_s_at_sample_shape=big["samples_per_s"],
+                      measured_points=[{k: p[k] for k in ("frames", "ocr_per_frame", "L", "s_per_step", "steps")} for p in points],
+                      sample="oracle (plain-torch CPU restatement of the reference) full train step, fp32, %d threads, "
+                             "B=%d x %d frames x %d OCR/frame (L=%d): %.2f s/step over %d steps = %.3f samples/s "
+                             "measured; scaled by the FLOP model (x%.4f) to the 100x100 workload"
+                             % (cores, Bs, Fs, big["ocr_per_frame"], big["L"], big["s_per_step"], big["steps"], big["samples_per_s"],
+                                big["flops"] / f_full))
+        if len(points) >= 2:
+            import math
+            a, b = points[-2], points[-1]
+            expo = math.log(b["s_per_step"] / a["s_per_step"]) / math.log(b["L"] / a["L"])
+            expo_model = math.log(b["flops"] / a["flops"]) / math.log(b["L"] / a["L"])
+            L_full = T_Q + 100 + 100 * 100 + DEC
+            result.update(measured_scaling_exponent_in_L=expo, flop_model_exponent_in_L=expo_model,
+                          value_by_measured_exponent=1.0 / (b["s_per_step"] * (L_full / b["L"]) ** expo))
     return result
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    flags>` as a child process (one rank per GPU over RCCL; base_trainer.py:51-71 is the reference's counterpart)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    one_gpu = os.environ.get("T2S_BENCH_ONE_GPU") == "1"
+    if have < n and not one_gpu:
+        print("bench.py: --gpus %d but only %d GPU(s) are visible.  (To rehearse the multi-rank control flow on one card: "
+              "T2S_BENCH_BACKEND=gloo T2S_BENCH_ONE_GPU=1 python bench.py --gpus %d ...)" % (n, have, n), file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] spawning %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    if os.environ.get("T2S_BENCH_DRY_SPAWN") == "1":          # tests: show the command, start nothing
+        print(json.dumps({"spawn": cmd}))
+        return 0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -160,9 +228,16 @@ def main():
                          "0 is the parity configuration")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched without a launcher: start the N ranks ourselves.  This parent has not touched the GPU (device_count() does not
+        # initialise it) and never will: the ranks are FRESH child processes of torch.distributed.run, rank 0 prints the JSON
+        # line to the inherited stdout, and the parent exits with the launcher's status.
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     cpu_res = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_res = cpu_baseline(args.vocab)          # host-only; runs before any GPU call
@@ -220,7 +295,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with AttnFwdTimer() as timer:
+    with AttnTimer() as timer:
         for _ in range(args.warmup):
             step()
         sync()
@@ -289,18 +364,25 @@ def main():
     f_total, f_attn = flops_per_sample_fwd(F, P, V)
     mult = 1.0 if args.forward_only else 3.0
     sps = world * B * args.steps / elapsed
-    att = timer.summary()
+    att_f, att_b = timer.summary_fwd(), timer.summary_bwd()
+    shape = "batch %d/GPU, %d frames x %d OCR/frame x 20 q-tokens, 12 decode steps, V=%d" % (B, F, P, V)
+    if (B, F, P, V) == (64, 100, 100, 5000):
+        shape += " (BASELINE.json configs[%d]%s)" % (1 if args.forward_only else 2, "; configs[3] per GPU" if world > 1 else "")
+    elif (F, P) == (300, 200):
+        shape += " (BASELINE.json configs[4]: long-sequence stress)"
+    else:
+        shape += " (not a BASELINE.json configuration)"
     res = {
         "metric": ("forward-only" if args.forward_only else "train-step") + " samples/sec (T2S, %d-frame x %d-OCR synthetic)" % (F, P),
         "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "T2S-QA %s, batch %d/GPU, %d frames x %d OCR/frame x 20 q-tokens, 12 decode steps, V=%d "
-                               "(BASELINE.json configs[%d])" % ("forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam, pos-BCE + 1000*InfoNCE)",
-                                                               B, F, P, V, 1 if args.forward_only else 2),
+        "config": {"workload": "T2S-QA %s, %s" % ("forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam, pos-BCE + 1000*InfoNCE)", shape),
                    "global_batch": world * B, "seq_len": T_Q + F + F * P + DEC, "parallelism": "dp%d" % world,
                    "dropout": args.dropout,
                    "precision": "bf16 MFMA operands, fp32 accumulate / residual stream / master weights" if args.dtype == "bf16" else "fp32"},
+        "ranks_seen": dist.get_world_size() if world > 1 else 1,
+        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None,
         "model_flops_per_sample": mult * f_total,
         "model_tflops": sps * mult * f_total / 1e12 / world,
         "attention_gemm_fraction_of_flops": f_attn / f_total,
@@ -308,19 +390,39 @@ def main():
     }
     if not args.forward_only:
         res["loss"] = float(last.detach())
-    if att:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("attn_fwd_bf16_kernel")
-        res["roofline"] = {"kernel": "attn_fwd_bf16_kernel (all launches with >= 1 GFLOP in the timed region)",
-                           "bound": "mfma", "achieved": att["tflops_executed"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": att["tflops_executed"] / PEAK_BF16_TFLOPS, "traffic": traffic,
-                           "launches": att["launches"], "avg_launch_ms": att["avg_ms"],
-                           "achieved_dense_mask_equivalent": att["tflops"],
-                           "note": "achieved = EXECUTED attention-GEMM FLOPs (4*12*64*L*sum_b(visible keys) per launch: masked keys "
-                                   "are skipped by key compaction, exact in fp32) / HIP-event time; achieved_dense_mask_equivalent "
-                                   "prices the same launches at the reference's dense-mask FLOPs 4*B*12*L^2*64 (SURVEY 8d)"}
+    # HBM traffic per launch from the PMC counters is a property of ONE configuration: profiles/traffic.json is keyed by
+    # (B, F, P, dropout) and anything else reports null
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("B%d_F%d_P%d_drop%g" % (B, F, P, args.dropout), {})
+    from vitxt_gqa_amd.ops import ATTN_BWD_PRODUCTS
+    fwd_block = bwd_block = None
+    if att_f:
+        fwd_block = {"kernel": "attn_fwd_bf16_kernel (all launches with >= 1 GFLOP in the timed region)",
+                     "bound": "mfma", "achieved": att_f["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": att_f["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic.get("attn_fwd"),
+                     "launches": att_f["launches"], "avg_launch_ms": att_f["avg_ms"], "ms_per_step": att_f["total_ms"] / args.steps,
+                     "achieved_dense_mask_equivalent": att_f["tflops_dense"],
+                     "note": "achieved = algorithmic attention-GEMM FLOPs over the VISIBLE keys (2 products: 4*12*64*L*sum_b(visible keys) "
+                             "per launch; masked keys are skipped by key compaction, exact in fp32) / HIP-event time; "
+                             "achieved_dense_mask_equivalent prices the same launches at the reference's dense-mask FLOPs "
+                             "4*B*12*L^2*64 (SURVEY 8d) and is not a utilisation"}
+    if att_b:
+        bwd_block = {"kernel": "attention backward launch group (attn_delta + %s; all launches with >= 1 GFLOP in the timed region)"
+                               % ("attn_bwd_fused_bf16_kernel" if ATTN_BWD_PRODUCTS == 5 else "attn_dkdv_bf16_kernel + attn_dq_bf16_kernel"),
+                     "bound": "mfma", "achieved": att_b["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": att_b["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic.get("attn_bwd"),
+                     "launches": att_b["launches"], "avg_launch_ms": att_b["avg_ms"], "ms_per_step": att_b["total_ms"] / args.steps,
+                     "executed_products": ATTN_BWD_PRODUCTS, "achieved_executed": att_b["tflops"] * ATTN_BWD_PRODUCTS / 5.0,
+                     "note": "achieved = ALGORITHMIC backward FLOPs over the visible keys (5 products: 10*12*64*L*sum_b(visible keys) per "
+                             "launch) / HIP-event time around ops.attn_bwd; achieved_executed counts the products the kernels really "
+                             "run (executed_products per (query, key) pair: S and dP are recomputed when it is 7)"}
+    # `roofline` = the dominant kernel group of the step (the attention backward in a train step, the forward otherwise)
+    if bwd_block is not None:
+        res["roofline"], res["roofline_fwd"] = bwd_block, fwd_block
+    elif fwd_block is not None:
+        res["roofline"] = fwd_block
     if cpu_res is not None:
         res["cpu_baseline"] = cpu_res
     if pcie is not None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2S_ABI_VERSION 1
+#define T2S_ABI_VERSION 2
 #define T2S_F32 0
 #define T2S_BF16 1
 #define T2S_HEAD_DIM 64
@@ -60,8 +60,7 @@ int t2s_compact_keys(const uint8_t* valid, int32_t* out_idx, int32_t* out_cnt, i
  * lse: [B, H, Lq] fp32, natural-log-sum-exp of the scaled scores (saved for backward).
  * drop_p > 0: attention-probability dropout (BertSelfAttention: dropout(softmax(.)) before .V):
  * out = (softmax(.) * keep / (1 - p')) V, keep(b, h, q, list position) a stateless function of drop_seed
- * (vitxt_gqa_amd/csrc/attn_common.h), p' = round(256 p)/256 (one byte per score).  drop_ws: kept for ABI
- * stability, unused (the mask needs no table) and may be NULL.  The backward call
+ * (vitxt_gqa_amd/csrc/attn_common.h), p' = round(256 p)/256 (one byte per score); the mask needs no workspace.  The backward call
  * regenerates the mask from the same seed; t2s_attn_dropout_mask exports it. */
 int t2s_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                  const int32_t* kv_idx, const int32_t* kv_cnt,
@@ -69,11 +68,10 @@ int t2s_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
                  int64_t q_row_stride, int64_t q_batch_stride,
                  int64_t kv_row_stride, int64_t kv_batch_stride,
                  int64_t o_row_stride, int64_t o_batch_stride,
-                 float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws,
-                 t2s_stream_t stream);
+                 float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 /* keep mask [B, H, Lq, Lk] (0/1 bytes; Lk = key-list positions) of the dropout above (tests). */
 int t2s_attn_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p, uint64_t drop_seed,
-                          uint32_t* drop_ws, t2s_stream_t stream);
+                          t2s_stream_t stream);
 
 /* Backward of the above.  delta: [B, H, Lq] fp32 workspace (rowsum(dO * O), written here).
  * dq/dk/dv use the q/kv strides.  dk/dv rows of keys that are not in the key list are NOT
@@ -87,8 +85,7 @@ int t2s_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
                  int64_t q_row_stride, int64_t q_batch_stride,
                  int64_t kv_row_stride, int64_t kv_batch_stride,
                  int64_t o_row_stride, int64_t o_batch_stride,
-                 float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws,
-                 t2s_stream_t stream);
+                 float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 /* The same for the self-attention layout (Lq == idx_cap: query rows = prefix rows + decoder rows; bf16), with
  * the zero-fill done here: row_valid [B, idx_cap - n_dec] bytes is the mask the key list was compacted from
  * (t2s_compact_keys' input); the dQ kernel, which visits every (row, head) anyway, writes the zero dK / dV

@@ -35,3 +35,40 @@ def test_round_trip_prefix_and_bare(tmp_path):
     for k, a in m1.state_dict().items():
         assert torch.equal(a, m3.state_dict()[k]) and torch.equal(a, m4.state_dict()[k])
     assert normalize_state_dict({"module.module.x": 1, "a.fa_history.b": 2}) == {"module.x": 1, "a.fa_context.b": 2}
+
+
+def test_optimizer_state_round_trip_in_the_reference_group_layout(tmp_path):
+    """The optimizer entry of a checkpoint is index-compatible with the reference's: param groups list EVERY parameter in the
+    reference's order (t2s.py:356-376), Adam state exists only for parameters that received gradients (the dead ones never do),
+    ``optimizer: None`` files load, and a state dict written in the reference's layout loads and resumes."""
+    from vitxt_gqa_amd import training_config
+    from vitxt_gqa_amd.optim import build_optimizer
+    from vitxt_gqa_amd.schema import is_dead_param
+    cfg = training_config()
+    m1 = make_model(3, 4, 40, text_vocab=60, seed=1, dtype=torch.float32)
+    opt1 = build_optimizer(m1, cfg)
+    names = [n for n, _ in m1.named_parameters()]
+    g = torch.Generator().manual_seed(0)
+    for n, p in m1.named_parameters():
+        if not is_dead_param(n):
+            p.grad = torch.randn(p.shape, generator=g) * 1e-3
+    opt1.step()
+    sd = opt1.state_dict()
+    n_params = len(names)
+    assert [len(gr["params"]) for gr in sd["param_groups"]] == [n_params - len(list(m1.mmt.parameters())), len(list(m1.mmt.parameters()))]
+    assert sorted(i for gr in sd["param_groups"] for i in gr["params"]) == list(range(n_params))
+    order = [id(p) for gr in opt1.param_groups for p in gr["params"]]
+    by_id = {id(p): n for n, p in m1.named_parameters()}
+    live_idx = {i for i, pid in enumerate(order) if not is_dead_param(by_id[pid])}
+    assert set(sd["state"]) == live_idx                                     # no Adam state for the 58 dead parameters
+    path = str(tmp_path / "with_opt.ckpt")
+    save_checkpoint(path, m1, opt1, best_iteration=3)
+    m2 = make_model(3, 4, 40, text_vocab=60, seed=2, dtype=torch.float32)
+    opt2 = build_optimizer(m2, cfg)
+    load_checkpoint(path, m2, opt2)
+    for k, st in opt1.state_dict()["state"].items():
+        assert torch.equal(st["exp_avg"], opt2.state_dict()["state"][k]["exp_avg"]) and torch.equal(st["exp_avg_sq"], opt2.state_dict()["state"][k]["exp_avg_sq"])
+    # a file written without an optimizer
+    path2 = str(tmp_path / "no_opt.ckpt")
+    save_checkpoint(path2, m1)
+    load_checkpoint(path2, m2, opt2)

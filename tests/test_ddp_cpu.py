@@ -80,3 +80,29 @@ def test_bucket_views_must_survive():
     m[0].weight.grad = None
     with pytest.raises(RuntimeError):
         b.reset()
+
+
+def _worker_unused(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _model()
+    buckets = GradBuckets(m.named_parameters(), bucket_bytes=2048)
+    buckets.reset()
+    m[0](torch.randn(4, 16)).sum().backward()          # a partial backward: the later layers get no gradient
+    try:
+        buckets.finish()
+        out[rank] = "no error"
+    except RuntimeError as e:
+        out[rank] = str(e)
+    dist.destroy_process_group()
+
+
+def test_finish_refuses_buckets_that_were_never_reduced():
+    """A requires_grad parameter without a gradient leaves its bucket un-reduced: finish() must say so, not return."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_unused, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert "never all-reduced" in out[r] and "4.weight" in out[r], out[r]

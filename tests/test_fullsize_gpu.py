@@ -127,3 +127,92 @@ def test_model_full_size_cached_decode_and_batch_equivariance():
     model.decode_with_prefix_cache = True
     assert torch.equal(c["pos_scores"].argmax(-1), d["pos_scores"].argmax(-1))
     assert (c["pos_scores"] - d["pos_scores"]).abs().max().item() < 2e-2 * max(1.0, d["pos_scores"].abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A full TRAIN step at the metric's sequence shapes (BASELINE.json configs[2]: 100 x 100, and configs[4]: 300 x 200): forward
+# through 11 big BERT layers and the three MMT passes, both losses, the hand-written backward (batched wgrad, in-place
+# addmm chains, t2s_attn_bwd_fill inside the model), global-norm clip and Adam - base_trainer.py:251-278, t2s.py:288-354.
+# The oracle cannot run these shapes, so the checks are properties.
+def _train_step_properties(Fn, Pn, B, V, seed, check_perm):
+    from vitxt_gqa_amd import training_config
+    from vitxt_gqa_amd.optim import build_optimizer, train_step
+    from vitxt_gqa_amd.schema import is_dead_param
+    from vitxt_gqa_amd.synth import make_batch, make_noise
+    from vitxt_gqa_amd.testing import make_model, to_device
+    model = make_model(Fn, Pn, V, dtype=torch.bfloat16, attn_gain=4.0, dropout=0.0).to(DEV).train()
+    batch = make_batch(B, Fn, Pn, V=V, seed=seed)
+    batch["train_prev_inds"][:, 3] = V + 7                 # one copied OCR token per answer: the OCR branch of PrevPredEmbeddings
+    batch["train_prev_inds"][:, 5] = V + Fn * Pn - 1
+    noise = make_noise(B, Fn, Pn, seed=seed)
+
+    def grads(bt, nz):
+        s = to_device(bt, DEV)
+        s.grounding_noise = tuple(t.to(DEV) for t in nz)
+        model.zero_grad(set_to_none=True)
+        out = model(s)
+        loss = sum(l.mean() for l in out["losses"].values())
+        loss.backward()
+        return loss.item(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    loss0, g0 = grads(batch, noise)
+    assert loss0 == loss0 and abs(loss0) < float("inf")
+    named = dict(model.named_parameters())
+    dead = {n for n in named if is_dead_param(n)}
+    assert len(dead) == 58
+    assert set(g0) == set(named) - dead, sorted(set(g0) ^ (set(named) - dead))[:8]
+    for n, g in g0.items():
+        assert torch.isfinite(g).all(), n
+        assert g.abs().max().item() > 0, "gradient of %s is identically zero" % n
+    if check_perm:
+        perm = torch.arange(B - 1, -1, -1)
+        loss1, g1 = grads({k: v[perm] for k, v in batch.items()}, tuple(t[perm] for t in noise))
+        assert abs(loss1 - loss0) < 2e-3 * abs(loss0)
+        tot0 = sum(g.double().norm().item() ** 2 for g in g0.values()) ** 0.5
+        tot1 = sum(g.double().norm().item() ** 2 for g in g1.values()) ** 0.5
+        assert abs(tot0 - tot1) < 1e-2 * tot0, (tot0, tot1)
+        for n in g0:                      # per-parameter norms (bf16 operands: the batched wgrad sums samples in another order)
+            a, b_ = g0[n].double().norm().item(), g1[n].double().norm().item()
+            assert abs(a - b_) <= 3e-2 * a + 1e-4 * tot0, (n, a, b_)
+    # a few optimizer steps on the fixed batch go downhill (clip 0.25, Adam, warm-up factor 0.2 -> lr 2e-5)
+    cfg = training_config()
+    opt = build_optimizer(model, cfg)
+    s = to_device(batch, DEV)
+    s.grounding_noise = tuple(t.to(DEV) for t in noise)
+    losses = []
+    for _ in range(4):
+        loss, norm, _ = train_step(model, opt, None, s, cfg)
+        assert torch.isfinite(loss) and torch.isfinite(norm)
+        losses.append(loss.item())
+    assert abs(losses[0] - loss0) < 2e-3 * abs(loss0)
+    assert losses[3] < losses[0], losses
+    return losses
+
+
+def test_train_step_full_size_100x100():
+    _need_gpu()
+    _train_step_properties(100, 100, B=2, V=5000, seed=11, check_perm=True)
+
+
+def test_train_step_stress_300x200():
+    """BASELINE.json configs[4]: 300 frames x 200 OCR tokens per frame, L = 60 332 rows per question."""
+    _need_gpu()
+    _train_step_properties(300, 200, B=1, V=5000, seed=12, check_perm=False)
+    torch.cuda.empty_cache()
+
+
+def test_attn_bwd_fill_equals_zero_fill_path_full_length():
+    """t2s_attn_bwd_fill (unlisted rows' dK / dV zeros written by the dQ kernel) == t2s_attn_bwd on a zero-filled buffer, bit
+    for bit, at L = 10 132 with the ref / pos / neg visibilities and the pos pass's static key bound."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    B = 3
+    keys, valid = _keys_and_mask(B, [0.7, 0.05, 0.006], seed=21)
+    g = torch.Generator().manual_seed(22)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    out, lse = ops.attn_fwd(x, keys)
+    a = ops.attn_bwd(x, out, dout, lse, keys)                               # fill path (keys.valid8 present)
+    plain = ops.KeyList(keys.idx, keys.cnt, keys.n_dec, keys.dec_q0, keys.cap_hint, None)
+    b = ops.attn_bwd(x, out, dout, lse, plain)                              # zero-fill path
+    assert torch.equal(a, b)

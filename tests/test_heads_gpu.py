@@ -111,16 +111,20 @@ def test_ground_select_matches_oracle_rule(B, F, P):
     assert torch.equal(sel["ground_frame"].cpu(), gf)
     assert torch.equal(sel["new_ocr_mask"].cpu(), newm)
     assert (sel["ocr_score"].cpu() - o_score).abs().max().item() < 1e-6
-    # OCR selection: identical wherever the GPU / CPU scores do not differ in their ordering (exact-tie rows are
-    # decided by the shared lowest-index rule; near-ties could flip with 1-ulp score differences, so compare counts
-    # everywhere and exact masks on the overwhelming majority)
-    same = (sel["pos_ocr_mask"].cpu() == pos_o).float().mean().item()
-    assert same > 0.999, same
+    # OCR selection masks are integer work: EQUALITY on every (sample, frame) row whose decisions (gumbel coin flips, the
+    # k-th / (k+1)-th boundary of both top-k selections) are separated by more than the score rounding (selection_util);
+    # rows that hinge on the last bits of a score are excluded, exact -10000 ties follow the shared lowest-index rule
+    from selection_util import decisive_ocr_rows
+    ok = decisive_ocr_rows(o_score, newm, e2, 5, F, P)
+    assert ok.float().mean().item() > 0.9, "too few decisive rows for the test to mean anything"
+    okn = ok.unsqueeze(-1).expand(B, F, P).reshape(B, N)
+    assert torch.equal(sel["pos_ocr_mask"].cpu()[okn], pos_o[okn])
+    assert torch.equal(sel["neg_ocr_mask"].cpu()[okn], neg_o[okn])
     assert sel["pos_ocr_mask"].sum(1).tolist() == [5.0 * F] * B
-    assert (sel["neg_ocr_mask"].cpu() == neg_o).float().mean().item() > 0.999
     assert sel["ground_box"].shape == (B, 5 * F, 4)
-    if same == 1.0:
-        assert torch.equal(sel["ground_box"].cpu(), box)
+    okb = ok.unsqueeze(-1).expand(B, F, 5).reshape(B, F * 5)
+    assert torch.equal(sel["ground_box"].cpu()[okb], box[okb])
+    print("decisive rows: %d of %d; all-equal masks: %s" % (int(ok.sum()), ok.numel(), torch.equal(sel["pos_ocr_mask"].cpu(), pos_o)))
 
 
 def test_embed_rows():

@@ -27,15 +27,15 @@ def test_library_exports_every_declared_symbol(lib):
     raw = ctypes.CDLL(hipext.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.t2s_abi_version() == 1
+    assert lib.t2s_abi_version() == 2
 
 
 def test_argument_validation_reports_errors(lib):
     rc = lib.t2s_gelu_fwd(None, None, 4, 0, None)
     assert rc != 0 and b"null pointer" in lib.t2s_last_error()
-    rc = lib.t2s_attn_fwd(*([ctypes.c_void_p(16)] * 5 + [None, None] + [1, 12, 0, 4, 0, 0] + [768] * 6 + [0.125, 1, 0.0, 0, None, None]))
+    rc = lib.t2s_attn_fwd(*([ctypes.c_void_p(16)] * 5 + [None, None] + [1, 12, 0, 4, 0, 0] + [768] * 6 + [0.125, 1, 0.0, 0, None]))
     assert rc != 0 and b"bad shape" in lib.t2s_last_error()
-    rc = lib.t2s_attn_fwd(*([ctypes.c_void_p(16)] * 5 + [None, None] + [1, 12, 4, 4, 0, 0] + [770] * 6 + [0.125, 1, 0.0, 0, None, None]))
+    rc = lib.t2s_attn_fwd(*([ctypes.c_void_p(16)] * 5 + [None, None] + [1, 12, 4, 4, 0, 0] + [770] * 6 + [0.125, 1, 0.0, 0, None]))
     assert rc != 0 and b"16 bytes" in lib.t2s_last_error()
 
 
@@ -66,10 +66,15 @@ def test_registry_and_boundary_surface():
     assert registry.get_loss_class("pos_bce_loss") is not None and registry.get_loss_class("InfoNCE") is not None
     groups = m.get_optimizer_parameters(training_config())
     assert len(groups) == 2 and "lr" not in groups[0] and groups[1]["lr"] == 1e-4     # [rest], [mmt @1.0*lr]
-    n_live = sum(p.numel() for g in groups for p in g["params"])
     dead = [n for n, p in m.named_parameters() if not p.requires_grad]
     assert all(is_dead_param(n) for n in dead) and len(dead) == 58
-    assert n_live == sum(p.numel() for n, p in m.named_parameters() if not is_dead_param(n))
+    # group MEMBERSHIP is the reference's (t2s.py:356-376): every parameter, the never-trained ones included, the mmt module's
+    # in the second group - so optimizer.state_dict() indices line up with reference checkpoints
+    mmt = list(m.mmt.parameters())
+    assert [id(p) for p in groups[1]["params"]] == [id(p) for p in mmt]
+    ids = {id(p) for p in mmt}
+    assert [id(p) for p in groups[0]["params"]] == [id(p) for p in m.parameters() if id(p) not in ids]
+    assert sum(len(g["params"]) for g in groups) == len(list(m.parameters()))
     s = SampleList({"text": torch.zeros(3, 20, dtype=torch.long)})
     assert s.get_batch_size() == 3 and s.text.shape == (3, 20) and SampleList([("a", 1)]).a == 1
 
@@ -100,3 +105,23 @@ def test_bench_flop_model_matches_survey_table():
         t, a = bench.flops_per_sample_fwd(F, P, 5000)
         assert abs(t - total) / total < 0.01, (F, P, t)
         assert abs(a - attn) / attn < 0.01, (F, P, a)
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher starts N ranks through torch.distributed.run (and refuses when the box has
+    fewer GPUs) - checked without a GPU through the dry-run switch."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, T2S_BENCH_DRY_SPAWN="1", T2S_BENCH_ONE_GPU="1")
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["spawn"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    env.pop("T2S_BENCH_ONE_GPU")
+    if __import__("torch").cuda.device_count() < 4:
+        out = subprocess.run([sys.executable, bench, "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 2 and "only" in out.stderr

@@ -296,3 +296,79 @@ def test_attention_bwd_fills_unlisted_rows_in_kernel(keep, drop_p):
     assert torch.equal(a, b)
     unlisted = ~valid
     assert a[:, :L1, 768:][unlisted].abs().max().item() == 0.0 if unlisted.any() else True
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_attention_bwd_survives_a_wrong_static_key_bound(dtype, drop_p):
+    """``cap_hint`` (the static bound on visible keys the model passes for the pos / neg passes, t2s.py `_three_pass`) only sizes
+    the dK/dV grid: when the real key count exceeds it - injected grounding masks, another temporal_id layout - the gradients
+    must still be those of the full key list (the tail launch / the last block's loop walks the remaining key blocks)."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    if dtype == torch.float32 and drop_p:
+        pytest.skip("covered by the bf16 case")
+    B, L1, n_dec = 2, 700, 12
+    L = L1 + n_dec
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.7).to(DEV).to(dtype)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(dtype)
+    valid = (torch.rand(B, L1, generator=g) < 0.8).to(DEV)                   # ~570 visible keys per sample
+    full = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
+    kw = dict(drop_p=drop_p, drop_seed=99) if drop_p else {}
+    out, lse = ops.attn_fwd(x, full, **kw)
+    want = ops.attn_bwd(x, out, dout, lse, full, **kw)
+    for hint in (40, 130, 300):                                            # far below the real count: 1, 2, 3 key blocks
+        wrong = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1, cap_hint=hint)
+        assert wrong.cap_hint == hint
+        got = ops.attn_bwd(x, out, dout, lse, wrong, **kw)
+        assert torch.equal(got, want), hint
+        nofill = ops.KeyList(wrong.idx, wrong.cnt, wrong.n_dec, wrong.dec_q0, hint, None)      # zero-fill path
+        assert torch.equal(ops.attn_bwd(x, out, dout, lse, nofill, **kw), want), hint
+
+
+def test_c_abi_from_two_threads():
+    """nn.DataParallel (the reference's shipped default, base_trainer.py:121-126) calls forward from one Python thread per
+    replica: the C ABI keeps no global mutable state and its error string is thread-local.  Two threads hammer different
+    kernels on their own streams; results must equal the single-threaded ones, and an argument error raised in one thread
+    must not leak into the other's t2s_last_error()."""
+    _need_gpu()
+    import threading
+    from vitxt_gqa_amd import hipext as X, ops
+    g = torch.Generator().manual_seed(23)
+    u = (torch.randn(4096, 3072, generator=g)).to(DEV).to(torch.bfloat16)
+    x = torch.randn(4096, 768, generator=g).to(DEV)
+    gam, bet = torch.ones(768, device=DEV), torch.zeros(768, device=DEV)
+    qkv = torch.randn(2, 300, 2304, generator=g).to(DEV).to(torch.bfloat16)
+    keys = ops.compact_keys(torch.ones(2, 300, dtype=torch.bool, device=DEV))
+    want_g = ops.gelu_fwd(u)
+    want_l = ops.add_layernorm_fwd(x.clone(), None, gam, bet, save=False)[0]
+    want_a = ops.attn_fwd(qkv, keys)[0]
+    torch.cuda.synchronize()
+    errs, msgs = [], {}
+
+    def worker(which):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for i in range(30):
+                    if which == 0:
+                        assert torch.equal(ops.gelu_fwd(u), want_g)
+                        assert torch.equal(ops.attn_fwd(qkv, keys)[0], want_a)
+                    else:
+                        assert torch.equal(ops.add_layernorm_fwd(x.clone(), None, gam, bet, save=False)[0], want_l)
+                        if i % 5 == 0:          # an argument error in THIS thread: rc != 0 and a message of its own
+                            rc = X.lib().t2s_gelu_fwd(None, None, 16, X.T2S_BF16, None)
+                            assert rc != 0
+                            msgs[which] = X.lib().t2s_last_error().decode()
+                st.synchronize()
+            if which == 0:
+                msgs[which] = X.lib().t2s_last_error().decode()
+        except BaseException as e:          # noqa: BLE001
+            errs.append((which, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert "gelu" in msgs[1] and "gelu" not in msgs[0], msgs

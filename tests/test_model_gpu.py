@@ -53,6 +53,20 @@ def test_forward_bf16_cfg1():
     for k in ("ref_scores", "pos_scores", "neg_scores"):
         err = (out[k].float().cpu() - fx[k]).abs().max().item()
         assert err < 1e-2, "%s max abs err %.3e" % (k, err)
+        # pointer / copy indices (north star: bit-exact): the argmax of every decoding row equals the reference's wherever the
+        # reference's own top-2 logit gap exceeds what two logits within the bf16 tolerance (1e-2 each) can close
+        flips = _index_flips(out[k].float().cpu(), fx[k], 2e-2)
+        print("%s: %d of %d argmax indices differ, all inside the bf16 tolerance" % (k, flips, fx[k].shape[0] * fx[k].shape[1]))
+
+
+def _index_flips(got, want, tol):
+    """Number of rows whose argmax differs; asserts that each of them is a near-tie of the reference (top-2 gap < tol)."""
+    gi, wi = got.argmax(-1), want.argmax(-1)
+    top2 = want.topk(2, dim=-1).values
+    gap = top2[..., 0] - top2[..., 1]
+    bad = gi != wi
+    assert (gap[bad] < tol).all(), "argmax differs on rows whose reference top-2 gap is %s (tolerance %g)" % (gap[bad].tolist(), tol)
+    return int(bad.sum())
 
 
 def test_own_selection_matches_reference_where_tie_free():
@@ -131,9 +145,27 @@ def test_cached_decode_equals_reference_loop(case, dtype, tol):
     for k in ("ref_scores", "pos_scores", "neg_scores"):
         assert (a[k] - b[k]).abs().max().item() < (1e-4 if dtype == torch.float32 else 2e-2), k
         assert (a[k].cpu() - fx["eval_" + k]).abs().max().item() < tol, k
-    if dtype == torch.float32:          # bf16 near-ties may legitimately flip an argmax
+    if dtype == torch.float32:
         assert torch.equal(pa, pb)
         assert torch.equal(a["pos_scores"].argmax(-1).cpu(), fx["eval_argmax"])
+    else:
+        # bf16 operands (the throughput dtype): greedy-decode indices against the reference's, step by step.  Row t of the
+        # final scores is the logit row that decided step t (causal decoder), so up to a sample's FIRST differing step the
+        # rows are comparable: every earlier index must be equal, and the differing one must be a near-tie of the reference
+        # (top-2 logit gap below what two logits within the 1e-2 bf16 tolerance can close).  Later steps of that sample were
+        # fed a different token and are not comparable.
+        got, want = a["pos_scores"].argmax(-1).cpu(), fx["eval_argmax"]
+        top2 = fx["eval_pos_scores"].topk(2, dim=-1).values
+        gap = top2[..., 0] - top2[..., 1]
+        flipped = 0
+        for b_ in range(got.shape[0]):
+            diff = (got[b_] != want[b_]).nonzero().flatten()
+            if diff.numel():
+                t = int(diff[0])
+                assert gap[b_, t].item() < 2e-2, "sample %d step %d: index %d vs %d at reference gap %.3e" % (
+                    b_, t, int(got[b_, t]), int(want[b_, t]), gap[b_, t].item())
+                flipped += 1
+        print("bf16 greedy decode: %d of %d samples leave the reference's index sequence (at a near-tie)" % (flipped, got.shape[0]))
 
 
 @pytest.mark.parametrize("B,F,P,V", [(1, 5, 5, 11), (3, 7, 9, 40), (2, 33, 6, 300), (2, 12, 1, 30), (2, 9, 3, 30)])
@@ -171,12 +203,25 @@ def test_ragged_inputs_match_oracle(B, F, P, V):
     f = model._last_fwd
     it = ref["_inter"]
     assert (f["frame_score"].double().cpu() - it["frame_score"]).abs().max().item() < 1e-4
-    # selections agree unless a GPU/CPU score differs by an ulp at a decision boundary: require exact equality of the
-    # frame stage (few candidates) and >= 99.5% of the OCR mask entries
+    # selection masks are integer work: the frame stage must be EQUAL (asserted to be decisive first), the OCR masks EQUAL on
+    # every (sample, frame) row whose decisions are separated by more than the fp32-vs-fp64 score difference (selection_util)
+    from selection_util import decisive_frames, decisive_ocr_rows
+    d_sc = (f["ocr_score"].double().cpu() - it["ocr_score"]).abs()
+    d_sc = d_sc[it["new_ocr_mask"] != 0].max().item() if (it["new_ocr_mask"] != 0).any() else 0.0
+    tol = max(2e-6, 4 * d_sc)
+    fm = batch["frame_mask"].double()
+    ok_f = decisive_frames(it["frame_score"], fm, e1, 5, tol=max(2e-6, 4 * (f["frame_score"].double().cpu() - it["frame_score"]).abs().max().item()))
+    assert ok_f.all(), "fixture seed gives a fragile frame selection; pick another seed"
     assert torch.equal(f["pos_obj_mask"].cpu().double(), it["pos_obj_mask"])
+    assert torch.equal(f["neg_obj_mask"].cpu().double(), it["neg_obj_mask"])
     assert torch.equal(out["ground_frame"].cpu(), ref["ground_frame"])
+    assert torch.equal(f["new_ocr_mask"].cpu().double(), it["new_ocr_mask"])
+    ok = decisive_ocr_rows(it["ocr_score"], it["new_ocr_mask"], e2, 5, F, P, tol=tol)
+    assert ok.float().mean().item() > 0.8
+    okn = ok.unsqueeze(-1).expand(B, F, P).reshape(B, F * P)
+    assert torch.equal(f["pos_ocr_mask"].cpu().double()[okn], it["pos_ocr_mask"][okn])
+    assert torch.equal(f["neg_ocr_mask"].cpu().double()[okn], it["neg_ocr_mask"][okn])
     agree = (f["pos_ocr_mask"].cpu().double() == it["pos_ocr_mask"]).double().mean().item()
-    assert agree > 0.995
     same_neg = (torch.equal(f["neg_ocr_mask"].cpu().double(), it["neg_ocr_mask"])
                 and torch.equal(f["neg_obj_mask"].cpu().double(), it["neg_obj_mask"]))
     if agree == 1.0 and same_neg:

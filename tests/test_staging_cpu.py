@@ -60,3 +60,20 @@ def test_collate_rejects_wrong_batch_size():
     import pytest
     with pytest.raises(ValueError):
         st.collate(_samples(make_batch(3, 3, 2, V=30, seed=0)))
+
+
+def test_prefetch_surfaces_loader_errors_and_needs_two_slots():
+    """A failure in the loader thread (fill / collate / upload) is re-raised in the consumer instead of replaying the previous,
+    already released batch; a ring of one slot cannot prefetch."""
+    import pytest
+    from vitxt_gqa_amd.staging import ArenaLayout, BatchStager
+    good = {"a": torch.arange(6, dtype=torch.float32).view(2, 3)}
+    st = BatchStager(ArenaLayout.from_batch(good), device="cpu", depth=2)
+    bad = {"a": torch.zeros(2, 4)}                      # wrong shape: copy_ into the pinned view raises in the loader thread
+    seen = []
+    with pytest.raises(RuntimeError, match="loader thread failed"):
+        for d in st.prefetch([good, bad, good]):
+            seen.append(d["a"].clone())
+    assert len(seen) == 1 and torch.equal(seen[0], good["a"])
+    with pytest.raises(ValueError):
+        next(BatchStager(ArenaLayout.from_batch(good), device="cpu", depth=1).prefetch([good]))

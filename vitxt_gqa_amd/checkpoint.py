@@ -3,7 +3,9 @@
 The reference writes ``torch.save({"model": state_dict, "optimizer": ..., "best_iteration": ..., "best_metric_value": ...,
 "config": ...})`` (``pythia/utils/checkpoint.py:226-240``) and, when loading, accepts a bare state_dict as well, strips one
 leading ``module.`` left by DataParallel / DDP and renames ``fa_history`` -> ``fa_context`` (``checkpoint.py:90-111``).  The
-parameter names of this build's T2S are the reference's (``vitxt_gqa_amd/schema.py``), so the tensors load unchanged.
+parameter names of this build's T2S are the reference's (``vitxt_gqa_amd/schema.py``), so the tensors load unchanged; the
+optimizer's param groups list every parameter in the reference's order (``T2S.get_optimizer_parameters``: the frozen dead
+parameters included), so ``optimizer.state_dict()`` indices agree with the reference's too and its checkpoints resume.
 """
 import torch
 
@@ -32,7 +34,7 @@ def load_checkpoint(path_or_obj, model=None, optimizer=None, strict=True, map_lo
     if model is not None:
         target = model.module if hasattr(model, "module") and not hasattr(model, "get_optimizer_parameters") else model
         target.load_state_dict(ck["model"], strict=strict)
-    if optimizer is not None and "optimizer" in ck:
+    if optimizer is not None and ck.get("optimizer") is not None:     # save_checkpoint writes None when it was given no optimizer
         optimizer.load_state_dict(ck["optimizer"])
     return ck
 

@@ -302,11 +302,12 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_f32_kernel(AttnParams p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
   const int nk = n_prefix + p.n_dec;
-  const int kp0 = blockIdx.x * 128;
-  if (kp0 >= nk) return;
+  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
+  // the last key block of the grid (sized from the static bound max_keys) continues while the list has more keys: a bound
+  // that does not hold costs time, never gradients
+  for (int kp0 = blockIdx.x * 128; kp0 < nk; kp0 = (blockIdx.x == gridDim.x - 1) ? kp0 + 128 : 0x3fffff00) {
   const int kpos = kp0 + wave * 32 + lr;
   const bool kvalid = kpos < nk;
-  const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
   const int kclamp = kvalid ? kpos : nk - 1;
   const int64_t krow = USE_IDX ? (int64_t)idx[kclamp] : (int64_t)kclamp;
   const float* __restrict__ Q = reinterpret_cast<const float*>(p.q) + (int64_t)b * p.q_bs + h * 64;
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_f32_kernel(AttnParams p) {
         *reinterpret_cast<f32x4*>(dvp + d) = v4;
       }
   }
+  }   // key blocks of this workgroup
 }
 
 template <bool USE_IDX>
@@ -507,7 +509,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
                          float* delta, void* dq, void* dk, void* dv, const int32_t* kv_idx, const int32_t* kv_cnt, int B,
                          int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys, int64_t q_row_stride, int64_t q_batch_stride,
                          int64_t kv_row_stride, int64_t kv_batch_stride, int64_t o_row_stride, int64_t o_batch_stride,
-                         float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, const uint8_t* row_valid,
+                         float scale, int dtype, float drop_p, uint64_t drop_seed, const uint8_t* row_valid,
                          t2s_stream_t stream) {
   T2S_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
   T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "attn_bwd: bad dtype %d", dtype);
@@ -531,7 +533,6 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   p.o_rs = o_row_stride; p.o_bs = o_batch_stride; p.scale = scale;
   p.row_valid = row_valid; p.valid_len = idx_cap - n_dec;
   hipStream_t st = (hipStream_t)stream;
-  (void)drop_ws;
   if (int e = attn_setup_dropout(p, drop_p, drop_seed, st, "attn_bwd")) return e;
   const int64_t rows = (int64_t)B * Lq;
   dim3 gd((unsigned)((rows + 3) / 4)), blk(256);
@@ -565,9 +566,9 @@ extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const v
                             float* delta, void* dq, void* dk, void* dv, const int32_t* kv_idx, const int32_t* kv_cnt, int B,
                             int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys, int64_t q_row_stride, int64_t q_batch_stride,
                             int64_t kv_row_stride, int64_t kv_batch_stride, int64_t o_row_stride, int64_t o_batch_stride,
-                            float scale, int dtype, float drop_p, uint64_t drop_seed, uint32_t* drop_ws, t2s_stream_t stream) {
+                            float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
   return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
-                       q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed, drop_ws,
+                       q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed,
                        nullptr, stream);
 }
 
@@ -581,6 +582,6 @@ extern "C" int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, co
   T2S_CHECK_ARG(dtype == T2S_BF16, "attn_bwd_fill: bf16 only (the fp32 kernels leave unlisted rows to the caller)");
   T2S_CHECK_ARG(Lq == idx_cap, "attn_bwd_fill: self-attention layout expected (query rows = prefix rows + decoder rows)");
   return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
-                       q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed, nullptr,
+                       q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed,
                        row_valid, stream);
 }

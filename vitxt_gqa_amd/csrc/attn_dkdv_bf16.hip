@@ -12,12 +12,7 @@
 
 #include "attn_common.h"
 
-// sweep form: -DT2S_DKDV_STAGED selects the staged wavefront (attn_dkdv_bf16_sweep_staged.inc)
-#ifdef T2S_DKDV_STAGED
-#define T2S_DKDV_SWEEP "attn_dkdv_bf16_sweep_staged.inc"
-#else
 #define T2S_DKDV_SWEEP "attn_dkdv_bf16_sweep.inc"
-#endif
 
 namespace {
 
@@ -32,18 +27,25 @@ constexpr int STAGE = 2 * TILE + 2 * QROWS * 4 + (QROWS / 2) * 4;   // Q | dO | 
 #ifndef T2S_DKDV_NW
 #define T2S_DKDV_NW 4
 #endif
-template <bool USE_IDX, bool DROP, int NW>
+template <bool USE_IDX, bool DROP, int NW, bool TAIL>
 __global__ __launch_bounds__(64 * NW, 2) void attn_dkdv_bf16_kernel(AttnParams p) {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   constexpr int KEYS = 32 * NW;                    // keys per workgroup
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   int kblk, h, b;
-  if (!attn_xcd_tile(p.kblocks, p.H, p.B, kblk, h, b)) return;                    // workgroup-uniform (attn_common.h)
+  if (!attn_xcd_tile(TAIL ? 1 : p.kblocks, p.H, p.B, kblk, h, b)) return;         // workgroup-uniform (attn_common.h)
   const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
   const int nk = n_prefix + p.n_dec;
-  const int kp0 = kblk * KEYS;
-  if (kp0 >= nk) return;                                   // uniform per workgroup
+  // The main grid covers p.kblocks key blocks per (sample, head): a host-side STATIC bound on the key count (max_keys).  A
+  // second, one-workgroup-per-(sample, head) TAIL launch of the same kernel walks whatever key blocks lie beyond it, so a
+  // bound that does not hold (injected grounding masks, a dataset whose temporal ids do not follow the P-slots-per-frame
+  // layout) costs time, never gradients; where the bound holds the tail workgroups exit at once.  (As a loop inside the main
+  // kernel the same guarantee spilled 6 VGPRs in the dropout variants.)
+  int kb = TAIL ? p.kblocks : kblk;
+  if (kb * KEYS >= nk) return;                             // uniform per workgroup
+  do {
+  const int kp0 = kb * KEYS;
   const int kpos = kp0 + wave * 32 + lr;                   // this lane's key position (column)
   const bool kvalid = kpos < nk;
   const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_dkdv_bf16_kernel(AttnParams p
         *reinterpret_cast<bf16x4*>(dvp + d) = v4;
       }
   }
+  } while (TAIL && (++kb) * KEYS < nk);   // key blocks of this workgroup (TAIL == false: exactly one, no loop is compiled)
 }
 
 }  // namespace
@@ -189,11 +192,17 @@ void launch_attn_dkdv_bf16(const AttnParams& p_in, int max_keys, hipStream_t st)
   AttnParams p = p_in;
   p.kblocks = (max_keys + 32 * NW - 1) / (32 * NW);
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(64 * NW);      // XCD-aware 1-D grid (attn_common.h)
+  dim3 tail(attn_xcd_grid(1, p.H, p.B));
+  const bool need_tail = p.kv_idx != nullptr && p.kblocks * 32 * NW < p.idx_cap;      // a dense list's length is known exactly
   if (p.drop_thresh) {
-    if (p.kv_idx) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, true, NW>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, true, NW>), grid, block, 0, st, p);
+    if (p.kv_idx) {
+      hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, true, NW, false>), grid, block, 0, st, p);
+      if (need_tail) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, true, NW, true>), tail, block, 0, st, p);
+    } else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, true, NW, false>), grid, block, 0, st, p);
   } else {
-    if (p.kv_idx) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, false, NW>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, false, NW>), grid, block, 0, st, p);
+    if (p.kv_idx) {
+      hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, false, NW, false>), grid, block, 0, st, p);
+      if (need_tail) hipLaunchKernelGGL((attn_dkdv_bf16_kernel<true, false, NW, true>), tail, block, 0, st, p);
+    } else hipLaunchKernelGGL((attn_dkdv_bf16_kernel<false, false, NW, false>), grid, block, 0, st, p);
   }
 }

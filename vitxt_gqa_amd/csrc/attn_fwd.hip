@@ -208,7 +208,7 @@ int check_common(const AttnParams& p, int dtype) {
 }  // namespace
 
 // shared by the forward / backward entry points: validates the dropout arguments and fills the params.  The mask is a
-// stateless function of the seed (attn_common.h); the drop_ws workspace of earlier ABI versions is no longer used.
+// stateless function of the seed (attn_common.h); no workspace.
 int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, hipStream_t st, const char* who) {
   (void)st;
   p.drop_seed_lo = p.drop_seed_hi = 0;
@@ -225,12 +225,11 @@ int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, hipStrea
   return 0;
 }
 
-extern "C" int t2s_attn_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p, uint64_t drop_seed, uint32_t* drop_ws,
+extern "C" int t2s_attn_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p, uint64_t drop_seed,
                                      t2s_stream_t stream) {
   T2S_CHECK_ARG(out && B > 0 && H > 0 && Lq > 0 && Lk > 0 && B <= 65535 && H <= 65535, "attn_dropout_mask: bad arguments");
   AttnParams p = {};
   p.B = B; p.H = H; p.Lq = Lq;
-  (void)drop_ws;
   if (int e = attn_setup_dropout(p, drop_p, drop_seed, (hipStream_t)stream, "attn_dropout_mask")) return e;
   T2S_CHECK_ARG(p.drop_thresh != 0, "attn_dropout_mask: drop_p must be > 0");
   hipLaunchKernelGGL(attn_drop_mask_kernel, dim3(Lq, H, B), dim3(256), 0, (hipStream_t)stream, out, p.drop_seed_lo, p.drop_seed_hi, H, Lq, Lk,
@@ -252,7 +251,7 @@ extern "C" int t2s_attn_fwd(const void* q, const void* k, const void* v, void* o
                             const int32_t* kv_cnt, int B, int H, int Lq, int idx_cap, int n_dec, int dec_q0,
                             int64_t q_row_stride, int64_t q_batch_stride, int64_t kv_row_stride, int64_t kv_batch_stride,
                             int64_t o_row_stride, int64_t o_batch_stride, float scale, int dtype, float drop_p, uint64_t drop_seed,
-                            uint32_t* drop_ws, t2s_stream_t stream) {
+                            t2s_stream_t stream) {
   T2S_CHECK_ARG(q && k && v && out && lse, "attn_fwd: null pointer");
   AttnParams p = {};
   p.q = q; p.k = k; p.v = v; p.out = out; p.lse = lse; p.kv_idx = kv_idx; p.kv_cnt = kv_cnt;
@@ -262,7 +261,6 @@ extern "C" int t2s_attn_fwd(const void* q, const void* k, const void* v, void* o
   if (int e = check_common(p, dtype)) return e;
   dim3 grid((Lq + BQ - 1) / BQ, H, B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  (void)drop_ws;
   if (int e = attn_setup_dropout(p, drop_p, drop_seed, st, "attn_fwd")) return e;
   if (dtype == T2S_BF16) {
     launch_attn_fwd_bf16(p, st);

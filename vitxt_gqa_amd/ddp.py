@@ -30,7 +30,13 @@ def shard_range(n_items, rank, world_size):
 
 
 class GradBuckets:
-    def __init__(self, params, bucket_bytes=48 << 20, group=None, average=True):
+    def __init__(self, params, bucket_bytes=48 << 20, group=None, average=True, names=None):
+        """``params``: parameters, or (name, parameter) pairs as from ``named_parameters()`` (names only serve error messages)."""
+        params = list(params)
+        self._names = {}
+        if params and isinstance(params[0], tuple):
+            self._names = {id(p): n for n, p in params}
+            params = [p for _, p in params]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.average = average
@@ -85,6 +91,21 @@ class GradBuckets:
         self._handles = []
 
     def finish(self):
+        """Wait for the outstanding collectives.  Every bucket must have been launched: a requires_grad parameter that got
+        no gradient this iteration (a new unused parameter, a partial backward, an eval-style branch) would leave its bucket
+        un-reduced and the ranks would step on different gradients - refuse instead of diverging silently (the reference
+        pays for the same guarantee with ``find_unused_parameters=True``, base_trainer.py:134-137)."""
+        if self.world > 1 and any(self._pending):
+            missing = [i for i, c in enumerate(self._pending) if c]
+            names = []
+            for bi in missing:
+                names += [self._names.get(id(p), "<%s>" % "x".join(map(str, p.shape))) for p in self.buckets[bi][1]]
+            for h in self._handles:
+                h.wait()
+            self._handles = []
+            raise RuntimeError("GradBuckets.finish(): %d of %d gradient buckets were never all-reduced: %d parameter(s) of them "
+                               "produced no gradient this iteration (candidates: %s)" % (len(missing), len(self.buckets),
+                                                                                         sum(self._pending), ", ".join(names[:8])))
         for h in self._handles:
             h.wait()
         self._handles = []

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2S_HIP_LIB") or os.path.join(_HERE, "libt2s_hip.so")      # override: kernel build experiments only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 T2S_F32, T2S_BF16 = 0, 1
 
@@ -20,9 +20,9 @@ _SIGS = {
     "t2s_abi_version": (c_int, []),
     "t2s_last_error": (c_char_p, []),
     "t2s_compact_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "t2s_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_int64] * 6 + [c_float, c_int, c_float, c_uint64, c_void_p, c_void_p]),
-    "t2s_attn_dropout_mask": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_uint64, c_void_p, c_void_p]),
-    "t2s_attn_bwd": (c_int, [c_void_p] * 12 + [c_int] * 7 + [c_int64] * 6 + [c_float, c_int, c_float, c_uint64, c_void_p, c_void_p]),
+    "t2s_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_int64] * 6 + [c_float, c_int, c_float, c_uint64, c_void_p]),
+    "t2s_attn_dropout_mask": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_uint64, c_void_p]),
+    "t2s_attn_bwd": (c_int, [c_void_p] * 12 + [c_int] * 7 + [c_int64] * 6 + [c_float, c_int, c_float, c_uint64, c_void_p]),
     "t2s_attn_bwd_fill": (c_int, [c_void_p] * 13 + [c_int] * 7 + [c_int64] * 6 + [c_float, c_int, c_float, c_uint64, c_void_p]),
     "t2s_add_layernorm_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_float, c_int, c_int, c_float, c_uint64, c_void_p]),
     "t2s_add_layernorm_fwd_nres": (c_int, [c_void_p] * 11 + [c_int64, c_float, c_int, c_int, c_float, c_uint64, c_void_p]),

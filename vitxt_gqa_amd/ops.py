@@ -12,6 +12,9 @@ from . import hipext as X
 HID = 768
 HEADS = 12
 HEAD_DIM = 64
+# matrix products per (query, key) pair the attention backward EXECUTES: the algorithm needs 5 (S, dP, dV, dK, dQ); the
+# two-kernel form (key-stationary dK/dV + query-stationary dQ, no atomics) recomputes S and dP: 7.  bench.py reports both.
+ATTN_BWD_PRODUCTS = 7
 
 
 def _rows768(t):
@@ -50,15 +53,10 @@ def _attn_views(qkv):
     return qkv[..., :HID], qkv[..., HID:2 * HID], qkv[..., 2 * HID:]
 
 
-def _drop_ws(B, L, drop_p, device):
-    return None      # the dropout mask is a stateless function of the seed: no workspace (include/t2s_hip.h)
-
-
 def attn_dropout_mask(B, Lq, Lk, drop_p, drop_seed, device):
     """[B, 12, Lq, Lk] 0/1 keep mask of the attention-probability dropout (Lk = key-list positions); tests."""
     out = torch.empty(B, HEADS, Lq, Lk, dtype=torch.uint8, device=device)
-    ws = _drop_ws(B, Lq, drop_p, device)
-    X.check(X.lib().t2s_attn_dropout_mask(X.ptr(out), B, HEADS, Lq, Lk, float(drop_p), int(drop_seed), X.ptr(ws), X.stream()),
+    X.check(X.lib().t2s_attn_dropout_mask(X.ptr(out), B, HEADS, Lq, Lk, float(drop_p), int(drop_seed), X.stream()),
             "t2s_attn_dropout_mask")
     return out
 
@@ -74,7 +72,7 @@ def attn_fwd(qkv, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0):
         X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(lse), X.ptr(keys.idx), X.ptr(keys.cnt),
         B, HEADS, L, keys.idx.shape[1], keys.n_dec, keys.dec_q0,
         qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
-        scale, X.dtype_code(qkv), float(drop_p), int(drop_seed), X.ptr(_drop_ws(B, L, drop_p, qkv.device)), X.stream()),
+        scale, X.dtype_code(qkv), float(drop_p), int(drop_seed), X.stream()),
         "t2s_attn_fwd")
     return out, lse
 
@@ -101,7 +99,7 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     if fill_in_kernel:
         X.check(X.lib().t2s_attn_bwd_fill(*head, X.ptr(keys.valid8), *dims, X.stream()), "t2s_attn_bwd_fill")
     else:
-        X.check(X.lib().t2s_attn_bwd(*head, *dims, X.ptr(_drop_ws(B, L, drop_p, qkv.device)), X.stream()), "t2s_attn_bwd")
+        X.check(X.lib().t2s_attn_bwd(*head, *dims, X.stream()), "t2s_attn_bwd")
     return dqkv
 
 
@@ -121,7 +119,7 @@ def attn_fwd_rows(q_rows, kv_buf, keys, scale=1.0 / 8.0):
         X.ptr(q_rows), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(lse), X.ptr(keys.idx), X.ptr(keys.cnt),
         B, HEADS, Lq, keys.idx.shape[1], keys.n_dec, 0,
         q_rows.stride(1), q_rows.stride(0), kv_buf.stride(1), kv_buf.stride(0), out.stride(1), out.stride(0),
-        scale, X.dtype_code(kv_buf), 0.0, 0, None, X.stream()), "t2s_attn_fwd")
+        scale, X.dtype_code(kv_buf), 0.0, 0, X.stream()), "t2s_attn_fwd")
     return out
 
 

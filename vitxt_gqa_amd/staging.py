@@ -110,6 +110,8 @@ class BatchStager:
     def __init__(self, layout, device="cuda:0", depth=2, device_only=None, post_upload=()):
         """``device_only``: spec {name: (shape, dtype)} of fields that exist only in the device arena; ``post_upload``:
         callables ``f(dev_views)`` run on the copy stream after the H2D copy (they fill the device-only fields)."""
+        if depth < 1:
+            raise ValueError("BatchStager needs at least one arena slot")
         self.layout = layout
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -194,22 +196,30 @@ class BatchStager:
         while the caller works on batch i.  ``batches`` yields stacked host batches (``stacked=True``) or lists of
         per-sample dicts.  Each yielded batch has been ``wait()``-ed on the current stream; it is released when the next
         one is requested."""
+        if len(self.slots) < 2:
+            raise ValueError("prefetch() needs a ring of depth >= 2: the next batch is uploaded while the current one is in use")
         it = iter(batches)
         box = {}
 
         def produce():
+            box.clear()                               # never leave the previous (already released) batch behind
             try:
-                b = next(it)
-            except StopIteration:
-                box["next"] = None
-                return
-            slot = self.fill(b) if stacked else self.collate(b)
-            box["next"] = self.upload(slot)
+                try:
+                    b = next(it)
+                except StopIteration:
+                    box["next"] = None
+                    return
+                slot = self.fill(b) if stacked else self.collate(b)
+                box["next"] = self.upload(slot)
+            except BaseException as e:                # fill / collate / upload failed: hand the error to the consumer
+                box["error"] = e
 
         th = threading.Thread(target=produce)
         th.start()
         while True:
             th.join()
+            if "error" in box:
+                raise RuntimeError("BatchStager.prefetch: the loader thread failed") from box["error"]
             cur = box.get("next")
             if cur is None:
                 return
@@ -217,8 +227,10 @@ class BatchStager:
             th.start()
             if self.cuda:
                 cur.wait()
-            yield cur
-            cur.release()
+            try:
+                yield cur
+            finally:
+                cur.release()
 
 
 def phoc_expander(slots_field="ocr_token_slots", out_field="context_feature_1"):

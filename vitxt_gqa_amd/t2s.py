@@ -509,13 +509,15 @@ class T2S(BaseModel):
 
     # -- optimizer hook (t2s.py:356-376) -------------------------------------------------------------
     def get_optimizer_parameters(self, config):
+        """Group MEMBERSHIP is the reference's (every parameter, the frozen dead ones included: they never get a gradient, so
+        Adam skips them there and here), which keeps ``optimizer.state_dict()`` index-compatible with reference checkpoints."""
         groups = []
         base_lr = config.optimizer_attributes.params.lr
         finetune = set()
         for m in self.finetune_modules:
-            ps = [p for p in m["module"].parameters() if p.requires_grad]
+            ps = list(m["module"].parameters())
             groups.append({"params": ps, "lr": base_lr * m["lr_scale"]})
             finetune.update(ps)
-        remaining = [p for p in self.parameters() if p.requires_grad and p not in finetune]
+        remaining = [p for p in self.parameters() if p not in finetune]
         groups.insert(0, {"params": remaining})
         return groups
