@@ -1,6 +1,6 @@
 """``BaseModel`` contract of ``pythia/models/base_model.py:53-149``: ``build()``,
-``init_losses_and_metrics()``, ``forward(sample_list) -> dict`` and ``__call__`` appending ``losses``
-(and an empty ``metrics`` dict: the metric evaluators are host-side string/IoU code outside the hot path)."""
+``init_losses_and_metrics()``, ``forward(sample_list) -> dict`` and ``__call__`` appending ``losses`` and ``metrics``
+(the yml ``metrics`` list through ``metrics.Metrics``: host-side string / IoU evaluators, as in the reference)."""
 import collections
 
 from torch import nn
@@ -20,7 +20,8 @@ class BaseModel(nn.Module):
     def init_losses_and_metrics(self):
         from .losses import Losses
         self.losses = Losses(self.config.get("losses", []))
-        self.metrics = lambda sample_list, model_output: {}
+        from .metrics import Metrics
+        self.metrics = Metrics(self.config.get("metrics", []))
 
     def forward(self, sample_list, *args, **kwargs):
         raise NotImplementedError("Forward of the child model class needs to be implemented.")

@@ -270,3 +270,145 @@ class BoxGroundAccuracy:
     def calculate(self, sample_list, model_output):
         _, acc = self.evaluator.eval_pred_list([], self.entries(sample_list, model_output), threshold=self.threshold)
         return torch.tensor(acc, device=model_output["ground_frame"].device)
+
+
+# ---- the ``Metrics`` container that ``BaseModel.__call__`` runs (pythia/modules/metrics.py:56-134, base_model.py:78-149) -----
+def dec_bytes2obj(byte_tensor):
+    """``pythia/utils/objects_to_byte_tensor.py:33-43``: a pickled object in a uint8 tensor, 2-byte big-endian length first
+    (how ``context_tokens_enc`` / ``gt_answers_enc`` travel through the collate function)."""
+    import pickle
+    b = byte_tensor.tolist() if torch.is_tensor(byte_tensor) else list(byte_tensor)
+    n = int(b[0]) * 256 + int(b[1])
+    return pickle.loads(bytes(int(x) for x in b[2:2 + n]))
+
+
+def enc_obj2bytes(obj, max_size=16384):
+    """Inverse of ``dec_bytes2obj`` (objects_to_byte_tensor.py:11-30)."""
+    import pickle
+    enc = pickle.dumps(obj)
+    if len(enc) > max_size:
+        raise ValueError("objects too large: object size %d, max size %d" % (len(enc), max_size))
+    t = torch.zeros(max_size, dtype=torch.uint8)
+    t[0], t[1] = len(enc) // 256, len(enc) % 256
+    t[2:2 + len(enc)] = torch.tensor(list(enc), dtype=torch.uint8)
+    return t
+
+
+def _batch_objects(sample_list, enc_key, plain_key):
+    """Per-sample python objects of a batch: the pickled byte tensors the reference's dataset emits (``*_enc``), or plain lists."""
+    if enc_key in sample_list:
+        enc = sample_list[enc_key]
+        enc = enc.cpu() if torch.is_tensor(enc) else enc
+        return [dec_bytes2obj(row) for row in enc]
+    return sample_list[plain_key]
+
+
+class _RegistryAnswerMetric:
+    """``textvqa_accuracy`` / ``stvqa_anls`` as the reference registers them: no constructor arguments, the answer processor
+    (vocabulary, EOS index, true vocabulary size) comes from ``registry.get(dataset_name + "_answer_processor")`` at call time
+    (metrics.py:175-231)."""
+    evaluator_cls = None
+
+    def __init__(self):
+        self.evaluator = self.evaluator_cls()
+
+    def calculate(self, sample_list, model_output, *args, **kwargs):
+        from .registry import registry
+        ap = registry.get(sample_list["dataset_name"] + "_answer_processor")
+        vocab_size = ap.get_true_vocab_size()
+        pred = model_output["pos_scores"].argmax(dim=-1)
+        tokens = _batch_objects(sample_list, "context_tokens_enc", "context_tokens")
+        gts = _batch_objects(sample_list, "gt_answers_enc", "gt_answers")
+        tok = getattr(ap, "word_tokenize", None) or (lambda w: w)
+        answers = decode_answers(pred, tokens, _Idx2Word(ap.answer_vocab), vocab_size, ap.EOS_IDX, tok)
+        entries = [{"pred_answer": a, "gt_answers": g} for a, g in zip(answers, gts)]
+        _, acc = self.evaluator.eval_pred_list([], entries)
+        return torch.tensor(acc, device=model_output["pos_scores"].device)
+
+    _calculate_with_checks = calculate
+    __call__ = calculate
+
+
+class _Idx2Word:
+    def __init__(self, vocab):
+        self.v = vocab
+
+    def __getitem__(self, i):
+        return self.v.idx2word(i) if hasattr(self.v, "idx2word") else self.v[i]
+
+
+def _register_default_metrics():
+    from .registry import registry
+
+    @registry.register_metric("textvqa_accuracy")
+    class RegisteredTextVQAAccuracy(_RegistryAnswerMetric):
+        name = "textvqa_accuracy"
+        evaluator_cls = TextVQAAccuracyEvaluator
+
+    @registry.register_metric("stvqa_anls")
+    class RegisteredSTVQAANLS(_RegistryAnswerMetric):
+        name = "stvqa_anls"
+        evaluator_cls = STVQAANLSEvaluator
+
+    for thr in (0.3, 0.5):
+        def make(thr=thr):
+            class RegisteredIOU:
+                """``IOU@t`` (metrics.py:233-339): the grounding annotation is taken from ``registry.get("ground_annotation")``
+                (a list of dicts; the reference reads a hard-coded .npy path, metrics.py:250-254)."""
+                name = "IOU@%s" % thr
+
+                def calculate(self, sample_list, model_output, *args, **kwargs):
+                    info = registry.get("ground_annotation")
+                    if info is None:
+                        raise RuntimeError("metric IOU@%s needs registry key 'ground_annotation' (list of dicts with question_id, "
+                                           "spatial_temporal_gt, fps, width, height)" % thr)
+                    return BoxGroundAccuracy(info, thr).calculate(sample_list, model_output)
+
+                _calculate_with_checks = calculate
+            return RegisteredIOU
+        registry.register_metric("IOU@%s" % thr)(make())
+
+
+class Metrics:
+    """``pythia/modules/metrics.py:56-134``: built from the yml ``metrics`` list (names or {type, params} dicts); called by
+    ``BaseModel.__call__`` with (sample_list, model_output); returns {"<dataset_type>/<dataset_name>/<metric>": 1-element float
+    tensor}.  Kept quirks: nothing is computed when the batch has no ``targets``; after the first TRAIN batch only
+    textvqa_accuracy / stvqa_anls survive (Appendix A, Q16: the reference reassigns ``self.metrics`` permanently); the values
+    are also published as ``registry["metrics.<dataset_name>.<dataset_type>"]``."""
+
+    def __init__(self, metric_list):
+        from .registry import registry
+        _register_default_metrics()
+        if not isinstance(metric_list, (list, tuple)):
+            metric_list = [metric_list]
+        self.metrics = {}
+        for metric in metric_list:
+            params = {}
+            if isinstance(metric, dict) or hasattr(metric, "keys"):
+                if "type" not in metric:
+                    raise ValueError("Metric {} needs to have 'type' attribute".format(metric))
+                params = dict(metric.get("params", {}))
+                metric = metric["type"]
+            elif not isinstance(metric, str):
+                raise TypeError("Metric {} has inappropriate type 'dict' or 'str' allowed".format(metric))
+            cls = registry.get_metric_class(metric)
+            if cls is None:
+                raise ValueError("No metric named {} registered to registry".format(metric))
+            self.metrics[metric] = cls(**params)
+
+    def __call__(self, sample_list, model_output, *args, **kwargs):
+        from .registry import registry
+        values = {}
+        if "targets" not in sample_list:
+            return values
+        dataset_type, dataset_name = sample_list["dataset_type"], sample_list["dataset_name"]
+        with torch.no_grad():
+            if dataset_type == "train":
+                self.metrics = {k: v for k, v in self.metrics.items() if k in {"textvqa_accuracy", "stvqa_anls"}}
+            for name, obj in self.metrics.items():
+                key = "{}/{}/{}".format(dataset_type, dataset_name, name)
+                v = obj._calculate_with_checks(sample_list, model_output, *args, **kwargs)
+                v = v.float() if torch.is_tensor(v) else torch.tensor(v, dtype=torch.float)
+                values[key] = v.view(1) if v.dim() == 0 else v
+        registry.register("{}.{}.{}".format("metrics", dataset_name, dataset_type), values)
+        return values

@@ -1,11 +1,11 @@
 """Host-side mirror of the slice of ``pythia/common/registry.py`` the T2S path touches
-(``register_model`` :159-185, ``register_loss``, ``register``/``get`` :232-321, ``get_model_class``,
-``get_loss_class``).  Same names and argument meaning, so the model file reads like the reference's
+(``register_model`` :159-185, ``register_loss``, ``register_metric`` :101-127, ``register``/``get`` :232-321,
+``get_model_class``, ``get_loss_class``, ``get_metric_class``).  Same names and argument meaning, so the model file reads like the reference's
 and can be pointed at the reference's own registry instead."""
 
 
 class Registry:
-    mapping = {"model_name_mapping": {}, "loss_name_mapping": {}, "optimizer_name_mapping": {}, "state": {}}
+    mapping = {"model_name_mapping": {}, "loss_name_mapping": {}, "metric_name_mapping": {}, "optimizer_name_mapping": {}, "state": {}}
 
     @classmethod
     def register_model(cls, name):
@@ -21,6 +21,13 @@ class Registry:
         def wrap(loss_cls):
             cls.mapping["loss_name_mapping"][name] = loss_cls
             return loss_cls
+        return wrap
+
+    @classmethod
+    def register_metric(cls, name):
+        def wrap(metric_cls):
+            cls.mapping["metric_name_mapping"][name] = metric_cls
+            return metric_cls
         return wrap
 
     @classmethod
@@ -53,6 +60,10 @@ class Registry:
     @classmethod
     def get_loss_class(cls, name):
         return cls.mapping["loss_name_mapping"].get(name, None)
+
+    @classmethod
+    def get_metric_class(cls, name):
+        return cls.mapping["metric_name_mapping"].get(name, None)
 
     @classmethod
     def get_optimizer_class(cls, name):

@@ -103,6 +103,30 @@ class TextBert(nn.Module):
         _dropout_cfg(self, config)
         _bert_init(self)
 
+    def load_pretrained(self, state_dict, strict=True):
+        """``TextBert.from_pretrained('bert-base-uncased', config=...)`` of the reference (t2s.py:47-56; the loader is the
+        third-party ``BertPreTrainedModel.from_pretrained``): from a Hugging Face BERT checkpoint's state_dict take the
+        embeddings and the FIRST ``num_hidden_layers`` encoder layers (3 in configs/t2s_abinet.yml); layers 3..11, the pooler
+        and the pre-training heads are ignored.  Accepted key spellings: with or without the ``bert.`` prefix, and the
+        old TF-style ``LayerNorm.gamma / .beta``.  Returns the list of checkpoint keys that were used."""
+        own = self.state_dict()
+        picked = {}
+        for k, v in state_dict.items():
+            k2 = k[5:] if k.startswith("bert.") else k
+            if k2.endswith("LayerNorm.gamma"):
+                k2 = k2[:-5] + "weight"
+            elif k2.endswith("LayerNorm.beta"):
+                k2 = k2[:-4] + "bias"
+            if k2 in own:
+                if tuple(v.shape) != tuple(own[k2].shape):
+                    raise ValueError("pretrained tensor %s has shape %s, text_bert expects %s" % (k, tuple(v.shape), tuple(own[k2].shape)))
+                picked[k2] = v
+        missing = [k for k in own if k not in picked]
+        if missing and strict:
+            raise KeyError("pretrained BERT state_dict lacks %d text_bert tensors, e.g. %s" % (len(missing), missing[:4]))
+        self.load_state_dict(picked, strict=False)
+        return sorted(picked)
+
     def forward(self, txt_inds, txt_mask, dtype):
         e = self.embeddings
         L = txt_inds.size(1)
@@ -328,8 +352,10 @@ class T2S(BaseModel):
         self.finetune_modules = []
         self.text_bert = TextBert(c.text_bert)
         if c.get("text_bert_init_from_bert_base", False):
-            # the reference loads ../../huggingface/bert-base-uncased (t2s.py:47-56): load those three layers
-            # through load_state_dict; the smaller learning rate is kept
+            # t2s.py:47-56: TextBert.from_pretrained('../../huggingface/bert-base-uncased') + the smaller learning rate.
+            # The weights are read from ``text_bert_pretrained_path`` (same default path) when the file is there; offline
+            # the text encoder keeps its N(0, 0.02) init and ``text_bert.load_pretrained(state_dict)`` can be called later.
+            self._load_bert_base(c.get("text_bert_pretrained_path", "../../huggingface/bert-base-uncased"))
             self.finetune_modules.append({"module": self.text_bert, "lr_scale": c.lr_scale_text_bert})
         self.text_bert_out_linear = nn.Identity()
         self.frame_embeddings = nn.Embedding(4000, 50)
@@ -362,6 +388,25 @@ class T2S(BaseModel):
             if is_dead_param(n):
                 p.requires_grad_(False)
         return self
+
+    def _load_bert_base(self, path):
+        import os
+        cand = [path] if os.path.isfile(path) else [os.path.join(path, f) for f in ("pytorch_model.bin", "model.safetensors")]
+        for f in cand:
+            if os.path.isfile(f):
+                if f.endswith(".safetensors"):
+                    from safetensors.torch import load_file
+                    sd = load_file(f)
+                else:
+                    sd = torch.load(f, map_location="cpu", weights_only=True)
+                used = self.text_bert.load_pretrained(sd)
+                if self.writer is not None:
+                    self.writer.write("text_bert initialised from %s (%d tensors)" % (f, len(used)))
+                return True
+        if self.writer is not None:
+            self.writer.write("text_bert_init_from_bert_base: no checkpoint under %s; text_bert keeps its random init "
+                              "(call model.text_bert.load_pretrained(state_dict))" % path)
+        return False
 
     def set_dropout(self, p):
         """Set every dropout probability of the model (hidden, attention-probability, embedding, obj/ocr input) to ``p``:
