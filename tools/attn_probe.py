@@ -36,20 +36,34 @@ def main():
     for _ in range(iters):
         out, lse = ops.attn_fwd(qkv, keys, **kw)
     ev[1].record()
-    dq = ops.attn_bwd(qkv, out, dout, lse, keys, **kw)
     torch.cuda.synchronize()
-    ev[2].record()
+    # backward: the two-kernel (7-product) and the fused (5-product, no dropout) forms, interleaved rounds in ONE process
+    forms = [("two-kernel", False)] + ([("fused", True)] if dp == 0 else [])
+    tb_all = {n: [] for n, _ in forms}
+    for n, f in forms:
+        ops.attn_bwd(qkv, out, dout, lse, keys, fused=f, **kw)
+    torch.cuda.synchronize()
     for _ in range(iters):
-        dq = ops.attn_bwd(qkv, out, dout, lse, keys, **kw)
+        for n, f in forms:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ops.attn_bwd(qkv, out, dout, lse, keys, fused=f, **kw)
+            b.record()
+            torch.cuda.synchronize()
+            tb_all[n].append(a.elapsed_time(b))
+    ev[2].record()
     ev[3].record()
     torch.cuda.synchronize()
     tf = ev[0].elapsed_time(ev[1]) / iters
-    tb = ev[2].elapsed_time(ev[3]) / iters
+    tb = sorted(tb_all["two-kernel"])[len(tb_all["two-kernel"]) // 2]
     dense = 4.0 * B * 12 * L * L * 64
     execd = 4.0 * B * 12 * L * nk * 64
     print("drop=%.2f " % dp, end="")
     print("B=%d L=%d keys=%.0f  fwd %.3f ms: %.1f TF/s dense-equivalent, %.1f TF/s executed | bwd %.3f ms: %.1f TF/s (2.5x fwd flops) executed %.1f"
           % (B, L, nk, tf, dense / tf / 1e9, execd / tf / 1e9, tb, 2.5 * dense / tb / 1e9, 2.5 * execd / tb / 1e9))
+    for n, ts in tb_all.items():
+        ts = sorted(ts)
+        print("   bwd %-10s median %.3f ms  min %.3f ms  -> %.1f TF/s on the algorithmic 5 products (executed keys)" % (n, ts[len(ts) // 2], ts[0], 2.5 * execd / ts[len(ts) // 2] / 1e9))
 
 
 if __name__ == "__main__":

@@ -177,6 +177,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st);
 // bf16 dK/dV kernel lives in attn_dkdv_bf16.hip
 void launch_attn_dkdv_bf16(const AttnParams& p, int max_keys, hipStream_t st);
+// fused 5-product bf16 backward (delta + housekeeping, main kernel, dQ cast) lives in attn_bwd_fused_bf16.hip
+int launch_attn_bwd_fused_bf16(const AttnParams& p, int max_keys, float* dq32, hipStream_t st);
 
 #define LOG2E 1.4426950408889634f
 

@@ -4,6 +4,7 @@ Every function validates shapes on the host before launching (an out-of-bounds k
 whole GPU node down) and raises RuntimeError with the library's message on failure.
 """
 import math
+import os
 
 import torch
 
@@ -77,7 +78,12 @@ def attn_fwd(qkv, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0):
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0):
+# True: bf16 launches without attention dropout use the fused 5-product kernel (t2s_attn_bwd_fused: S and dP computed once, dQ summed
+# across key blocks with fp32 atomics); False: always the two-kernel 7-product form.
+ATTN_BWD_FUSED = os.environ.get("T2S_ATTN_BWD_FUSED", "1") != "0"
+
+
+def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, fused=None):
     """Returns dqkv [B, L, 2304] (rows of keys outside the key list get exact zeros in the K/V thirds)."""
     B, L, _ = qkv.shape
     q, k, v = _attn_views(qkv)
@@ -92,14 +98,20 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     dq, dk, dv = _attn_views(dqkv)
     delta = torch.empty_like(lse)
     head = (X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(dout), X.ptr(lse), X.ptr(delta),
-            X.ptr(dq), X.ptr(dk), X.ptr(dv), X.ptr(keys.idx), X.ptr(keys.cnt))
+            X.ptr(dq), X.ptr(dk), X.ptr(dv))
+    klist = (X.ptr(keys.idx), X.ptr(keys.cnt))
     dims = (B, HEADS, L, cap, keys.n_dec, keys.dec_q0, keys.cap_hint,
             qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
-            scale, X.dtype_code(qkv), float(drop_p), int(drop_seed))
-    if fill_in_kernel:
-        X.check(X.lib().t2s_attn_bwd_fill(*head, X.ptr(keys.valid8), *dims, X.stream()), "t2s_attn_bwd_fill")
+            scale, X.dtype_code(qkv))
+    use_fused = (ATTN_BWD_FUSED if fused is None else fused) and qkv.dtype == torch.bfloat16 and drop_p == 0.0
+    if use_fused:
+        dq32 = torch.empty(B, L, HID, dtype=torch.float32, device=qkv.device)        # fp32 dQ accumulation workspace (zeroed in the call)
+        X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(dq32), *klist, X.ptr(keys.valid8) if fill_in_kernel else None, *dims, X.stream()),
+                "t2s_attn_bwd_fused")
+    elif fill_in_kernel:
+        X.check(X.lib().t2s_attn_bwd_fill(*head, *klist, X.ptr(keys.valid8), *dims, float(drop_p), int(drop_seed), X.stream()), "t2s_attn_bwd_fill")
     else:
-        X.check(X.lib().t2s_attn_bwd(*head, *dims, X.stream()), "t2s_attn_bwd")
+        X.check(X.lib().t2s_attn_bwd(*head, *klist, *dims, float(drop_p), int(drop_seed), X.stream()), "t2s_attn_bwd")
     return dqkv
 
 
