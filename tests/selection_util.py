@@ -8,7 +8,8 @@ oracle).  A row (sample, frame) of the spatial stage - or a sample of the tempor
     g ~ O(1): only the noise decides, up to the rounding of the sum and of log()), and
   * the k-th and (k+1)-th candidates of the top-k are either separated by more than ``tol`` RELATIVE to their size (the scores
     are softmax probabilities: two correct implementations differ by ~1e-6 .. 1e-5 relative, whatever the magnitude) plus an
-    absolute ``atol`` (default 1e-43: a few fp32 denormal quanta - peaked softmaxes produce such values), or tie EXACTLY at
+    absolute ``atol`` (default 3e-45: two fp32 denormal quanta - peaked softmaxes produce values that small, and two of
+    them that round to the same fp32 number are a tie on the GPU), or tie EXACTLY at
     the -10000 fill
     (exact ties are resolved by the shared lowest-index rule), for the "largest" and the "smallest"
     selection alike.
@@ -52,13 +53,13 @@ def relative_diff(got, want):
     return ((got.double() - want.double()).abs()[m] / want.double().abs()[m]).max().item() if m.any() else 0.0
 
 
-def decisive_frames(frame_score, frame_mask, expo_frame, topk, tol=1e-4, atol=1e-43, tol_g=1e-6):
+def decisive_frames(frame_score, frame_mask, expo_frame, topk, tol=1e-4, atol=3e-45, tol_g=1e-6):
     """[B] bool: samples whose temporal selection (pos / neg frame top-k) is robust."""
     pos_s, neg_s, fragile = _split(frame_score, expo_frame, frame_mask, tol_g)
     return (~fragile.any(-1)) & _boundary_ok(pos_s, topk, True, tol, atol) & _boundary_ok(neg_s, topk, False, tol, atol)
 
 
-def decisive_ocr_rows(ocr_score, new_mask, expo_ocr, topk, F, P, tol=1e-4, atol=1e-43, tol_g=1e-6):
+def decisive_ocr_rows(ocr_score, new_mask, expo_ocr, topk, F, P, tol=1e-4, atol=3e-45, tol_g=1e-6):
     """[B, F] bool: (sample, frame) rows whose spatial selection (pos / neg OCR top-k of the frame's P slots) is robust."""
     B = ocr_score.shape[0]
     pos_s, neg_s, fragile = _split(ocr_score, expo_ocr, new_mask, tol_g)

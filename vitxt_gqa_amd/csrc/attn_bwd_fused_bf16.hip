@@ -19,6 +19,8 @@
 // 32 x 32 tile (query sub-block w >> 1, dim block w & 1) of dQ = dS K over ALL 384 keys (both operands by
 // ds_read_b64_tr_b16 from the two images) and adds it to the fp32 dQ buffer: each accumulator register is two 128-byte
 // row segments, the shape the atomics run at full rate for.
+#include <type_traits>
+
 #include "attn_common.h"
 
 namespace {
@@ -32,12 +34,119 @@ constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4;   // Q | dO | -lse*log2
 constexpr int FB_KIMG = FB_KEYS * 128;
 constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
 
-template <bool USE_IDX, bool TAIL>
+// ---- MFMAs with the register file of their accumulator chosen by hand.  With 512 registers per lane the compiler selects the
+// AGPR form for every MFMA and then copies each S / dP tile between the two files around the softmax (816 v_accvgpr_* in
+// the first build of this kernel: more VALU time than the MFMAs themselves).  Here the long-lived dK^T / dV^T accumulators are
+// tied to AGPRs ("+a") and the S / dP tiles to VGPRs ("+v"), so no copy exists.  hipcc pads nothing inside or behind an asm
+// statement (cdna_hip_programming.md section 5.7): the leading s_nop 1 covers a VALU-written operand, the s_nop 11 behind the
+// last MFMA of a VGPR chain covers its result being read by VALU code (8-pass MFMA: 12 wait states).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define FB_U4(x) __builtin_bit_cast(u32x4, x)
+__device__ __forceinline__ void fb_mfma_sdp(f32x16& sacc, f32x16& dpacc, const bf16x8 (&qf)[4], const bf16x8 (&kf)[4], const bf16x8 (&dof)[4],
+                                            const u32x4 (&vf)[4]) {
+  asm("s_nop 1\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %2, %6, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %1, %10, %14, %1\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %3, %7, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %1, %11, %15, %1\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %4, %8, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %1, %12, %16, %1\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %5, %9, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %1, %13, %17, %1\n\t"
+      "s_nop 11"
+      : "+v"(sacc), "+v"(dpacc)
+      : "v"(FB_U4(qf[0])), "v"(FB_U4(qf[1])), "v"(FB_U4(qf[2])), "v"(FB_U4(qf[3])), "v"(FB_U4(kf[0])), "v"(FB_U4(kf[1])), "v"(FB_U4(kf[2])),
+        "v"(FB_U4(kf[3])), "v"(FB_U4(dof[0])), "v"(FB_U4(dof[1])), "v"(FB_U4(dof[2])), "v"(FB_U4(dof[3])), "a"(vf[0]), "a"(vf[1]),
+        "a"(vf[2]), "a"(vf[3]));        // the V fragments live in AGPRs for the whole kernel (an MFMA B operand may be an AGPR)
+}
+// dV^T[db] += dO^T[s][db] P[s], dK^T[db] += Q^T[s][db] dS[s]  (s = 0, 1; db = 0, 1): eight MFMAs into AGPR accumulators
+__device__ __forceinline__ void fb_mfma_dvdk(f32x16& dv0, f32x16& dv1, f32x16& dk0, f32x16& dk1, const bf16x8 (&doT)[2][2], const bf16x8 (&qT)[2][2],
+                                             const bf16x8 (&pf)[2], const bf16x8 (&dsf)[2]) {
+  asm("s_nop 1\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %4, %12, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %2, %8, %14, %2\n\t"
+      "v_mfma_f32_32x32x16_bf16 %1, %5, %12, %1\n\t"
+      "v_mfma_f32_32x32x16_bf16 %3, %9, %14, %3\n\t"
+      "v_mfma_f32_32x32x16_bf16 %0, %6, %13, %0\n\t"
+      "v_mfma_f32_32x32x16_bf16 %2, %10, %15, %2\n\t"
+      "v_mfma_f32_32x32x16_bf16 %1, %7, %13, %1\n\t"
+      "v_mfma_f32_32x32x16_bf16 %3, %11, %15, %3"
+      : "+a"(dv0), "+a"(dv1), "+a"(dk0), "+a"(dk1)
+      : "v"(FB_U4(doT[0][0])), "v"(FB_U4(doT[0][1])), "v"(FB_U4(doT[1][0])), "v"(FB_U4(doT[1][1])), "v"(FB_U4(qT[0][0])), "v"(FB_U4(qT[0][1])),
+        "v"(FB_U4(qT[1][0])), "v"(FB_U4(qT[1][1])), "v"(FB_U4(pf[0])), "v"(FB_U4(pf[1])), "v"(FB_U4(dsf[0])), "v"(FB_U4(dsf[1])));
+}
+
+// ---- single-MFMA statements for the software-pipelined sweep (the compiler orders them among the VALU code between the
+// scheduling fences; it knows nothing of their latency, so every consumer is placed by construction - see FB_PIPE below)
+#define FB_MFMA_V0(acc, a, b, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(FB_U4(a)), "v"(FB_U4(b)), "v"(c))
+#define FB_MFMA_V(acc, a, b) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(FB_U4(a)), "v"(FB_U4(b)))
+#define FB_MFMA_VA0(acc, a, ba, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(FB_U4(a)), "a"(ba), "v"(c))
+#define FB_MFMA_VA(acc, a, ba) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(FB_U4(a)), "a"(ba))
+#define FB_MFMA_A(acc, a, b) asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(FB_U4(a)), "v"(b))
+#define FB_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// transposed fragment from a row-block base and this lane's two precomputed offsets (rows r and r + 8 of the block)
+__device__ __forceinline__ bf16x8 fb_tr(const char* base, const int (&va2)[2]) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + va2[0]));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + va2[1]));
+  const s16x8 c = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, c);
+}
+
+__device__ __forceinline__ uint32_t fb_pack2(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, bf16x2_t{(__bf16)a, (__bf16)b});
+}
+
+// m-th MFMA (m = 0..7) of G1(block I): S and dP chains of key block I % 3, alternating; each chain starts from the row constants
+template <int I, int M>
+__device__ __forceinline__ void fb_g1(f32x16 (&sacc)[2], f32x16 (&dpacc)[2], const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], const bf16x8 (&kf)[4],
+                                      const u32x4 (&vf)[FB_KB][4]) {
+  constexpr int s = M / 2, kb = I % 3, par = I & 1;
+  if constexpr (M % 2 == 0) FB_MFMA_V(sacc[par], qf[s], kf[s]);
+  else FB_MFMA_VA(dpacc[par], dof[s], vf[kb][s]);
+}
+// m-th MFMA of G2(block I): m = 0..3 dV^T (needs P), m = 4..7 dK^T (needs dS)
+template <int I, int M>
+__device__ __forceinline__ void fb_g2(f32x16 (&dvacc)[FB_KB][2], f32x16 (&dkacc)[FB_KB][2], const bf16x8 (&doT)[2][2], const bf16x8 (&qT)[2][2],
+                                      const uint32_t (&pfw)[8], const uint32_t (&dsw)[8]) {
+  constexpr int kb = I % 3, s = (M & 3) >> 1, db = M & 1;
+  if constexpr (M < 4) {
+    const u32x4 b = {pfw[4 * s], pfw[4 * s + 1], pfw[4 * s + 2], pfw[4 * s + 3]};
+    FB_MFMA_A(dvacc[kb][db], doT[s][db], b);
+  } else {
+    const u32x4 b = {dsw[4 * s], dsw[4 * s + 1], dsw[4 * s + 2], dsw[4 * s + 3]};
+    FB_MFMA_A(dkacc[kb][db], qT[s][db], b);
+  }
+}
+// chunk m (registers 2m, 2m+1) of the softmax of block I: P = exp2(S'), packed bf16 operand word
+template <int I, int M>
+__device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8]) {
+  constexpr int par = I & 1;
+  const float p0 = fast_exp2(sacc[par][2 * M]), p1 = fast_exp2(sacc[par][2 * M + 1]);
+  sacc[par][2 * M] = p0;
+  sacc[par][2 * M + 1] = p1;
+  pfw[M] = fb_pack2(p0, p1);
+}
+// chunk m of dS = P * dP' of block I
+template <int I, int M>
+__device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dpacc)[2], uint32_t (&dsw)[8]) {
+  constexpr int par = I & 1;
+  dsw[M] = fb_pack2(sacc[par][2 * M] * dpacc[par][2 * M], sacc[par][2 * M + 1] * dpacc[par][2 * M + 1]);
+}
+
+// MODE 0: workgroups whose 384 keys are all valid prefix keys run the software-pipelined sweep, the others exit; MODE 1: the
+// complement (the general sweep with the validity / decoder rule and skipped key blocks); MODE 2: the tail launch (general
+// sweep, loops over the key blocks beyond the static bound).  Separate kernels, so that each is register-allocated for one sweep.
+template <bool USE_IDX, int MODE>
 __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams p, float* __restrict__ dq32) {
+  constexpr bool TAIL = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const kimg = smem;                         // [384 keys][64 d] bf16, tile_off swizzle
-  char* const dsimg = smem + FB_KIMG;              // [384 keys][64 q] bf16, same layout
-  char* const stage = smem + 2 * FB_KIMG;
+  char* const stage = smem;                        // 2 x (Q tile | dO tile | -lse*log2e | -delta)
+  char* const kimg = smem + 2 * FB_STAGE;          // [384 keys][64 d] bf16, tile_off swizzle
+  char* const dsimg = kimg + FB_KIMG;              // [384 keys][64 q] bf16, same layout
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   int kblk, h, b;
   if (!attn_xcd_tile(TAIL ? 1 : p.kblocks, p.H, p.B, kblk, h, b)) return;         // workgroup-uniform (attn_common.h)
@@ -56,12 +165,30 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   const float c = p.scale * LOG2E;
   const int nqt = (p.Lq + FB_QROWS - 1) / FB_QROWS;
   const int sr = tid >> 3, sc = tid & 7;
+  // per-lane LDS byte offsets, computed once: row fragment of row lr of a 32-row block (chunk 2s + lh), transposed fragment
+  // (rows 4lh + qq and + 8, chunk 4db + 2g1 + (pp >> 1)), dS^T store (row lr, chunk cc); block / tile / image offsets are
+  // immediates or uniform adds on top of these
+  int ka[4], va[2][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) ka[s] = tile_off(lr, 2 * s + lh);
+  {
+    const int g1 = (lane >> 4) & 1, i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = 4 * db + 2 * g1 + (pp >> 1);
+      va[db][0] = tile_off(4 * lh + qq, chunk) + ((pp & 1) << 3);
+      va[db][1] = tile_off(4 * lh + qq + 8, chunk) + ((pp & 1) << 3);
+    }
+  }
+  const int wrow = lr * 128, wxor = tile_f(lr) << 4;          // dS^T store of chunk cc: wrow + ((cc << 4) ^ wxor)
 
   do {   // key blocks of this workgroup (TAIL == false: exactly one, no loop is compiled)
     const int kp0 = kbw * FB_KEYS;
     const int nkeys_wg = (nk - kp0) < FB_KEYS ? (nk - kp0) : FB_KEYS;              // valid keys of this workgroup
     const int nks = (nkeys_wg + 15) >> 4;                                          // 16-key steps of the dQ product
     const bool edge_wg = (kp0 + FB_KEYS > n_prefix);                               // decoder keys or the end of the list inside
+    if (MODE == 0 && edge_wg) return;                                              // (nkeys_wg == FB_KEYS follows from !edge_wg)
+    if (MODE == 1 && !edge_wg) return;
     // ---- K image of the workgroup's keys, pre-scaled by scale*log2e (one bf16 rounding per element, as the dK/dV kernel's
     // register fragments); rows past the list repeat its last key (their P is forced to 0 below)
 #pragma unroll
@@ -76,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       *reinterpret_cast<bf16x8*>(kimg + tile_off(row, sc)) = kv;
     }
     // ---- this wave's keys: V fragments (B operands of dP), list positions, validity
-    bf16x8 vf[FB_KB][4];
+    u32x4 vf[FB_KB][4];
     int kdec[FB_KB];          // decoder step of this lane's key of block kb (negative: prefix key)
     bool kvalid[FB_KB];
     int64_t krow[FB_KB];
@@ -89,7 +216,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       kdec[kb] = kpos - n_prefix;
       const char* vp = Vg + (krow[kb] * p.kv_rs + 8 * lh) * 2;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) vf[kb][s] = *reinterpret_cast<const bf16x8*>(vp + 32 * s);
+      for (int s = 0; s < 4; ++s) {
+        vf[kb][s] = *reinterpret_cast<const u32x4*>(vp + 32 * s);
+        asm volatile("" : "+a"(vf[kb][s]));          // park it in the accumulator file
+      }
     }
     f32x16 dkacc[FB_KB][2], dvacc[FB_KB][2];
 #pragma unroll
@@ -139,7 +269,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     FB_STAGE_WRITE(0);
     __syncthreads();
 
-    const int dq_qb = wave >> 1, dq_db = wave & 1;          // this wave's 32 x 32 tile of dQ
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int dq_qb = wave_u >> 1, dq_db = wave_u & 1;          // this wave's 32 x 32 tile of dQ (provably wave-uniform)
+    // the query sweep in two compiled forms behind ONE workgroup-uniform branch: FULL = all 384 keys valid prefix keys (no
+    // validity / decoder rule, no skipped key blocks: straight-line code), and the general form
+    auto sweep = [&](auto full_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
       FB_STAGE_LOAD();                                      // next tile in sequence (past the end: clamped rows, harmless)
@@ -148,6 +283,98 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       const float* lse_s = reinterpret_cast<const float*>(qb_ + 2 * FB_TILE);
       const float* del_s = lse_s + FB_QROWS;
       // ================= phase A: S, dP, dS, dV^T, dK^T per (query sub-block, key block) =================
+      if constexpr (FULL) {
+        // Software pipeline over the tile's six blocks b_i = (query sub-block i / 3, key block i % 3).  One wave per SIMD issues in
+        // order, so an MFMA only overlaps VALU / LDS work that stands BETWEEN it and the next MFMA in the instruction stream.
+        // Slots of 8 MFMAs each, fenced into one-MFMA groups:
+        //   G1(b0) | G1(b1) + E(b0) | G2(b0) + M(b0) | G1(b2) + E(b1) | G2(b1) + M(b1) | ... | G1(b5) + E(b4) | G2(b4) + M(b4) + E(b5) | G2(b5) + M(b5)
+        // G1 = S, dP chains (row constants through the C operand of the first MFMA); E = P = exp2(S') and its bf16 operand
+        // words (2 v_exp + 1 cvt per group); G2 = 4 dV^T MFMAs (need P) then 4 dK^T MFMAs (need dS); M = dS = P dP' (4 mul + 2 cvt
+        // per group, in the dV^T half).  Every consumer stands at least one MFMA group behind the MFMA that produces its input
+        // (S3 is the 7th MFMA of a G1, E starts in the next slot; dP3 is the 8th, M starts a whole slot later): the wait states the
+        // hardware does not interlock are covered by construction.  LDS loads of a slot's successor are issued at its head.
+        bf16x8 qf[4], dof[4], qT[2][2], doT[2][2], kf[4];
+        f32x16 sacc[2], dpacc[2];
+        uint32_t pfw[8], dsw[8];
+        const char* kw_ = kimg + wave * (FB_WKEYS * 128);
+        char* dsw_ = dsimg + wave * (FB_WKEYS * 128) + 8 * lh;
+#define FB_LD_QF(sb_)                                                                               \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
+    qf[s] = *reinterpret_cast<const bf16x8*>(qb_ + ka[s] + (sb_) * 4096);                           \
+    dof[s] = *reinterpret_cast<const bf16x8*>(dob_ + ka[s] + (sb_) * 4096);                         \
+  }
+#define FB_LD_SEEDS(i_)  /* accumulators of block i start from the row constants of this lane's rows (broadcast reads) */  \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ((i_) / 3) * 32 + 8 * g + 4 * lh);     \
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + ((i_) / 3) * 32 + 8 * g + 4 * lh);     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) { sacc[(i_) & 1][4 * g + j] = l4[j]; dpacc[(i_) & 1][4 * g + j] = d4[j]; }  \
+  }
+#define FB_LD_QT(sb_)                                                                               \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                     \
+  _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                \
+    qT[s][db] = fb_tr(qb_ + ((sb_) * 32 + 16 * s) * 128, va[db]);                                   \
+    doT[s][db] = fb_tr(dob_ + ((sb_) * 32 + 16 * s) * 128, va[db]);                                 \
+  }
+#define FB_LD_KF(kb_)                                                                               \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kw_ + ka[s] + (kb_) * 4096);
+#define FB_ST_DS(i_)     /* dS^T image rows of block i: queries sb*32 + 16s + {0..3, 8..11} + 4lh of this lane's key */  \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
+    *reinterpret_cast<uint2*>(dsw_ + ((i_) % 3) * 4096 + (wrow + (((4 * ((i_) / 3) + 2 * s) << 4) ^ wxor))) = make_uint2(dsw[4 * s], dsw[4 * s + 1]);          \
+    *reinterpret_cast<uint2*>(dsw_ + ((i_) % 3) * 4096 + (wrow + (((4 * ((i_) / 3) + 2 * s + 1) << 4) ^ wxor))) = make_uint2(dsw[4 * s + 2], dsw[4 * s + 3]);  \
+  }
+#define FB_G1(i_, m_) fb_g1<i_, m_>(sacc, dpacc, qf, dof, kf, vf)
+#define FB_G2(i_, m_) fb_g2<i_, m_>(dvacc, dkacc, doT, qT, pfw, dsw)
+#define FB_E(i_, m_) fb_ve<i_, m_>(sacc, pfw)
+#define FB_M(i_, m_) fb_vm<i_, m_>(sacc, dpacc, dsw)
+        // slot "G1(n) + E(e)": eight groups of one MFMA of G1(b_n) and one chunk of E(b_e)
+#define FB_SLOT_G1E(n_, e_)                                                                         \
+  FB_G1(n_, 0); FB_E(e_, 0); FB_FENCE(); FB_G1(n_, 1); FB_E(e_, 1); FB_FENCE(); FB_G1(n_, 2); FB_E(e_, 2); FB_FENCE();            \
+  FB_G1(n_, 3); FB_E(e_, 3); FB_FENCE(); FB_G1(n_, 4); FB_E(e_, 4); FB_FENCE(); FB_G1(n_, 5); FB_E(e_, 5); FB_FENCE();            \
+  FB_G1(n_, 6); FB_E(e_, 6); FB_FENCE(); FB_G1(n_, 7); FB_E(e_, 7); FB_FENCE();
+        // slot "G2(i) + M(i)": dV^T MFMAs with two chunks of M each, then the dK^T MFMAs beside the dS^T stores
+#define FB_SLOT_G2M(i_)                                                                             \
+  FB_G2(i_, 0); FB_M(i_, 0); FB_M(i_, 1); FB_FENCE(); FB_G2(i_, 1); FB_M(i_, 2); FB_M(i_, 3); FB_FENCE();                        \
+  FB_G2(i_, 2); FB_M(i_, 4); FB_M(i_, 5); FB_FENCE(); FB_G2(i_, 3); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE();                        \
+  FB_G2(i_, 4); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS((i_) + 2); } FB_FENCE();               \
+  FB_G2(i_, 6); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
+        FB_LD_QF(0); FB_LD_SEEDS(0); FB_LD_KF(0);
+        FB_FENCE();
+        // slot 0: G1(b0), nothing to pair yet; the transposed fragments of sub-block 0 arrive meanwhile
+        FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
+        FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
+        FB_LD_KF(1); FB_FENCE();
+        FB_SLOT_G1E(1, 0);
+        FB_LD_KF(2); FB_FENCE();
+        FB_SLOT_G2M(0);
+        FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
+        FB_LD_QF(1); FB_LD_KF(0); FB_FENCE();
+        FB_SLOT_G2M(1);
+        FB_SLOT_G1E(3, 2);
+        FB_LD_KF(1); FB_FENCE();
+        FB_SLOT_G2M(2);                                      // last use of sub-block 0's transposed fragments
+        FB_LD_QT(1); FB_FENCE();
+        FB_SLOT_G1E(4, 3);
+        FB_LD_KF(2); FB_FENCE();
+        FB_SLOT_G2M(3);
+        FB_SLOT_G1E(5, 4);
+        // slot "G2(b4) + M(b4) + E(b5)"
+        FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_E(5, 0); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_E(5, 1); FB_FENCE();
+        FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_E(5, 2); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_E(5, 3); FB_FENCE();
+        FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 4); FB_FENCE(); FB_G2(4, 5); FB_E(5, 5); FB_FENCE(); FB_G2(4, 6); FB_E(5, 6); FB_FENCE();
+        FB_G2(4, 7); FB_E(5, 7); FB_FENCE();
+        FB_SLOT_G2M(5);
+#undef FB_LD_QF
+#undef FB_LD_SEEDS
+#undef FB_LD_QT
+#undef FB_LD_KF
+#undef FB_ST_DS
+#undef FB_G1
+#undef FB_G2
+#undef FB_E
+#undef FB_M
+#undef FB_SLOT_G1E
+#undef FB_SLOT_G2M
+      } else {
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
         bf16x8 qf[4], dof[4], qT[2][2], doT[2][2];
@@ -163,27 +390,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             qT[s][db] = lds_tr_frag(qb_, sb * 32 + 16 * s, db, lane);
             doT[s][db] = lds_tr_frag(dob_, sb * 32 + 16 * s, db, lane);
           }
-        f32x16 seed_s, seed_dp;          // row constants of this lane's accumulator rows: acc_row(r, lh) = 8g + 4lh + j
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + sb * 32 + 8 * g + 4 * lh);
-          const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + sb * 32 + 8 * g + 4 * lh);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { seed_s[4 * g + j] = l4[j]; seed_dp[4 * g + j] = d4[j]; }
-        }
 #pragma unroll
         for (int kb = 0; kb < FB_KB; ++kb) {
           const int keyrow0 = wave * FB_WKEYS + kb * 32;
-          if (keyrow0 < nkeys_wg) {                          // wave-uniform: key blocks past the list are skipped
-            f32x16 sacc = seed_s, dpacc = seed_dp;
+          if (FULL || keyrow0 < nkeys_wg) {                  // wave-uniform: key blocks past the list are skipped
+            // accumulators start from the row constants of this lane's rows acc_row(r, lh) = 8g + 4lh + j (broadcast LDS reads)
+            f32x16 sacc, dpacc;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              sacc = mfma_bf16(qf[s], lds_row_frag(kimg, keyrow0 + lr, s, lh), sacc);        // c*S[q, key] - LSE*log2e
-              dpacc = mfma_bf16(dof[s], vf[kb][s], dpacc);                                    // dP[q, key] - delta
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + sb * 32 + 8 * g + 4 * lh);
+              const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + sb * 32 + 8 * g + 4 * lh);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { sacc[4 * g + j] = l4[j]; dpacc[4 * g + j] = d4[j]; }
             }
+            bf16x8 kf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[s] = lds_row_frag(kimg, keyrow0 + lr, s, lh);
+            fb_mfma_sdp(sacc, dpacc, qf, kf, dof, vf[kb]);           // c*S[q, key] - LSE*log2e ; dP[q, key] - delta
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = fast_exp2(sacc[r]);
-            if (edge_wg) {          // decoder / validity rule behind a real uniform branch (see attn_dkdv_bf16_sweep.inc)
+            if (!FULL && edge_wg) {          // decoder / validity rule behind a real uniform branch (see attn_dkdv_bf16_sweep.inc)
               asm volatile("" ::: "memory");
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
@@ -194,44 +420,76 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) dpacc[r] = sacc[r] * dpacc[r];
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { pf[s] = acc_to_frag(sacc, s); dsf[s] = acc_to_frag(dpacc, s); }
+            fb_mfma_dvdk(dvacc[kb][0], dvacc[kb][1], dkacc[kb][0], dkacc[kb][1], doT, qT, pf, dsf);
+            // dS^T image: this lane's key row, queries sb*32 + 16s + {0..3, 8..11} + 4lh: two 8-byte stores per s
             char* dsrow = dsimg + 8 * lh;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-              const bf16x8 pf = acc_to_frag(sacc, s), dsf = acc_to_frag(dpacc, s);
-#pragma unroll
-              for (int db = 0; db < 2; ++db) {
-                dvacc[kb][db] = mfma_bf16(doT[s][db], pf, dvacc[kb][db]);       // dV^T[d, key] += dO^T[d, q] P[q, key]
-                dkacc[kb][db] = mfma_bf16(qT[s][db], dsf, dkacc[kb][db]);       // dK^T[d, key] += Q^T[d, q] dS[q, key]
-              }
-              // dS^T image: this lane's key row, queries sb*32 + 16s + {0..3, 8..11} + 4lh: two 8-byte stores
-              const uint4 w = __builtin_bit_cast(uint4, dsf);
+              const uint4 w = __builtin_bit_cast(uint4, dsf[s]);
               *reinterpret_cast<uint2*>(dsrow + tile_off(keyrow0 + lr, 4 * sb + 2 * s)) = make_uint2(w.x, w.y);
               *reinterpret_cast<uint2*>(dsrow + tile_off(keyrow0 + lr, 4 * sb + 2 * s + 1)) = make_uint2(w.z, w.w);
             }
           }
         }
       }
+      }   // general form
       __syncthreads();                                       // the dS^T image of this query tile is complete
       // ================= phase B: dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
       {
         f32x16 dqacc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqacc[i] = 0.f;
-        for (int ks = 0; ks < nks; ++ks)
-          dqacc = mfma_bf16(lds_tr_frag(dsimg, 16 * ks, dq_qb, lane), lds_tr_frag(kimg, 16 * ks, dq_db, lane), dqacc);
+        if (FULL) {          // 24 steps in groups of 4: the transposed reads of a group run ahead of its MFMAs
+          for (int k4 = 0; k4 < FB_KEYS / 16; k4 += 4) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              af[u] = lds_tr_frag(dsimg, 16 * (k4 + u), dq_qb, lane);
+              bfr[u] = lds_tr_frag(kimg, 16 * (k4 + u), dq_db, lane);
+            }
+            asm("s_nop 1\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %1, %5, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %2, %6, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %3, %7, %0\n\t"
+                "v_mfma_f32_32x32x16_bf16 %0, %4, %8, %0"
+                : "+v"(dqacc)
+                : "v"(FB_U4(af[0])), "v"(FB_U4(af[1])), "v"(FB_U4(af[2])), "v"(FB_U4(af[3])), "v"(FB_U4(bfr[0])), "v"(FB_U4(bfr[1])),
+                  "v"(FB_U4(bfr[2])), "v"(FB_U4(bfr[3])));
+          }
+        } else {
+          for (int ks = 0; ks < nks; ++ks) {
+            const bf16x8 a1 = lds_tr_frag(dsimg, 16 * ks, dq_qb, lane), b1 = lds_tr_frag(kimg, 16 * ks, dq_db, lane);
+            asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(a1)), "v"(FB_U4(b1)));
+          }
+        }
+        asm volatile("s_nop 11" : "+v"(dqacc));              // MFMA result -> VALU read
         // dS (K c) = c dS K;  dQ = scale dS K = acc * ln 2.  Register r = query row acc_row(r, lh), 32 consecutive dims per
         // half wave: two 128-byte segments per wave instruction
         const int q0 = qt * FB_QROWS + dq_qb * 32;
-        float* dst = DQ + dq_db * 32 + lr;
+        const int rstep = p.H * 64;
+        float* rowp = DQ + (int64_t)q0 * rstep + dq_db * 32;          // wave-uniform (dq_qb / dq_db come from readfirstlane)
+        const int loff = lr + 4 * lh * rstep;                          // this lane's element offset
+        if (q0 + 32 <= p.Lq) {                               // whole sub-block inside the sequence
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int q = q0 + acc_row(r, lh);
-          if (q < p.Lq) unsafeAtomicAdd(dst + (int64_t)q * (p.H * 64), dqacc[r] * 0.6931471805599453f);
+          for (int r = 0; r < 16; ++r) unsafeAtomicAdd(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (q0 + acc_row(r, lh) < p.Lq) unsafeAtomicAdd(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
         }
       }
       FB_STAGE_WRITE(buf ^ 1);
       __syncthreads();                                       // next tile staged; every wave is done reading the dS^T image
     }
+    };
+    sweep(std::integral_constant<bool, MODE == 0>{});
+    // dK^T / dV^T were last written by asm MFMAs the compiler does not see as such: cover MFMA result -> v_accvgpr_read
+#pragma unroll
+    for (int kb = 0; kb < FB_KB; ++kb)
+      asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dkacc[kb][0]), "+a"(dkacc[kb][1]), "+a"(dvacc[kb][0]), "+a"(dvacc[kb][1]));
 #undef FB_STAGE_LOAD
 #undef FB_STAGE_WRITE
 
@@ -317,22 +575,26 @@ __global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restri
 int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, float* dq32, hipStream_t st) {
   AttnParams p = p_in;
   // > 64 KB of LDS per workgroup needs the opt-in; set on every call (idempotent, per device, no state of ours is kept)
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
-    t2s_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS per workgroup", FB_SMEM);
-    return 3;
-  }
+  const void* kernels[] = {reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 0>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 1>),
+                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 2>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 0>),
+                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 1>)};
+  for (const void* k : kernels)
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
+      t2s_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS per workgroup", FB_SMEM);
+      return 3;
+    }
   const int64_t rows = (int64_t)p.B * p.Lq;
   hipLaunchKernelGGL(attn_delta_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)p.o, (const bf16_t*)p.dout, p.delta,
                      dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.B, p.H, p.Lq, p.o_rs, p.o_bs, p.kv_rs, p.kv_bs);
   p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256), tail(attn_xcd_grid(1, p.H, p.B));
   if (p.kv_idx) {
-    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<true, false>), grid, block, FB_SMEM, st, p, dq32);
-    if (p.kblocks * FB_KEYS < p.idx_cap) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<true, true>), tail, block, FB_SMEM, st, p, dq32);
+    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<true, 0>), grid, block, FB_SMEM, st, p, dq32);
+    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<true, 1>), grid, block, FB_SMEM, st, p, dq32);
+    if (p.kblocks * FB_KEYS < p.idx_cap) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<true, 2>), tail, block, FB_SMEM, st, p, dq32);
   } else {
-    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<false, false>), grid, block, FB_SMEM, st, p, dq32);
+    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<false, 0>), grid, block, FB_SMEM, st, p, dq32);
+    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<false, 1>), grid, block, FB_SMEM, st, p, dq32);
   }
   const int width = p.H * 64;
   const int64_t total8 = rows * (width / 8);
