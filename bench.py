@@ -57,7 +57,7 @@ class AttnTimer:
             e1.record()
             keys = args[0] if prods == 2 else args[3]
             B, L, _ = qkv.shape
-            store.append((e0, e1, B, L, keys.cnt, keys.n_dec))
+            store.append((e0, e1, B, L, keys.cnt, keys.n_dec, self.ops.LAST_ATTN_BWD_PRODUCTS if prods == 5 else 2))
             return r
         return f
 
@@ -73,15 +73,17 @@ class AttnTimer:
     def _summary(events, products, min_flops=1e9):
         """products: matrix products per (query, key) pair counted as algorithmic work (forward 2, backward 5)."""
         big = []
-        for a, b, B, L, cnt, nd in events:
+        for a, b, B, L, cnt, nd, executed in events:
             dense = 2.0 * products * B * 12 * L * L * 64
             if dense >= min_flops:
                 vis = float((cnt.sum() + cnt.numel() * nd).item())
-                big.append((a.elapsed_time(b) * 1e-3, dense, 2.0 * products * 12 * 64 * L * vis))
+                alg = 2.0 * products * 12 * 64 * L * vis
+                big.append((a.elapsed_time(b) * 1e-3, dense, alg, alg * executed / products, executed))
         if not big:
             return None
-        t, f, fx = sum(x[0] for x in big), sum(x[1] for x in big), sum(x[2] for x in big)
-        return dict(launches=len(big), avg_ms=1e3 * t / len(big), tflops_dense=f / t / 1e12, tflops=fx / t / 1e12, total_ms=1e3 * t)
+        t, f, fx, fe = sum(x[0] for x in big), sum(x[1] for x in big), sum(x[2] for x in big), sum(x[3] for x in big)
+        return dict(launches=len(big), avg_ms=1e3 * t / len(big), tflops_dense=f / t / 1e12, tflops=fx / t / 1e12, tflops_executed=fe / t / 1e12,
+                    total_ms=1e3 * t, fused_launches=sum(1 for x in big if x[4] == 5))
 
     def summary_fwd(self):
         return self._summary(self.fwd, 2)
@@ -396,7 +398,6 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("B%d_F%d_P%d_drop%g" % (B, F, P, args.dropout), {})
-    from vitxt_gqa_amd.ops import ATTN_BWD_PRODUCTS
     fwd_block = bwd_block = None
     if att_f:
         fwd_block = {"kernel": "attn_fwd_bf16_kernel (all launches with >= 1 GFLOP in the timed region)",
@@ -409,15 +410,16 @@ def main():
                              "achieved_dense_mask_equivalent prices the same launches at the reference's dense-mask FLOPs "
                              "4*B*12*L^2*64 (SURVEY 8d) and is not a utilisation"}
     if att_b:
-        bwd_block = {"kernel": "attention backward launch group (attn_delta + %s; all launches with >= 1 GFLOP in the timed region)"
-                               % ("attn_bwd_fused_bf16_kernel" if ATTN_BWD_PRODUCTS == 5 else "attn_dkdv_bf16_kernel + attn_dq_bf16_kernel"),
+        bwd_block = {"kernel": "attention backward launch group (attn_delta + attn_dkdv_bf16_kernel + attn_dq_bf16_kernel, or attn_delta_prep + "
+                               "attn_bwd_fused_bf16_kernel + attn_dq_cast for the launches that take the fused 5-product form; all launches "
+                               "with >= 1 GFLOP in the timed region)",
                      "bound": "mfma", "achieved": att_b["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": att_b["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic.get("attn_bwd"),
-                     "launches": att_b["launches"], "avg_launch_ms": att_b["avg_ms"], "ms_per_step": att_b["total_ms"] / args.steps,
-                     "executed_products": ATTN_BWD_PRODUCTS, "achieved_executed": att_b["tflops"] * ATTN_BWD_PRODUCTS / 5.0,
+                     "launches": att_b["launches"], "fused_5_product_launches": att_b["fused_launches"], "avg_launch_ms": att_b["avg_ms"],
+                     "ms_per_step": att_b["total_ms"] / args.steps, "achieved_executed": att_b["tflops_executed"],
                      "note": "achieved = ALGORITHMIC backward FLOPs over the visible keys (5 products: 10*12*64*L*sum_b(visible keys) per "
                              "launch) / HIP-event time around ops.attn_bwd; achieved_executed counts the products the kernels really "
-                             "run (executed_products per (query, key) pair: S and dP are recomputed when it is 7)"}
+                             "run (7 per (query, key) pair in the two-kernel form, which recomputes S and dP; 5 in the fused form)"}
     # `roofline` = the dominant kernel group of the step (the attention backward in a train step, the forward otherwise)
     if bwd_block is not None:
         res["roofline"], res["roofline_fwd"] = bwd_block, fwd_block

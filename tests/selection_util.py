@@ -39,6 +39,8 @@ def _boundary_ok(vals, k, largest, tol, atol):
     M = vals.shape[-1]
     if k >= M:
         return torch.ones(vals.shape[:-1], dtype=torch.bool)
+    # a score below 1e-30 may have been flushed to zero somewhere inside an fp32 softmax / renormalisation: all of them count as 0
+    vals = torch.where(vals.abs() < 1e-30, torch.zeros_like(vals), vals)
     s = torch.sort(vals, dim=-1, descending=largest).values
     a, b = s[..., k - 1], s[..., k]
     real = torch.minimum(a.abs(), b.abs()) < 1.0                    # at least one of the two is a score, not the -10000 fill

@@ -212,7 +212,15 @@ def test_attn_bwd_fill_equals_zero_fill_path_full_length():
     x = (torch.randn(B, L, 2304, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
     dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
     out, lse = ops.attn_fwd(x, keys)
-    a = ops.attn_bwd(x, out, dout, lse, keys)                               # fill path (keys.valid8 present)
     plain = ops.KeyList(keys.idx, keys.cnt, keys.n_dec, keys.dec_q0, keys.cap_hint, None)
-    b = ops.attn_bwd(x, out, dout, lse, plain)                              # zero-fill path
+    a = ops.attn_bwd(x, out, dout, lse, keys, fused=False)                  # fill path (keys.valid8 present), two-kernel form
+    b = ops.attn_bwd(x, out, dout, lse, plain, fused=False)                 # zero-fill path
     assert torch.equal(a, b)
+    # the fused five-product form: dK / dV deterministic and equal between its two fill paths, dQ (summed with float atomics)
+    # equal to rounding; all of it within bf16 rounding of the two-kernel form
+    fa = ops.attn_bwd(x, out, dout, lse, keys, fused=True)
+    fb = ops.attn_bwd(x, out, dout, lse, plain, fused=True)
+    assert torch.equal(fa[..., 768:], fb[..., 768:])
+    sc = a.float().abs().max().item()
+    assert (fa[..., :768].float() - fb[..., :768].float()).abs().max().item() < 1e-2 * sc
+    assert (fa.float() - a.float()).abs().max().item() < 3e-2 * sc

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Where a query tile of the fused attention backward spends its cycles: builds a DIAGNOSTIC copy of the library with -DFB_STAMP
+(s_memtime stamps around the segments of the tile loop, summed per workgroup by wave 0), runs one launch and prints the
+shares.  The stamps serialise the segments (fences), so read the SHARES, not the total (cdna_hip_programming.md section 7).
+usage (GPU box): python tools/fused_stamps.py [B keep]"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "tools", "ablate", "_build")
+os.makedirs(out, exist_ok=True)
+lib = os.path.join(out, "libt2s_stamp.so")
+from vitxt_gqa_amd import build as Bld  # noqa: E402
+subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-DFB_STAMP", "-o", lib] + Bld.sources())
+os.environ["T2S_HIP_LIB"] = lib
+import torch  # noqa: E402
+from vitxt_gqa_amd import ops  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+keep = float(sys.argv[2]) if len(sys.argv) > 2 else 0.7
+L1, nd = 10120, 12
+L = L1 + nd
+torch.manual_seed(0)
+qkv = torch.randn(B, L, 2304, device="cuda", dtype=torch.bfloat16)
+dout = torch.randn(B, L, 768, device="cuda", dtype=torch.bfloat16)
+valid = torch.rand(B, L1, device="cuda") < keep
+valid[:, 0] = True
+keys = ops.compact_keys(valid, n_dec=nd, dec_row0=L1)
+o, lse = ops.attn_fwd(qkv, keys)
+for _ in range(3):
+    ops.attn_bwd(qkv, o, dout, lse, keys, fused=True)
+torch.cuda.synchronize()
+d = ops._LAST_DQ32[B * L * 768:].view(torch.int64).view(-1, 8)[:256].cpu()
+d = d[d[:, 6] > 0]
+names = ["phase A", "stage write", "barrier 1", "phase B", "atomics", "barrier 2"]
+tiles = d[:, 6].double()
+per = d[:, :6].double() / tiles.unsqueeze(1)
+print("workgroups sampled: %d, tiles per workgroup %d" % (len(d), int(tiles[0])))
+tot = per.sum(1).mean().item()
+for i, n in enumerate(names):
+    print("  %-12s %8.0f cycles per tile  (%4.1f %%)" % (n, per[:, i].mean().item(), 100 * per[:, i].mean().item() / tot))
+print("  %-12s %8.0f cycles per tile (stamped build; MFMA time of a tile: 120 x 32 = 3840)" % ("sum", tot))

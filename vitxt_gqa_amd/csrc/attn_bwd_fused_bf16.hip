@@ -121,13 +121,19 @@ __device__ __forceinline__ void fb_g2(f32x16 (&dvacc)[FB_KB][2], f32x16 (&dkacc)
     FB_MFMA_A(dkacc[kb][db], qT[s][db], b);
   }
 }
-// chunk m (registers 2m, 2m+1) of the softmax of block I: P = exp2(S'), packed bf16 operand word
-template <int I, int M>
-__device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8]) {
-  constexpr int par = I & 1;
-  const float p0 = fast_exp2(sacc[par][2 * M]), p1 = fast_exp2(sacc[par][2 * M + 1]);
-  sacc[par][2 * M] = p0;
-  sacc[par][2 * M + 1] = p1;
+// chunk m (registers 2m, 2m+1) of the softmax of block I: P = exp2(S'), packed bf16 operand word.  EDGE: the validity /
+// decoder rule - this lane's key is visible to the tile rows >= thr (thr = first visible row - row of register 0 of this lane;
+// register r is row (r & 3) + 8 (r >> 2) above it), so one compare + select per score
+template <int I, int M, bool EDGE>
+__device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], const int thr) {
+  constexpr int par = I & 1, r0 = 2 * M, r1 = 2 * M + 1;
+  float p0 = fast_exp2(sacc[par][r0]), p1 = fast_exp2(sacc[par][r1]);
+  if (EDGE) {
+    p0 = ((r0 & 3) + 8 * (r0 >> 2)) >= thr ? p0 : 0.f;
+    p1 = ((r1 & 3) + 8 * (r1 >> 2)) >= thr ? p1 : 0.f;
+  }
+  sacc[par][r0] = p0;
+  sacc[par][r1] = p1;
   pfw[M] = fb_pack2(p0, p1);
 }
 // chunk m of dS = P * dP' of block I
@@ -138,8 +144,9 @@ __device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dp
 }
 
 // MODE 0: workgroups whose 384 keys are all valid prefix keys run the software-pipelined sweep, the others exit; MODE 1: the
-// complement (the general sweep with the validity / decoder rule and skipped key blocks); MODE 2: the tail launch (general
-// sweep, loops over the key blocks beyond the static bound).  Separate kernels, so that each is register-allocated for one sweep.
+// complement (the same pipeline with the validity / decoder rule applied to P; waves without a valid key skip phase A); MODE 2:
+// the tail launch (plain sweep, loops over the key blocks beyond the static bound).  Separate kernels, so that each is
+// register-allocated for one sweep.
 template <bool USE_IDX, int MODE>
 __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams p, float* __restrict__ dq32) {
   constexpr bool TAIL = MODE == 2;
@@ -271,10 +278,46 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int dq_qb = wave_u >> 1, dq_db = wave_u & 1;          // this wave's 32 x 32 tile of dQ (provably wave-uniform)
+    const int vaq[2] = {dq_qb ? va[1][0] : va[0][0], dq_qb ? va[1][1] : va[0][1]};
+    const int vad[2] = {dq_db ? va[1][0] : va[0][0], dq_db ? va[1][1] : va[0][1]};
+    // EDGE: first tile row that sees this lane's key of block kb (prefix keys: every row; keys past the list: none)
+    int qmin[FB_KB];
+#pragma unroll
+    for (int kb = 0; kb < FB_KB; ++kb) qmin[kb] = !kvalid[kb] ? (1 << 30) : (kdec[kb] < 0 ? -(1 << 30) : p.dec_q0 + kdec[kb]);
     // the query sweep in two compiled forms behind ONE workgroup-uniform branch: FULL = all 384 keys valid prefix keys (no
     // validity / decoder rule, no skipped key blocks: straight-line code), and the general form
-    auto sweep = [&](auto full_tag) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(full_tag)::value;
+    auto sweep = [&](auto pipe_tag, auto edge_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(pipe_tag)::value;         // the software-pipelined phase A (all three key blocks of every wave run)
+    constexpr bool EDGE = decltype(edge_tag)::value;         // ... with the validity / decoder rule applied to P
+    constexpr bool PREF = FULL && !EDGE;                     // the first operands of tile t+1 are fetched from LDS during phase B of tile t
+    bf16x8 qf[4], dof[4], kf[4];
+    f32x16 sacc[2], dpacc[2];
+    const char* kw_ = kimg + wave * (FB_WKEYS * 128);
+#define FB_LD_QF(qbase_, dobase_, sb_)                                                              \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
+    qf[s] = *reinterpret_cast<const bf16x8*>((qbase_) + ka[s] + (sb_) * 4096);                      \
+    dof[s] = *reinterpret_cast<const bf16x8*>((dobase_) + ka[s] + (sb_) * 4096);                    \
+  }
+#define FB_LD_SEEDS(lse_, del_, i_)  /* accumulators of block i start from the row constants of this lane's rows (broadcast reads) */  \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>((lse_) + ((i_) / 3) * 32 + 8 * g + 4 * lh);    \
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>((del_) + ((i_) / 3) * 32 + 8 * g + 4 * lh);    \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) { sacc[(i_) & 1][4 * g + j] = l4[j]; dpacc[(i_) & 1][4 * g + j] = d4[j]; }  \
+  }
+#define FB_LD_KF(kb_)                                                                               \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kw_ + ka[s] + (kb_) * 4096);
+    if (PREF) {          // tile 0's first operands (stage buffer 0 was written and fenced by the barrier above)
+      FB_LD_QF(stage, stage + FB_TILE, 0);
+      FB_LD_SEEDS(reinterpret_cast<const float*>(stage + 2 * FB_TILE), reinterpret_cast<const float*>(stage + 2 * FB_TILE) + FB_QROWS, 0);
+      FB_LD_KF(0);
+    }
+#ifdef FB_STAMP   // diagnostic build only (tools/ablate): where a tile's cycles go; never defined in a product build
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
+#define FB_TICK(k_) { FB_FENCE(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1) :: "memory"); st_sum[k_] += st_t1 - st_t0; st_t0 = st_t1; FB_FENCE(); }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0) :: "memory");
+#else
+#define FB_TICK(k_)
+#endif
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
       FB_STAGE_LOAD();                                      // next tile in sequence (past the end: clamped rows, harmless)
@@ -284,39 +327,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       const float* del_s = lse_s + FB_QROWS;
       // ================= phase A: S, dP, dS, dV^T, dK^T per (query sub-block, key block) =================
       if constexpr (FULL) {
+        if (!EDGE || wave_u * FB_WKEYS < nkeys_wg) {        // EDGE: a wave whose 96 keys all lie past the list has nothing to add
         // Software pipeline over the tile's six blocks b_i = (query sub-block i / 3, key block i % 3).  One wave per SIMD issues in
         // order, so an MFMA only overlaps VALU / LDS work that stands BETWEEN it and the next MFMA in the instruction stream.
         // Slots of 8 MFMAs each, fenced into one-MFMA groups:
-        //   G1(b0) | G1(b1) + E(b0) | G2(b0) + M(b0) | G1(b2) + E(b1) | G2(b1) + M(b1) | ... | G1(b5) + E(b4) | G2(b4) + M(b4) + E(b5) | G2(b5) + M(b5)
+        //   G1(b0) | G1(b1) + E(b0) | G2(b0) + M(b0) | G1(b2) + E(b1) | G2(b1) + M(b1) | ... | G1(b5) + E(b4) | G2(b4) + M(b4), E(b5) | G2(b5) + M(b5)
         // G1 = S, dP chains (row constants through the C operand of the first MFMA); E = P = exp2(S') and its bf16 operand
         // words (2 v_exp + 1 cvt per group); G2 = 4 dV^T MFMAs (need P) then 4 dK^T MFMAs (need dS); M = dS = P dP' (4 mul + 2 cvt
         // per group, in the dV^T half).  Every consumer stands at least one MFMA group behind the MFMA that produces its input
         // (S3 is the 7th MFMA of a G1, E starts in the next slot; dP3 is the 8th, M starts a whole slot later): the wait states the
         // hardware does not interlock are covered by construction.  LDS loads of a slot's successor are issued at its head.
-        bf16x8 qf[4], dof[4], qT[2][2], doT[2][2], kf[4];
-        f32x16 sacc[2], dpacc[2];
+        bf16x8 qT[2][2], doT[2][2];
+        int thr[2] = {0, 0};          // EDGE: visibility threshold of the block whose softmax runs (by block parity)
+        const int rowb = qt * FB_QROWS + 4 * lh;
+#define FB_THR(i_) if (EDGE) thr[(i_) & 1] = qmin[(i_) % 3] - rowb - ((i_) / 3) * 32;
         uint32_t pfw[8], dsw[8];
-        const char* kw_ = kimg + wave * (FB_WKEYS * 128);
         char* dsw_ = dsimg + wave * (FB_WKEYS * 128) + 8 * lh;
-#define FB_LD_QF(sb_)                                                                               \
-  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
-    qf[s] = *reinterpret_cast<const bf16x8*>(qb_ + ka[s] + (sb_) * 4096);                           \
-    dof[s] = *reinterpret_cast<const bf16x8*>(dob_ + ka[s] + (sb_) * 4096);                         \
-  }
-#define FB_LD_SEEDS(i_)  /* accumulators of block i start from the row constants of this lane's rows (broadcast reads) */  \
-  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
-    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ((i_) / 3) * 32 + 8 * g + 4 * lh);     \
-    const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + ((i_) / 3) * 32 + 8 * g + 4 * lh);     \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) { sacc[(i_) & 1][4 * g + j] = l4[j]; dpacc[(i_) & 1][4 * g + j] = d4[j]; }  \
-  }
 #define FB_LD_QT(sb_)                                                                               \
   _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                     \
   _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                \
     qT[s][db] = fb_tr(qb_ + ((sb_) * 32 + 16 * s) * 128, va[db]);                                   \
     doT[s][db] = fb_tr(dob_ + ((sb_) * 32 + 16 * s) * 128, va[db]);                                 \
   }
-#define FB_LD_KF(kb_)                                                                               \
-  _Pragma("unroll") for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kw_ + ka[s] + (kb_) * 4096);
 #define FB_ST_DS(i_)     /* dS^T image rows of block i: queries sb*32 + 16s + {0..3, 8..11} + 4lh of this lane's key */  \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
     *reinterpret_cast<uint2*>(dsw_ + ((i_) % 3) * 4096 + (wrow + (((4 * ((i_) / 3) + 2 * s) << 4) ^ wxor))) = make_uint2(dsw[4 * s], dsw[4 * s + 1]);          \
@@ -324,10 +356,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   }
 #define FB_G1(i_, m_) fb_g1<i_, m_>(sacc, dpacc, qf, dof, kf, vf)
 #define FB_G2(i_, m_) fb_g2<i_, m_>(dvacc, dkacc, doT, qT, pfw, dsw)
-#define FB_E(i_, m_) fb_ve<i_, m_>(sacc, pfw)
+#define FB_E(i_, m_) fb_ve<i_, m_, EDGE>(sacc, pfw, thr[(i_) & 1])
 #define FB_M(i_, m_) fb_vm<i_, m_>(sacc, dpacc, dsw)
         // slot "G1(n) + E(e)": eight groups of one MFMA of G1(b_n) and one chunk of E(b_e)
 #define FB_SLOT_G1E(n_, e_)                                                                         \
+  FB_THR(e_);                                                                                       \
   FB_G1(n_, 0); FB_E(e_, 0); FB_FENCE(); FB_G1(n_, 1); FB_E(e_, 1); FB_FENCE(); FB_G1(n_, 2); FB_E(e_, 2); FB_FENCE();            \
   FB_G1(n_, 3); FB_E(e_, 3); FB_FENCE(); FB_G1(n_, 4); FB_E(e_, 4); FB_FENCE(); FB_G1(n_, 5); FB_E(e_, 5); FB_FENCE();            \
   FB_G1(n_, 6); FB_E(e_, 6); FB_FENCE(); FB_G1(n_, 7); FB_E(e_, 7); FB_FENCE();
@@ -335,19 +368,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #define FB_SLOT_G2M(i_)                                                                             \
   FB_G2(i_, 0); FB_M(i_, 0); FB_M(i_, 1); FB_FENCE(); FB_G2(i_, 1); FB_M(i_, 2); FB_M(i_, 3); FB_FENCE();                        \
   FB_G2(i_, 2); FB_M(i_, 4); FB_M(i_, 5); FB_FENCE(); FB_G2(i_, 3); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE();                        \
-  FB_G2(i_, 4); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS((i_) + 2); } FB_FENCE();               \
+  FB_G2(i_, 4); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE();               \
   FB_G2(i_, 6); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
-        FB_LD_QF(0); FB_LD_SEEDS(0); FB_LD_KF(0);
+        if (!PREF) { FB_LD_QF(qb_, dob_, 0); FB_LD_SEEDS(lse_s, del_s, 0); FB_LD_KF(0); }
         FB_FENCE();
         // slot 0: G1(b0), nothing to pair yet; the transposed fragments of sub-block 0 arrive meanwhile
-        FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
+        FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
         FB_LD_KF(1); FB_FENCE();
         FB_SLOT_G1E(1, 0);
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(0);
         FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
-        FB_LD_QF(1); FB_LD_KF(0); FB_FENCE();
+        FB_LD_QF(qb_, dob_, 1); FB_LD_KF(0); FB_FENCE();
         FB_SLOT_G2M(1);
         FB_SLOT_G1E(3, 2);
         FB_LD_KF(1); FB_FENCE();
@@ -357,16 +390,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(3);
         FB_SLOT_G1E(5, 4);
-        // slot "G2(b4) + M(b4) + E(b5)"
-        FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_E(5, 0); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_E(5, 1); FB_FENCE();
-        FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_E(5, 2); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_E(5, 3); FB_FENCE();
-        FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 4); FB_FENCE(); FB_G2(4, 5); FB_E(5, 5); FB_FENCE(); FB_G2(4, 6); FB_E(5, 6); FB_FENCE();
-        FB_G2(4, 7); FB_E(5, 7); FB_FENCE();
+        // slot "G2(b4) + M(b4) + E(b5)": E(b5) only behind the dV^T MFMAs of b4, which still read the operand words of P(b4)
+        FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_FENCE();
+        FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_FENCE();
+        FB_THR(5);
+        FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 0); FB_E(5, 1); FB_FENCE(); FB_G2(4, 5); FB_E(5, 2); FB_E(5, 3); FB_FENCE();
+        FB_G2(4, 6); FB_E(5, 4); FB_E(5, 5); FB_FENCE(); FB_G2(4, 7); FB_E(5, 6); FB_E(5, 7); FB_FENCE();
         FB_SLOT_G2M(5);
-#undef FB_LD_QF
-#undef FB_LD_SEEDS
+#undef FB_THR
 #undef FB_LD_QT
-#undef FB_LD_KF
 #undef FB_ST_DS
 #undef FB_G1
 #undef FB_G2
@@ -374,6 +406,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_M
 #undef FB_SLOT_G1E
 #undef FB_SLOT_G2M
+        }
       } else {
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
@@ -436,36 +469,70 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         }
       }
       }   // general form
+      // Stage the next tile here, at the end of phase A: the global loads issued at the top of the tile have long landed (the
+      // LDS writes wait on vmcnt, which retires in order - behind the 16 atomics of phase B that wait would last their
+      // ~3000-cycle round trip), the buffer was last read in phase A of the previous tile, and the barrier below publishes it,
+      // so that phase B can already fetch the next tile's first operands.
+      FB_TICK(0);                                            // phase A
+      FB_STAGE_WRITE(buf ^ 1);
+      FB_TICK(1);                                            // stage write
       __syncthreads();                                       // the dS^T image of this query tile is complete
+      FB_TICK(2);                                            // barrier 1
       // ================= phase B: dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
       {
         f32x16 dqacc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqacc[i] = 0.f;
-        if (FULL) {          // 24 steps in groups of 4: the transposed reads of a group run ahead of its MFMAs
-          for (int k4 = 0; k4 < FB_KEYS / 16; k4 += 4) {
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              af[u] = lds_tr_frag(dsimg, 16 * (k4 + u), dq_qb, lane);
-              bfr[u] = lds_tr_frag(kimg, 16 * (k4 + u), dq_db, lane);
-            }
-            asm("s_nop 1\n\t"
-                "v_mfma_f32_32x32x16_bf16 %0, %1, %5, %0\n\t"
-                "v_mfma_f32_32x32x16_bf16 %0, %2, %6, %0\n\t"
-                "v_mfma_f32_32x32x16_bf16 %0, %3, %7, %0\n\t"
-                "v_mfma_f32_32x32x16_bf16 %0, %4, %8, %0"
-                : "+v"(dqacc)
-                : "v"(FB_U4(af[0])), "v"(FB_U4(af[1])), "v"(FB_U4(af[2])), "v"(FB_U4(af[3])), "v"(FB_U4(bfr[0])), "v"(FB_U4(bfr[1])),
-                  "v"(FB_U4(bfr[2])), "v"(FB_U4(bfr[3])));
+        // steps of 16 keys in groups of 4; full key blocks: 24 steps with the transposed reads of group g+1 in flight under the
+        // MFMAs of group g, otherwise the steps that hold valid keys (rows past them may never have been written)
+#define FB_DQ_LOAD(af_, bf_, g_)                                                                    \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
+    af_[u] = fb_tr(dsimg + (16 * (4 * (g_) + u)) * 128, vaq);                                       \
+    bf_[u] = fb_tr(kimg + (16 * (4 * (g_) + u)) * 128, vad);                                        \
+  }
+#define FB_DQ_MFMA(af_, bf_)                                                                        \
+  asm("s_nop 1\n\t"                                                                                \
+      "v_mfma_f32_32x32x16_bf16 %0, %1, %5, %0\n\t"                                                \
+      "v_mfma_f32_32x32x16_bf16 %0, %2, %6, %0\n\t"                                                \
+      "v_mfma_f32_32x32x16_bf16 %0, %3, %7, %0\n\t"                                                \
+      "v_mfma_f32_32x32x16_bf16 %0, %4, %8, %0"                                                     \
+      : "+v"(dqacc)                                                                                 \
+      : "v"(FB_U4(af_[0])), "v"(FB_U4(af_[1])), "v"(FB_U4(af_[2])), "v"(FB_U4(af_[3])), "v"(FB_U4(bf_[0])), "v"(FB_U4(bf_[1])),  \
+        "v"(FB_U4(bf_[2])), "v"(FB_U4(bf_[3])));
+        if constexpr (PREF) {
+          bf16x8 afA[4], bfA[4], afB[4], bfB[4];
+          FB_DQ_LOAD(afA, bfA, 0);
+          FB_DQ_LOAD(afB, bfB, 1);
+          {   // the next tile's first operands (its stage buffer was published by the barrier above)
+            const char* nq_ = stage + (buf ^ 1) * FB_STAGE;
+            FB_LD_QF(nq_, nq_ + FB_TILE, 0);
+            FB_LD_SEEDS(reinterpret_cast<const float*>(nq_ + 2 * FB_TILE), reinterpret_cast<const float*>(nq_ + 2 * FB_TILE) + FB_QROWS, 0);
+            FB_LD_KF(0);
           }
+          FB_FENCE();
+          FB_DQ_MFMA(afA, bfA); FB_DQ_LOAD(afA, bfA, 2); FB_FENCE();
+          FB_DQ_MFMA(afB, bfB); FB_DQ_LOAD(afB, bfB, 3); FB_FENCE();
+          FB_DQ_MFMA(afA, bfA); FB_DQ_LOAD(afA, bfA, 4); FB_FENCE();
+          FB_DQ_MFMA(afB, bfB); FB_DQ_LOAD(afB, bfB, 5); FB_FENCE();
+          FB_DQ_MFMA(afA, bfA); FB_FENCE();
+          FB_DQ_MFMA(afB, bfB);
         } else {
-          for (int ks = 0; ks < nks; ++ks) {
-            const bf16x8 a1 = lds_tr_frag(dsimg, 16 * ks, dq_qb, lane), b1 = lds_tr_frag(kimg, 16 * ks, dq_db, lane);
+          const int nsteps = FULL ? (EDGE ? nks : FB_KEYS / 16) : nks;
+          int k4 = 0;
+          for (; k4 + 4 <= nsteps; k4 += 4) {
+            bf16x8 af[4], bfr[4];
+            FB_DQ_LOAD(af, bfr, k4 >> 2);
+            FB_DQ_MFMA(af, bfr);
+          }
+          for (; k4 < nsteps; ++k4) {
+            const bf16x8 a1 = fb_tr(dsimg + (16 * k4) * 128, vaq), b1 = fb_tr(kimg + (16 * k4) * 128, vad);
             asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(a1)), "v"(FB_U4(b1)));
           }
         }
+#undef FB_DQ_LOAD
+#undef FB_DQ_MFMA
         asm volatile("s_nop 11" : "+v"(dqacc));              // MFMA result -> VALU read
+        FB_TICK(3);                                          // phase B MFMAs
         // dS (K c) = c dS K;  dQ = scale dS K = acc * ln 2.  Register r = query row acc_row(r, lh), 32 consecutive dims per
         // half wave: two 128-byte segments per wave instruction
         const int q0 = qt * FB_QROWS + dq_qb * 32;
@@ -481,11 +548,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             if (q0 + acc_row(r, lh) < p.Lq) unsafeAtomicAdd(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
         }
       }
-      FB_STAGE_WRITE(buf ^ 1);
-      __syncthreads();                                       // next tile staged; every wave is done reading the dS^T image
+      FB_TICK(4);                                            // atomics
+      __syncthreads();                                       // every wave is done reading the dS^T image
+      FB_TICK(5);                                            // barrier 2
     }
+#ifdef FB_STAMP
+    if (MODE == 0 && lane == 0 && wave == 0) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(dq32 + (int64_t)p.B * p.Lq * (p.H * 64)) + (int64_t)(blockIdx.x & 255) * 8;
+      for (int k = 0; k < 6; ++k) dbg[k] = st_sum[k];
+      dbg[6] = (unsigned long long)nqt;
+    }
+#endif
     };
-    sweep(std::integral_constant<bool, MODE == 0>{});
+    sweep(std::integral_constant<bool, MODE != 2>{}, std::integral_constant<bool, MODE == 1>{});
+#undef FB_LD_QF
+#undef FB_LD_SEEDS
+#undef FB_LD_KF
     // dK^T / dV^T were last written by asm MFMAs the compiler does not see as such: cover MFMA result -> v_accvgpr_read
 #pragma unroll
     for (int kb = 0; kb < FB_KB; ++kb)

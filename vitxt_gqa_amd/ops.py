@@ -13,9 +13,10 @@ from . import hipext as X
 HID = 768
 HEADS = 12
 HEAD_DIM = 64
-# matrix products per (query, key) pair the attention backward EXECUTES: the algorithm needs 5 (S, dP, dV, dK, dQ); the
-# two-kernel form (key-stationary dK/dV + query-stationary dQ, no atomics) recomputes S and dP: 7.  bench.py reports both.
-ATTN_BWD_PRODUCTS = 7
+# matrix products per (query, key) pair the attention backward EXECUTES: the algorithm needs 5 (S, dP, dV, dK, dQ); the fused form
+# (t2s_attn_bwd_fused) runs exactly those, the two-kernel form (key-stationary dK/dV + query-stationary dQ, no atomics) recomputes
+# S and dP: 7.  attn_bwd() records which form a call took in LAST_ATTN_BWD_PRODUCTS (bench.py reports executed and algorithmic).
+LAST_ATTN_BWD_PRODUCTS = 7
 
 
 def _rows768(t):
@@ -81,6 +82,8 @@ def attn_fwd(qkv, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0):
 # True: bf16 launches without attention dropout use the fused 5-product kernel (t2s_attn_bwd_fused: S and dP computed once, dQ summed
 # across key blocks with fp32 atomics); False: always the two-kernel 7-product form.
 ATTN_BWD_FUSED = os.environ.get("T2S_ATTN_BWD_FUSED", "1") != "0"
+ATTN_BWD_FUSED_MIN_KEYS = 2048
+_LAST_DQ32 = None      # tools/fused_stamps.py reads the diagnostic build's cycle stamps from its tail
 
 
 def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, fused=None):
@@ -103,9 +106,19 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     dims = (B, HEADS, L, cap, keys.n_dec, keys.dec_q0, keys.cap_hint,
             qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
             scale, X.dtype_code(qkv))
-    use_fused = (ATTN_BWD_FUSED if fused is None else fused) and qkv.dtype == torch.bfloat16 and drop_p == 0.0
+    # default policy: the fused form for launches that may see most of the sequence as keys; launches with a small static key
+    # bound (the pos / neg passes: <= 537 / 62 keys) stay on the two-kernel form, whose 128-key blocks and two waves per SIMD
+    # suit a handful of keys better than 384-key blocks at one wave per SIMD (tools/attn_probe.py: 0.88 vs 1.9 ms at 516 keys, B=8)
+    if fused is None:
+        fused = ATTN_BWD_FUSED and keys.cap_hint >= ATTN_BWD_FUSED_MIN_KEYS
+    use_fused = fused and qkv.dtype == torch.bfloat16 and drop_p == 0.0
+    global LAST_ATTN_BWD_PRODUCTS
+    LAST_ATTN_BWD_PRODUCTS = 5 if use_fused else 7
     if use_fused:
-        dq32 = torch.empty(B, L, HID, dtype=torch.float32, device=qkv.device)        # fp32 dQ accumulation workspace (zeroed in the call)
+        # fp32 dQ accumulation workspace (zeroed in the call); 16 KB of slack behind it for the stamps of the diagnostic build
+        dq32 = torch.empty(B * L * HID + 4096, dtype=torch.float32, device=qkv.device)
+        global _LAST_DQ32
+        _LAST_DQ32 = dq32
         X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(dq32), *klist, X.ptr(keys.valid8) if fill_in_kernel else None, *dims, X.stream()),
                 "t2s_attn_bwd_fused")
     elif fill_in_kernel:
