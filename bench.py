@@ -262,7 +262,7 @@ def main():
 
     from vitxt_gqa_amd import training_config
     from vitxt_gqa_amd.ddp import GradBuckets
-    from vitxt_gqa_amd.optim import build_optimizer, clip_gradients, lr_lambda_update
+    from vitxt_gqa_amd.optim import build_optimizer, clip_and_step, lr_lambda_update
     from vitxt_gqa_amd.synth import make_batch, make_noise
     from vitxt_gqa_amd.testing import make_model, to_device
 
@@ -287,8 +287,7 @@ def main():
         buckets.reset()
         loss.backward()
         buckets.finish()
-        clip_gradients(model, cfg)
-        opt.step()
+        clip_and_step(model, opt, cfg)          # global-norm clip 0.25 + Adam (one fused multi-tensor pass)
         sched.step()
         return loss
 

@@ -60,7 +60,7 @@ int t2s_compact_keys(const uint8_t* valid, int32_t* out_idx, int32_t* out_cnt, i
  * lse: [B, H, Lq] fp32, natural-log-sum-exp of the scaled scores (saved for backward).
  * drop_p > 0: attention-probability dropout (BertSelfAttention: dropout(softmax(.)) before .V):
  * out = (softmax(.) * keep / (1 - p')) V, keep(b, h, q, list position) a stateless function of drop_seed
- * (vitxt_gqa_amd/csrc/attn_common.h), p' = round(256 p)/256 (one byte per score); the mask needs no workspace.  The backward call
+ * (vitxt_gqa_amd/csrc/attn_common.h), p' = round(65536 p)/65536 (a 16-bit threshold: 0.1 -> 0.100006); the mask needs no workspace.  The backward call
  * regenerates the mask from the same seed; t2s_attn_dropout_mask exports it. */
 int t2s_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                  const int32_t* kv_idx, const int32_t* kv_cnt,
@@ -236,6 +236,21 @@ int t2s_infonce_bwd(const float* q, const float* p, const float* n, const float*
  * (14 unigram regions x 36 + 2 bigram regions x 50).  A byte outside [a-z0-9] before the first NUL - where the
  * reference raises RuntimeError - turns that token's row into NaN; the host wrapper rejects such input beforehand. */
 int t2s_phoc(const uint8_t* tokens, int64_t n_tokens, int width, float* out, int64_t out_row_stride, t2s_stream_t stream);
+
+/* ---- global-norm clip + Adam, multi-tensor (BaseTrainer._backward pythia/trainers/base_trainer.py:262-272: clip_gradients
+ * pythia/utils/general.py:32-41 = torch.nn.utils.clip_grad_norm_(params, max_norm), then torch.optim.Adam.step(),
+ * build_utils.py:54-83; weight_decay 0, no amsgrad).  desc: device table [n_tensors, 5] int64 rows (param, grad, exp_avg,
+ * exp_avg_sq pointers - fp32, contiguous - and numel); chunks: device table [n_chunks, 2] int32 rows (tensor, chunk within the
+ * tensor) with t2s_optim_chunk_elems() elements per chunk; partials: [n_chunks] fp32 workspace; norm_coef: [2] fp32 = (total
+ * L2 norm, clip coefficient min(1, max_norm / (norm + 1e-6))); group_of: device [n_tensors] int32 param-group index; group_lr:
+ * HOST array of n_groups <= 8 learning rates; step: 1-based Adam step count (bias corrections); norm_coef may be NULL for
+ * t2s_adam_step (no clipping); write_grad != 0 writes the clipped gradients back (the reference clips p.grad in place). */
+int t2s_optim_chunk_elems(void);
+int t2s_grad_sqnorm(const int64_t* desc, const int32_t* chunks, int n_chunks, float* partials, t2s_stream_t stream);
+int t2s_clip_coef(const float* partials, int n_chunks, float max_norm, float* norm_coef, t2s_stream_t stream);
+int t2s_adam_step(const int64_t* desc, const int32_t* chunks, int n_chunks, const int32_t* group_of,
+                  const float* group_lr, int n_groups, float beta1, float beta2, float eps, int step,
+                  const float* norm_coef, int write_grad, t2s_stream_t stream);
 
 #ifdef __cplusplus
 }

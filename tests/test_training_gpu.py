@@ -96,3 +96,36 @@ def test_bf16_dropout_training_learns_a_fixed_batch():
         assert torch.isfinite(loss)
     first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
     assert last < 0.8 * first, losses
+
+
+def test_fused_clip_adam_matches_torch_clip_and_adam():
+    """FusedClipAdam.step_clipped (t2s_grad_sqnorm / t2s_clip_coef / t2s_adam_step) against torch.nn.utils.clip_grad_norm_ +
+    torch.optim.Adam over several steps on tensors of awkward sizes (ragged tails, more than one 64 Ki chunk, two param groups
+    with different learning rates, a parameter without a gradient), and its state_dict loads into a plain torch Adam."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vitxt_gqa_amd.optim import FusedClipAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(768, 768), (3072,), (5, 7), (1,), (200003,), (64, 1025)]
+    pa = [torch.nn.Parameter(torch.randn(*s_, generator=g).to(DEV)) for s_ in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    dead_a, dead_b = torch.nn.Parameter(torch.ones(3, device=DEV)), torch.nn.Parameter(torch.ones(3, device=DEV))
+    oa = FusedClipAdam([{"params": pa[:4] + [dead_a]}, {"params": pa[4:], "lr": 3e-4}], lr=1e-3, eps=1e-8)
+    ob = torch.optim.Adam([{"params": pb[:4] + [dead_b]}, {"params": pb[4:], "lr": 3e-4}], lr=1e-3, eps=1e-8)
+    for step in range(4):
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g).to(DEV) * (10.0 if step == 1 else 0.01)     # step 1 clips hard, the others do not
+            x.grad, y.grad = gr.clone(), gr.clone()
+        na = oa.step_clipped(0.25)
+        nb = torch.nn.utils.clip_grad_norm_(pb + [dead_b], 0.25)
+        ob.step()
+        assert abs(na.item() - nb.item()) < 1e-5 * nb.item()
+        for x, y in zip(pa, pb):
+            assert (x.grad - y.grad).abs().max().item() <= 1e-6 * y.grad.abs().max().item() + 1e-12        # clipped in place, as the reference
+            assert (x - y).abs().max().item() < 2e-6, step
+    assert torch.equal(dead_a, dead_b)
+    sd = oa.state_dict()
+    assert set(sd["state"]) == set(ob.state_dict()["state"]) and sd["state"][0]["step"].item() == 4.0
+    oc = torch.optim.Adam([{"params": pb[:4] + [dead_b]}, {"params": pb[4:], "lr": 3e-4}], lr=1e-3, eps=1e-8)
+    oc.load_state_dict(sd)                                                  # the reference's optimizer can resume from it
+    assert torch.allclose(oc.state_dict()["state"][4]["exp_avg"], ob.state_dict()["state"][4]["exp_avg"], atol=1e-7)

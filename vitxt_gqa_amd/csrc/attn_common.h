@@ -22,8 +22,8 @@ struct AttnParams {
   float scale;
   // attention-probability dropout (BertSelfAttention: dropout(softmax(.)) before .V); thresh == 0 disables it
   uint32_t drop_seed_lo, drop_seed_hi;
-  uint32_t drop_thresh;          // drop iff byte < thresh, thresh = round(p * 256)
-  float drop_inv;                // 1 / (1 - thresh/256)
+  uint32_t drop_thresh;          // 16-bit threshold round(p * 65536) in [1, 65535]: drop iff the score's 16-bit value is below it
+  float drop_inv;                // 1 / (1 - thresh / 65536)
   // backward, optional: row_valid [B, valid_len] bytes, 0 = the prefix row is NOT in the key list.  The dQ kernel, which
   // visits every (row, head) anyway, then writes the zeros of that row's dK / dV slices, so the caller need not zero-fill
   // the gradient buffer (rows >= valid_len, the decoder rows, are always listed)
@@ -34,7 +34,7 @@ struct AttnParams {
 // ---- attention-probability dropout.  keep(q, kpos) is a stateless function of (seed, sample, head, q, kpos) so that
 // the forward, dQ and dK/dV kernels regenerate the same mask in their different register layouts; kpos is the POSITION
 // in the compacted key list.  The function is built to cost ~3 VALU instructions per score in kernels that are VALU
-// bound:   t(q, kpos) = ((rowkey16(q) ^ colkey16(kpos)) * 0x9E37 mod 2^16) read as int16,   keep iff t >= thresh * 256 - 32768
+// bound:   t(q, kpos) = ((rowkey16(q) ^ colkey16(kpos)) * 0x9E37 mod 2^16) read as int16,   keep iff t >= thresh - 32768   (thresh = round(65536 p): p' = p to 1.5e-5)
 // where rowkey16 / colkey16 are 16 bits of full-quality 32-bit hashes of (seed, sample, head, q) and (seed, sample, head,
 // kpos).  Those hashes are per-lane constants on the stationary axis and are computed once per tile (32 threads, one
 // key pair each, staged in LDS) on the streamed axis, so the per-score work is xor + multiply + compare - and it is
@@ -60,11 +60,11 @@ __device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) 
 #endif
 constexpr uint32_t ATTN_DROP_MUL = 0x9E37u;
 // generic per-element form (fp32 kernels, mask export).  The 16-bit product is read as a SIGNED number and compared with
-// thresh * 256 - 32768: the same drop probability thresh / 256 as an unsigned byte compare, without the flip of the top
+// thresh - 32768: the same drop probability thresh / 65536 as an unsigned 16-bit compare, without the flip of the top
 // bit the unsigned form needs before a signed saturating subtract (one VALU instruction per score pair in VALU-bound loops).
 __device__ __forceinline__ bool attn_drop_keep16(uint32_t rk16, uint32_t ck16, uint32_t thresh) {
   const int t = (int)(short)(((rk16 ^ ck16) * ATTN_DROP_MUL) & 0xFFFFu);
-  return t >= (int)(thresh << 8) - 32768;
+  return t >= (int)thresh - 32768;
 }
 // packed form: a2 ^ b2 holds (rowkey ^ colkey) of two scores in its 16-bit halves; returns per half a signed 16-bit
 // value that is NEGATIVE iff the score is dropped: v_xor, v_pk_mul_lo_u16, v_pk_sub_i16 clamp - three instructions for two
@@ -76,8 +76,8 @@ __device__ __forceinline__ uint32_t attn_drop_pair_diff(uint32_t a2, uint32_t b2
   const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, thresh2s));
   return __builtin_bit_cast(uint32_t, d);
 }
-// thresh * 256 - 32768 as a 16-bit pattern, in both halves
-__device__ __forceinline__ uint32_t attn_drop_thresh2s(uint32_t thresh) { return (((thresh << 8) ^ 0x8000u) & 0xFFFFu) * 0x10001u; }
+// thresh - 32768 as a 16-bit pattern, in both halves
+__device__ __forceinline__ uint32_t attn_drop_thresh2s(uint32_t thresh) { return ((thresh ^ 0x8000u) & 0xFFFFu) * 0x10001u; }
 // 0xFFFF in every DROPPED half (v_pk_ashrrev_i16), for clearing halves of packed bf16 words
 __device__ __forceinline__ uint32_t attn_drop_pair_dropped(uint32_t a2, uint32_t b2, uint32_t thresh2s) {
   typedef short s16x2 __attribute__((ext_vector_type(2)));

@@ -216,10 +216,10 @@ int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, hipStrea
   p.drop_inv = 1.f;
   if (drop_p <= 0.f) return 0;
   T2S_CHECK_ARG(drop_p < 1.f, "%s: dropout probability %f outside [0, 1)", who, drop_p);
-  int th = (int)(drop_p * 256.f + 0.5f);
-  th = th < 1 ? 1 : (th > 255 ? 255 : th);
+  int th = (int)(drop_p * 65536.f + 0.5f);
+  th = th < 1 ? 1 : (th > 65535 ? 65535 : th);
   p.drop_thresh = (uint32_t)th;
-  p.drop_inv = 256.f / (256.f - (float)th);
+  p.drop_inv = 65536.f / (65536.f - (float)th);
   p.drop_seed_lo = (uint32_t)drop_seed;
   p.drop_seed_hi = (uint32_t)(drop_seed >> 32);
   return 0;
