@@ -33,15 +33,19 @@ struct AttnParams {
 
 // ---- attention-probability dropout.  keep(q, kpos) is a stateless function of (seed, sample, head, q, kpos) so that
 // the forward, dQ and dK/dV kernels regenerate the same mask in their different register layouts; kpos is the POSITION
-// in the compacted key list.  The function is built to cost ~3 VALU instructions per score in kernels that are VALU
-// bound:   t(q, kpos) = ((rowkey16(q) ^ colkey16(kpos)) * 0x9E37 mod 2^16) read as int16,   keep iff t >= thresh - 32768   (thresh = round(65536 p): p' = p to 1.5e-5)
-// where rowkey16 / colkey16 are 16 bits of full-quality 32-bit hashes of (seed, sample, head, q) and (seed, sample, head,
-// kpos).  Those hashes are per-lane constants on the stationary axis and are computed once per tile (32 threads, one
-// key pair each, staged in LDS) on the streamed axis, so the per-score work is xor + multiply + compare - and it is
+// in the compacted key list.  The function is built to cost ~2.5 VALU instructions per score in kernels that are VALU
+// bound:   t(q, kpos) = (rowkey16(q) * colkey16(kpos) mod 2^16) read as int16,   keep iff t >= thresh - 32768   (thresh = round(65536 p))
+// where rowkey16 / colkey16 are ODD 16-bit values cut from full-quality 32-bit hashes of (seed, sample, head, q) and (seed, sample,
+// head, kpos).  Those hashes are per-lane constants on the stationary axis and are computed once per tile (32 threads, one
+// key pair each, staged in LDS) on the streamed axis, so the per-score work is multiply + compare - and it is
 // done on TWO scores per instruction with packed 16-bit math: a bf16x2 word of P holds two consecutive keys of the
 // lane's query (forward, dQ) or two consecutive queries of the lane's key (dK/dV), exactly the two 16-bit halves.
-// For a fixed row the values t are independent over keys and vice versa (colkey16 / rowkey16 are independent uniform
-// 16-bit values and x -> x * odd is a bijection); two rows share a mask only if their 16-bit keys collide (2^-16).
+// Multiplication by an odd number is a bijection of the odd residues mod 2^16, so for a fixed row the values t are
+// independent and uniform over keys (colkey16 independent uniform odd values) and vice versa.  NOT the reference's i.i.d.
+// Philox draw: two rows are related by t2 = (rk2 / rk1) t1, a multiplicative scramble; rows share a mask only if their keys
+// collide (2^-15 per pair) and are visibly correlated only for a handful of special key ratios (1, -1, small odd numbers and
+// their inverses).  (The first form of this function, (rowkey ^ colkey) * 0x9E37, cost one instruction more per pair and left
+// 0.8 % of the row pairs correlated beyond 6.5 sigma: tests/test_dropout_gpu.py measures both properties.)
 __device__ __forceinline__ uint32_t attn_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
@@ -50,29 +54,27 @@ __device__ __forceinline__ uint32_t attn_drop_salt(uint32_t seed_lo, uint32_t se
   return attn_hash32(seed_lo ^ attn_hash32(seed_hi ^ (bh * 0x9E3779B1u)));
 }
 #ifdef T2S_ABL_NOHASH   // timing-only ablation (tools/ablate): key generation without its cost; never defined in a product build
-__device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q) { return (salt + (uint32_t)q) & 0xFFFFu; }
-__device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) { return (salt ^ (uint32_t)kpos) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q) { return ((salt + (uint32_t)q) & 0xFFFFu) | 1u; }
+__device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) { return ((salt ^ (uint32_t)kpos) & 0xFFFFu) | 1u; }
 #else
-__device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q) { return attn_hash32(salt + (uint32_t)q * 0x85EBCA6Bu) >> 16; }
+__device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q) { return (attn_hash32(salt + (uint32_t)q * 0x85EBCA6Bu) >> 16) | 1u; }
 __device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) {
-  return attn_hash32((salt ^ 0xC2B2AE35u) + (uint32_t)kpos * 0x27D4EB2Fu) >> 16;
+  return (attn_hash32((salt ^ 0xC2B2AE35u) + (uint32_t)kpos * 0x27D4EB2Fu) >> 16) | 1u;
 }
 #endif
-constexpr uint32_t ATTN_DROP_MUL = 0x9E37u;
 // generic per-element form (fp32 kernels, mask export).  The 16-bit product is read as a SIGNED number and compared with
 // thresh - 32768: the same drop probability thresh / 65536 as an unsigned 16-bit compare, without the flip of the top
 // bit the unsigned form needs before a signed saturating subtract (one VALU instruction per score pair in VALU-bound loops).
 __device__ __forceinline__ bool attn_drop_keep16(uint32_t rk16, uint32_t ck16, uint32_t thresh) {
-  const int t = (int)(short)(((rk16 ^ ck16) * ATTN_DROP_MUL) & 0xFFFFu);
+  const int t = (int)(short)((rk16 * ck16) & 0xFFFFu);
   return t >= (int)thresh - 32768;
 }
-// packed form: a2 ^ b2 holds (rowkey ^ colkey) of two scores in its 16-bit halves; returns per half a signed 16-bit
-// value that is NEGATIVE iff the score is dropped: v_xor, v_pk_mul_lo_u16, v_pk_sub_i16 clamp - three instructions for two
-// scores.
+// packed form: a2 / b2 hold the row and column keys of two scores in their 16-bit halves; returns per half a signed 16-bit
+// value that is NEGATIVE iff the score is dropped: v_pk_mul_lo_u16, v_pk_sub_i16 clamp - two instructions for two scores.
 __device__ __forceinline__ uint32_t attn_drop_pair_diff(uint32_t a2, uint32_t b2, uint32_t thresh2s /* attn_drop_thresh2s(thresh) */) {
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const u16x2 t = __builtin_bit_cast(u16x2, a2 ^ b2) * u16x2{(unsigned short)ATTN_DROP_MUL, (unsigned short)ATTN_DROP_MUL};
+  const u16x2 t = __builtin_bit_cast(u16x2, a2) * __builtin_bit_cast(u16x2, b2);
   const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, thresh2s));
   return __builtin_bit_cast(uint32_t, d);
 }
