@@ -237,6 +237,16 @@ int t2s_infonce_bwd(const float* q, const float* p, const float* n, const float*
  * reference raises RuntimeError - turns that token's row into NaN; the host wrapper rejects such input beforehand. */
 int t2s_phoc(const uint8_t* tokens, int64_t n_tokens, int width, float* out, int64_t out_row_stride, t2s_stream_t stream);
 
+/* ---- FastText OCR-token vectors (context_feature_0) from a table resident in HBM.  Replaces the host lookup of
+ * FastTextProcessor._map_strings_to_indices pythia/datasets/processors.py:478-491 -> WordToVectorDict pythia/utils/vocab.py:375-381
+ * -> third-party fasttext FastText::getWordVector.  table: [table_rows, dim] fp32 = the model's input matrix (nwords + bucket
+ * rows); CSR batch: offsets [slots + 1] int32 into ids / word_end; ids [nnz] int32 subword rows of the slot's words in order
+ * (-1 = a word with no row); word_end [nnz] uint8 = 1 on the last entry of each word.  out [slots, dim] fp32:
+ * mean over words of ((sum of the word's rows) * float(1 / #rows)), in fastText's order of fp32 operations; an empty slot is 0. */
+int t2s_fasttext_rows(const float* table, int64_t table_rows, int dim, const int32_t* ids,
+                      const uint8_t* word_end, const int32_t* offsets, int64_t slots, float* out,
+                      t2s_stream_t stream);
+
 /* ---- global-norm clip + Adam, multi-tensor (BaseTrainer._backward pythia/trainers/base_trainer.py:262-272: clip_gradients
  * pythia/utils/general.py:32-41 = torch.nn.utils.clip_grad_norm_(params, max_norm), then torch.optim.Adam.step(),
  * build_utils.py:54-83; weight_decay 0, no amsgrad).  desc: device table [n_tensors, 5] int64 rows (param, grad, exp_avg,

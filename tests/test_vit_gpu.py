@@ -1,0 +1,73 @@
+"""The ViT frame-feature producer (vitxt_gqa_amd/vit.py; reference: tools/video_feat/obtain_vit_feat.py:37-53) against the model
+the reference script runs - Hugging Face ``ViTModel`` - with the same (random) weights: a tiny configuration and a ViT-L-shaped
+one (1024 = 16 x 64, 224 x 224 input, 197 tokens; 2 layers), fp32 and bf16 operands; the image preprocessing against
+``ViTImageProcessor``; the per-frame ``[1, hidden]`` .npy files the dataset reader expects (dataset.py:267-282)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.mark.parametrize("hidden,heads,layers,ffn,img", [(128, 2, 2, 256, 32), (1024, 16, 2, 4096, 224)])
+def test_cls_features_match_hf_vit(hidden, heads, layers, ffn, img):
+    _need_gpu()
+    from transformers import ViTConfig, ViTModel
+    from vitxt_gqa_amd.vit import ViTFeatureExtractor
+    torch.manual_seed(0)
+    cfg = ViTConfig(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ffn, image_size=img,
+                    patch_size=16, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ref = ViTModel(cfg).eval()
+    with torch.no_grad():                      # spread the weights a little: the default init gives near-uniform attention
+        for n, p in ref.named_parameters():
+            if p.dim() > 1:
+                p.mul_(3.0)
+    x = torch.randn(3, 3, img, img)
+    with torch.no_grad():
+        want = ref(pixel_values=x).last_hidden_state[:, 0, :]
+    kw = dict(hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ffn, image_size=img, patch_size=16,
+              layer_norm_eps=cfg.layer_norm_eps)
+    got32 = ViTFeatureExtractor(ref.state_dict(), dtype=torch.float32, **kw)(x).cpu()
+    assert got32.shape == want.shape
+    assert (got32 - want).abs().max().item() < 2e-3, (got32 - want).abs().max().item()
+    got16 = ViTFeatureExtractor(ref.state_dict(), dtype=torch.bfloat16, **kw)(x).cpu()
+    assert (got16 - want).abs().max().item() < 6e-2, (got16 - want).abs().max().item()
+
+
+def test_preprocess_and_npy_files(tmp_path):
+    _need_gpu()
+    from PIL import Image
+    from transformers import ViTConfig, ViTImageProcessor, ViTModel
+    from vitxt_gqa_amd.vit import ViTFeatureExtractor, extract_video_features, preprocess
+    rng = np.random.default_rng(0)
+    frames = tmp_path / "frames" / "7"
+    os.makedirs(frames)
+    imgs = []
+    for i in range(5):
+        a = rng.integers(0, 256, size=(90 + 7 * i, 160, 3), dtype=np.uint8)
+        Image.fromarray(a).save(str(frames / ("%06d.png" % i)))
+        imgs.append(Image.open(str(frames / ("%06d.png" % i))))
+    proc = ViTImageProcessor(size={"height": 32, "width": 32}, image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5], resample=2)   # vit-large-patch16-224-in21k defaults at 32 px
+    want = proc(images=imgs, return_tensors="pt")["pixel_values"]
+    got = preprocess(imgs, size=32)
+    assert (got - want).abs().max().item() < 1e-6
+    cfg = ViTConfig(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, image_size=32, patch_size=16)
+    torch.manual_seed(1)
+    ref = ViTModel(cfg).eval()
+    model = ViTFeatureExtractor(ref.state_dict(), hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256,
+                                image_size=32, patch_size=16, layer_norm_eps=cfg.layer_norm_eps, dtype=torch.float32)
+    out_dir = tmp_path / "feat" / "7"
+    assert extract_video_features(model, str(frames), str(out_dir), batch=2, size=32) == 5
+    with torch.no_grad():
+        cls = ref(pixel_values=want).last_hidden_state[:, 0, :].numpy()
+    for i in range(5):
+        f = np.load(str(out_dir / ("%06d.npy" % i)))
+        assert f.shape == (1, 128) and f.dtype == np.float32 and np.abs(f[0] - cls[i]).max() < 2e-3
+    assert extract_video_features(model, str(frames), str(out_dir), batch=2, size=32) == 0         # existing features are kept

@@ -42,6 +42,7 @@ _SIGS = {
     "t2s_bce_masked": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),
     "t2s_infonce_stats": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p]),
     "t2s_infonce_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_void_p]),
+    "t2s_fasttext_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "t2s_optim_chunk_elems": (c_int, []),
     "t2s_grad_sqnorm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "t2s_clip_coef": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
