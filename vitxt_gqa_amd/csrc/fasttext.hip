@@ -17,6 +17,7 @@ constexpr int FT_MAX_CHUNKS = 4;       // float4 chunks per lane: dims up to 102
 __global__ __launch_bounds__(256) void fasttext_rows_kernel(const float* __restrict__ table, int64_t table_rows, int dim, const int32_t* __restrict__ ids,
                                                             const uint8_t* __restrict__ word_end, const int32_t* __restrict__ off, int64_t slots,
                                                             float* __restrict__ out) {
+#pragma clang fp contract(off)          // multiply and add round separately, as the library's Vector::mul / numpy's sum do (no FMA)
   const int lane = threadIdx.x & 63;
   const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (slot >= slots) return;

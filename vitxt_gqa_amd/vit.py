@@ -48,6 +48,22 @@ def attention_dense(qkv, n_heads):
     return out
 
 
+_RENAMES = (("layers.", "encoder.layer."), (".attention.q_proj.", ".attention.attention.query."), (".attention.k_proj.", ".attention.attention.key."),
+            (".attention.v_proj.", ".attention.attention.value."), (".attention.o_proj.", ".attention.output.dense."),
+            (".mlp.fc1.", ".intermediate.dense."), (".mlp.fc2.", ".output.dense."))
+
+
+def _classic_key(k):
+    """Checkpoint key spellings: the published vit-large-patch16-224-in21k files use ``encoder.layer.N.attention.attention.query`` ...;
+    recent ``transformers`` releases save ``layers.N.attention.q_proj`` / ``mlp.fc1`` ...; an optional ``vit.`` prefix.  -> the former."""
+    if k.startswith("vit."):
+        k = k[4:]
+    if k.startswith("layers."):
+        for a, b in _RENAMES:
+            k = k.replace(a, b, 1) if a != "layers." else (b + k[len(a):] if k.startswith(a) else k)
+    return k
+
+
 class ViTFeatureExtractor:
     def __init__(self, state_dict, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
                  image_size=224, patch_size=16, layer_norm_eps=1e-12, device="cuda:0", dtype=torch.bfloat16):
@@ -55,7 +71,7 @@ class ViTFeatureExtractor:
             raise ValueError("the attention kernels are built for head_dim 64 (ViT-L: 16 x 64)")
         self.h, self.nl, self.nh, self.ffn = hidden_size, num_hidden_layers, num_attention_heads, intermediate_size
         self.img, self.patch, self.eps, self.dt, self.dev = image_size, patch_size, layer_norm_eps, dtype, torch.device(device)
-        sd = {(k[4:] if k.startswith("vit.") else k): v for k, v in state_dict.items()}
+        sd = {_classic_key(k): v for k, v in state_dict.items()}
         g = lambda k: sd[k].detach().to(self.dev, torch.float32)
         dt = dtype
         self.cls = g("embeddings.cls_token")
