@@ -99,7 +99,7 @@ int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, const void* o
                       int64_t o_row_stride, int64_t o_batch_stride,
                       float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 /* The same gradients from ONE key-stationary kernel that runs the algorithm's five matrix products per (query, key) pair
- * (S and dP are computed once; the two-kernel form above recomputes them: seven): bf16, no attention dropout.  dQ is summed
+ * (S and dP are computed once; the two-kernel form above recomputes them: seven): bf16; attention dropout as above (same mask).  dQ is summed
  * across the 384-key blocks of a (sample, head) with fp32 atomics into dq32 [B, Lq, H*64] (workspace, contents on entry
  * irrelevant: zeroed here) and then rounded once into dq; the float sum makes dq depend on arrival order in its last bits
  * (dk / dv stay deterministic).  row_valid as for t2s_attn_bwd_fill, or NULL (then the caller zero-fills dk / dv). */
@@ -110,7 +110,7 @@ int t2s_attn_bwd_fused(const void* q, const void* k, const void* v, const void* 
                        int64_t q_row_stride, int64_t q_batch_stride,
                        int64_t kv_row_stride, int64_t kv_batch_stride,
                        int64_t o_row_stride, int64_t o_batch_stride,
-                       float scale, int dtype, t2s_stream_t stream);
+                       float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 
 /* ---- residual + LayerNorm (BertSelfOutput / BertOutput / BertLayerNorm; also
  * t2s.py:87-88,116-117,685-687): z = x + res (res may be NULL); y = (z-mean)/sqrt(var+eps)*g+b,

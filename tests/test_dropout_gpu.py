@@ -184,6 +184,30 @@ def test_attention_dropout_fwd_bwd(L1, n_dec, dtype, tol):
     (gref,) = torch.autograd.grad(ref, xr, dout.double())
     sc = gref.abs().max().item()
     assert (dqkv.double() - gref).abs().max().item() < tol * max(1.0, sc) * (1 if dtype == torch.float32 else 2)
+    if dtype == torch.bfloat16:          # the fused five-product backward regenerates the same mask (key on the lane, 96 keys per wave)
+        fused = ops.attn_bwd(qkv, out, dout, lse, keys, drop_p=p, drop_seed=seed, fused=True)
+        assert (fused.double() - gref).abs().max().item() < tol * max(1.0, sc) * 2
+
+
+def test_attention_dropout_fused_backward_at_length():
+    """Fused backward with dropout at a length where every code path runs (full 384-key blocks through the software pipeline, an
+    edge block with decoder keys): against the two-kernel form with the same seed."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, L1, n_dec, p, seed = 2, 1300, 12, 0.1, 77
+    L = L1 + n_dec
+    qkv = (torch.randn(B, L, 2304, generator=g) * 1.2).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    valid = (torch.rand(B, L1, generator=g) < 0.8).to(DEV)
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
+    out, lse = ops.attn_fwd(qkv, keys, drop_p=p, drop_seed=seed)
+    two = ops.attn_bwd(qkv, out, dout, lse, keys, drop_p=p, drop_seed=seed, fused=False)
+    fus = ops.attn_bwd(qkv, out, dout, lse, keys, drop_p=p, drop_seed=seed, fused=True)
+    sc = two.float().abs().max().item()
+    assert (fus.float() - two.float()).abs().max().item() < 3e-2 * max(1.0, sc)
+    other = ops.attn_bwd(qkv, out, dout, lse, keys, drop_p=p, drop_seed=seed + 1, fused=True)        # another seed: another mask
+    assert (other.float() - two.float()).abs().max().item() > 0.1 * sc
 
 
 def test_model_trains_with_dropout():

@@ -374,8 +374,9 @@ def test_c_abi_from_two_threads():
     assert "gelu" in msgs[1] and "gelu" not in msgs[0], msgs
 
 
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
 @pytest.mark.parametrize("B,L1,n_dec,keep", CASES + [(2, 1000, 12, 0.7), (2, 900, 0, 1.0), (1, 1500, 12, 0.3)])
-def test_attention_bwd_fused_five_products(B, L1, n_dec, keep):
+def test_attention_bwd_fused_five_products(B, L1, n_dec, keep, drop_p):
     """t2s_attn_bwd_fused (one key-stationary kernel, S and dP computed once, dQ summed across 384-key blocks with fp32 atomics)
     against the fp64 gradient and against the two-kernel form; dK / dV of rows outside the key list exactly zero, with and
     without the in-call zero fill."""
@@ -388,16 +389,21 @@ def test_attention_bwd_fused_five_products(B, L1, n_dec, keep):
     valid[:, 0] = True
     dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
     keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
-    out, lse = ops.attn_fwd(x, keys)
-    xr = x.double().requires_grad_(True)
-    ref = ref_attention(xr, dense_mask(valid, n_dec, L), 0.125)
-    (gref,) = torch.autograd.grad(ref, xr, dout.double())
-    scale = gref.abs().max().item()
-    two = ops.attn_bwd(x, out, dout, lse, keys, fused=False)
+    kw = dict(drop_p=drop_p, drop_seed=4242) if drop_p else {}
+    out, lse = ops.attn_fwd(x, keys, **kw)
+    two = ops.attn_bwd(x, out, dout, lse, keys, fused=False, **kw)
+    scale = two.float().abs().max().item()
+    gref = None
+    if not drop_p:                                     # without dropout: the fp64 gradient (with it: the two-kernel form, which
+        xr = x.double().requires_grad_(True)           # tests/test_dropout_gpu.py checks against a dense restatement with the same mask)
+        ref = ref_attention(xr, dense_mask(valid, n_dec, L), 0.125)
+        (gref,) = torch.autograd.grad(ref, xr, dout.double())
+        scale = gref.abs().max().item()
     for kl in (keys, ops.KeyList(keys.idx, keys.cnt, keys.n_dec, keys.dec_q0, None, None)):       # in-call fill / caller's zero fill
-        got = ops.attn_bwd(x, out, dout, lse, kl, fused=True)
-        gerr = (got.double() - gref).abs().max().item()
-        assert gerr < 3e-2 * max(1.0, scale) * 2, "fused bwd max err %.3e (scale %.3e)" % (gerr, scale)
+        got = ops.attn_bwd(x, out, dout, lse, kl, fused=True, **kw)
+        if gref is not None:
+            gerr = (got.double() - gref).abs().max().item()
+            assert gerr < 3e-2 * max(1.0, scale) * 2, "fused bwd max err %.3e (scale %.3e)" % (gerr, scale)
         assert (got.double() - two.double()).abs().max().item() < 3e-2 * max(1.0, scale)
         kvalid = torch.cat([valid, torch.ones(B, n_dec, dtype=torch.bool, device=DEV)], 1)
         if (~kvalid).any():

@@ -38,7 +38,7 @@ def main():
     ev[1].record()
     torch.cuda.synchronize()
     # backward: the two-kernel (7-product) and the fused (5-product, no dropout) forms, interleaved rounds in ONE process
-    forms = [("two-kernel", False)] + ([("fused", True)] if dp == 0 else [])
+    forms = [("two-kernel", False), ("fused", True)]
     tb_all = {n: [] for n, _ in forms}
     for n, f in forms:
         ops.attn_bwd(qkv, out, dout, lse, keys, fused=f, **kw)

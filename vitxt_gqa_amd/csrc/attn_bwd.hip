@@ -537,8 +537,8 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   const int64_t rows = (int64_t)B * Lq;
   dim3 gd((unsigned)((rows + 3) / 4)), blk(256);
   dim3 gkv((max_keys + 127) / 128, H, B), gq((Lq + 127) / 128, H, B);
-  if (dq32) {      // fused 5-product form (attn_bwd_fused_bf16.hip): bf16, no attention dropout
-    T2S_CHECK_ARG(dtype == T2S_BF16 && p.drop_thresh == 0, "attn_bwd_fused: bf16 without attention dropout only");
+  if (dq32) {      // fused 5-product form (attn_bwd_fused_bf16.hip): bf16
+    T2S_CHECK_ARG(dtype == T2S_BF16, "attn_bwd_fused: bf16 only");
     T2S_CHECK_ARG(Lq * (int64_t)H * 64 < ((int64_t)1 << 31), "attn_bwd_fused: a sample's fp32 dQ rows must span < 2^31 elements");
     if (int e = launch_attn_bwd_fused_bf16(p, max_keys, dq32, st)) return e;
   } else if (dtype == T2S_BF16) {
@@ -594,11 +594,12 @@ extern "C" int t2s_attn_bwd_fused(const void* q, const void* k, const void* v, c
                                   float* delta, void* dq, void* dk, void* dv, float* dq32, const int32_t* kv_idx, const int32_t* kv_cnt,
                                   const uint8_t* row_valid, int B, int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys,
                                   int64_t q_row_stride, int64_t q_batch_stride, int64_t kv_row_stride, int64_t kv_batch_stride,
-                                  int64_t o_row_stride, int64_t o_batch_stride, float scale, int dtype, t2s_stream_t stream) {
+                                  int64_t o_row_stride, int64_t o_batch_stride, float scale, int dtype, float drop_p, uint64_t drop_seed,
+                                  t2s_stream_t stream) {
   T2S_CHECK_ARG(dq32, "attn_bwd_fused: the fp32 dQ accumulation buffer is required");
   T2S_CHECK_ARG(dtype == T2S_BF16, "attn_bwd_fused: bf16 only");
   T2S_CHECK_ARG(!row_valid || (kv_idx && Lq == idx_cap), "attn_bwd_fused: row_valid needs the key list and the self-attention layout");
   return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
-                       q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, 0.f, 0,
+                       q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed,
                        row_valid, dq32, stream);
 }

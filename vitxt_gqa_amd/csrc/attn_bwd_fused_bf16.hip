@@ -30,7 +30,7 @@ constexpr int FB_WKEYS = 32 * FB_KB;              // 96 keys per wave
 constexpr int FB_KEYS = 4 * FB_WKEYS;             // 384 keys per workgroup
 constexpr int FB_QROWS = 64;
 constexpr int FB_TILE = FB_QROWS * 128;           // bytes of a 64-row bf16 tile
-constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4;   // Q | dO | -lse*log2e | -delta
+constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + (FB_QROWS / 2) * 4;   // Q | dO | -lse*log2e | -delta | dropout row keys (pairs)
 constexpr int FB_KIMG = FB_KEYS * 128;
 constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
 
@@ -82,6 +82,7 @@ __device__ __forceinline__ void fb_mfma_dvdk(f32x16& dv0, f32x16& dv1, f32x16& d
 #define FB_MFMA_V(acc, a, b) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(FB_U4(a)), "v"(FB_U4(b)))
 #define FB_MFMA_VA0(acc, a, ba, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(FB_U4(a)), "a"(ba), "v"(c))
 #define FB_MFMA_VA(acc, a, ba) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(FB_U4(a)), "a"(ba))
+#define FB_MFMA_VAZ(acc, a, ba) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(FB_U4(a)), "a"(ba))
 #define FB_MFMA_A(acc, a, b) asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(FB_U4(a)), "v"(b))
 #define FB_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -101,11 +102,12 @@ __device__ __forceinline__ uint32_t fb_pack2(float a, float b) {
 }
 
 // m-th MFMA (m = 0..7) of G1(block I): S and dP chains of key block I % 3, alternating; each chain starts from the row constants
-template <int I, int M>
+template <int I, int M, bool DROP>
 __device__ __forceinline__ void fb_g1(f32x16 (&sacc)[2], f32x16 (&dpacc)[2], const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], const bf16x8 (&kf)[4],
                                       const u32x4 (&vf)[FB_KB][4]) {
   constexpr int s = M / 2, kb = I % 3, par = I & 1;
   if constexpr (M % 2 == 0) FB_MFMA_V(sacc[par], qf[s], kf[s]);
+  else if constexpr (DROP && s == 0) FB_MFMA_VAZ(dpacc[par], dof[0], vf[kb][0]);      // dropout: dP from zero, delta subtracted behind the mask
   else FB_MFMA_VA(dpacc[par], dof[s], vf[kb][s]);
 }
 // m-th MFMA of G2(block I): m = 0..3 dV^T (needs P), m = 4..7 dK^T (needs dS)
@@ -124,30 +126,42 @@ __device__ __forceinline__ void fb_g2(f32x16 (&dvacc)[FB_KB][2], f32x16 (&dkacc)
 // chunk m (registers 2m, 2m+1) of the softmax of block I: P = exp2(S'), packed bf16 operand word.  EDGE: the validity /
 // decoder rule - this lane's key is visible to the tile rows >= thr (thr = first visible row - row of register 0 of this lane;
 // register r is row (r & 3) + 8 (r >> 2) above it), so one compare + select per score
-template <int I, int M, bool EDGE>
-__device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], const int thr) {
+template <int I, int M, bool EDGE, bool DROP>
+__device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], const int thr, uint32_t (&mw)[8], const uint32_t rkw, const uint32_t ck2,
+                                      const uint32_t th2) {
   constexpr int par = I & 1, r0 = 2 * M, r1 = 2 * M + 1;
   float p0 = fast_exp2(sacc[par][r0]), p1 = fast_exp2(sacc[par][r1]);
   if (EDGE) {
     p0 = ((r0 & 3) + 8 * (r0 >> 2)) >= thr ? p0 : 0.f;
     p1 = ((r1 & 3) + 8 * (r1 >> 2)) >= thr ? p1 : 0.f;
   }
-  sacc[par][r0] = p0;
+  sacc[par][r0] = p0;                                  // dS uses the UNdropped probability
   sacc[par][r1] = p1;
-  pfw[M] = fb_pack2(p0, p1);
+  if (DROP) {                                          // registers (2m, 2m+1) are two consecutive queries of this lane's key: one packed mask word
+    mw[M] = attn_drop_pair_dropped(rkw, ck2, th2);     // 0xFFFF in every dropped half
+    pfw[M] = attn_drop_apply(fb_pack2(p0, p1), mw[M]); // dV uses the dropped one (scaled by 1/(1-p) at the end)
+  } else {
+    pfw[M] = fb_pack2(p0, p1);
+  }
 }
-// chunk m of dS = P * dP' of block I
-template <int I, int M>
-__device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dpacc)[2], uint32_t (&dsw)[8]) {
+// chunk m of dS of block I: P * dP' (dP' = dP - delta from the seeded chain), or with dropout P * (dP * M / (1-p) - delta)
+template <int I, int M, bool DROP>
+__device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dpacc)[2], uint32_t (&dsw)[8], const uint32_t (&mw)[8], const float nd0,
+                                      const float nd1, const float inv) {
   constexpr int par = I & 1;
-  dsw[M] = fb_pack2(sacc[par][2 * M] * dpacc[par][2 * M], sacc[par][2 * M + 1] * dpacc[par][2 * M + 1]);
+  if (DROP) {
+    const float d0 = attn_drop_zero(dpacc[par][2 * M], attn_drop_lo32(mw[M])), d1 = attn_drop_zero(dpacc[par][2 * M + 1], attn_drop_hi32(mw[M]));
+    dsw[M] = fb_pack2(sacc[par][2 * M] * __builtin_fmaf(d0, inv, nd0), sacc[par][2 * M + 1] * __builtin_fmaf(d1, inv, nd1));
+  } else {
+    dsw[M] = fb_pack2(sacc[par][2 * M] * dpacc[par][2 * M], sacc[par][2 * M + 1] * dpacc[par][2 * M + 1]);
+  }
 }
 
 // MODE 0: workgroups whose 384 keys are all valid prefix keys run the software-pipelined sweep, the others exit; MODE 1: the
 // complement (the same pipeline with the validity / decoder rule applied to P; waves without a valid key skip phase A); MODE 2:
 // the tail launch (plain sweep, loops over the key blocks beyond the static bound).  Separate kernels, so that each is
 // register-allocated for one sweep.
-template <bool USE_IDX, int MODE>
+template <bool USE_IDX, int MODE, bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams p, float* __restrict__ dq32) {
   constexpr bool TAIL = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -245,6 +259,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     uint32_t qo0 = (uint32_t)(sr * p.q_rs * 2) + (uint32_t)sc * 16u, oo0 = (uint32_t)(sr * p.o_rs * 2) + (uint32_t)sc * 16u;
     uint32_t qo1 = qo0 + (uint32_t)(32 * p.q_rs * 2), oo1 = oo0 + (uint32_t)(32 * p.o_rs * 2);
     int ld_row = tid & 63;
+    int ld_row0 = 0;              // first query row of the tile being loaded (uniform)
+    // attention-probability dropout (attn_common.h): this lane's column key of each key block in both 16-bit halves; the row keys of
+    // the tile's 32 query pairs are hashed by threads 0..31 while the tile is staged (dkdv kernel's scheme: the same mask function)
+    const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
+    uint32_t ck2[FB_KB];
+#pragma unroll
+    for (int kb = 0; kb < FB_KB; ++kb) ck2[kb] = DROP ? attn_drop_colkey16(salt, kp0 + wave * FB_WKEYS + kb * 32 + lr) * 0x10001u : 0u;
+    const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
+    const float drop_inv = p.drop_inv;
+    uint32_t rkreg = 0;
 #define FB_STAGE_LOAD()                                                                         \
   {                                                                                             \
     const uint32_t a0_ = qo0 < q_max ? qo0 : q_max, b0_ = oo0 < o_max ? oo0 : o_max;            \
@@ -257,8 +281,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     const float l_ = LSE[r2c_] * LOG2E, dl_ = DELTA[r2c_];                                      \
     lreg = ld_row < p.Lq ? -l_ : -INFINITY;                                                     \
     dreg = ld_row < p.Lq ? -dl_ : 0.f;                                                          \
+    if (DROP && tid < FB_QROWS / 2) {                                                           \
+      const int qa_ = ld_row0 + 2 * tid, qb2_ = qa_ + 1;                                        \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1) << 16); \
+    }                                                                                           \
     qo0 += q_step; oo0 += o_step; qo1 += q_step; oo1 += o_step;                                 \
-    ld_row += FB_QROWS;                                                                         \
+    ld_row += FB_QROWS; ld_row0 += FB_QROWS;                                                    \
   }
 #define FB_STAGE_WRITE(buf_)                                                                    \
   {                                                                                             \
@@ -271,6 +299,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       reinterpret_cast<float*>(base_ + 2 * FB_TILE)[tid] = lreg;                                \
       reinterpret_cast<float*>(base_ + 2 * FB_TILE + FB_QROWS * 4)[tid] = dreg;                 \
     }                                                                                           \
+    if (DROP && tid < FB_QROWS / 2) reinterpret_cast<uint32_t*>(base_ + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
   }
     FB_STAGE_LOAD();
     FB_STAGE_WRITE(0);
@@ -301,8 +330,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #define FB_LD_SEEDS(lse_, del_, i_)  /* accumulators of block i start from the row constants of this lane's rows (broadcast reads) */  \
   _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
     const f32x4 l4 = *reinterpret_cast<const f32x4*>((lse_) + ((i_) / 3) * 32 + 8 * g + 4 * lh);    \
-    const f32x4 d4 = *reinterpret_cast<const f32x4*>((del_) + ((i_) / 3) * 32 + 8 * g + 4 * lh);    \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) { sacc[(i_) & 1][4 * g + j] = l4[j]; dpacc[(i_) & 1][4 * g + j] = d4[j]; }  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) sacc[(i_) & 1][4 * g + j] = l4[j];                \
+    if (!DROP) {      /* dropout: the dP chain starts from zero, delta is subtracted behind the mask (FB_M) */  \
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>((del_) + ((i_) / 3) * 32 + 8 * g + 4 * lh); \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) dpacc[(i_) & 1][4 * g + j] = d4[j];             \
+    }                                                                                               \
   }
 #define FB_LD_KF(kb_)                                                                               \
   _Pragma("unroll") for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kw_ + ka[s] + (kb_) * 4096);
@@ -338,6 +370,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // (S3 is the 7th MFMA of a G1, E starts in the next slot; dP3 is the 8th, M starts a whole slot later): the wait states the
         // hardware does not interlock are covered by construction.  LDS loads of a slot's successor are issued at its head.
         bf16x8 qT[2][2], doT[2][2];
+        uint32_t mw[8], rkw[8];       // dropout: mask words of the block in its softmax, row-key words of the next one
+        f32x4 dl[4];                  // dropout: -delta of the rows of the block whose dS is formed
+        const uint32_t* rk_s = reinterpret_cast<const uint32_t*>(del_s + FB_QROWS);
+#define FB_LD_RK(i_)     /* row-key words of block i: registers (2m, 2m+1) = rows 8g + 4lh + {0,1} / {2,3}: word (sb*32 + 8g + 4lh)/2 + (m & 1) */ \
+  if (DROP) { _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                       \
+    const uint2 w2 = *reinterpret_cast<const uint2*>(rk_s + ((i_) / 3) * 16 + 4 * g + 2 * lh);      \
+    rkw[2 * g] = w2.x; rkw[2 * g + 1] = w2.y; } }
+#define FB_LD_DL(i_)                                                                                \
+  if (DROP) { _Pragma("unroll") for (int g = 0; g < 4; ++g) dl[g] = *reinterpret_cast<const f32x4*>(del_s + ((i_) / 3) * 32 + 8 * g + 4 * lh); }
         int thr[2] = {0, 0};          // EDGE: visibility threshold of the block whose softmax runs (by block parity)
         const int rowb = qt * FB_QROWS + 4 * lh;
 #define FB_THR(i_) if (EDGE) thr[(i_) & 1] = qmin[(i_) % 3] - rowb - ((i_) / 3) * 32;
@@ -354,18 +395,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     *reinterpret_cast<uint2*>(dsw_ + ((i_) % 3) * 4096 + (wrow + (((4 * ((i_) / 3) + 2 * s) << 4) ^ wxor))) = make_uint2(dsw[4 * s], dsw[4 * s + 1]);          \
     *reinterpret_cast<uint2*>(dsw_ + ((i_) % 3) * 4096 + (wrow + (((4 * ((i_) / 3) + 2 * s + 1) << 4) ^ wxor))) = make_uint2(dsw[4 * s + 2], dsw[4 * s + 3]);  \
   }
-#define FB_G1(i_, m_) fb_g1<i_, m_>(sacc, dpacc, qf, dof, kf, vf)
+#define FB_G1(i_, m_) fb_g1<i_, m_, DROP>(sacc, dpacc, qf, dof, kf, vf)
 #define FB_G2(i_, m_) fb_g2<i_, m_>(dvacc, dkacc, doT, qT, pfw, dsw)
-#define FB_E(i_, m_) fb_ve<i_, m_, EDGE>(sacc, pfw, thr[(i_) & 1])
-#define FB_M(i_, m_) fb_vm<i_, m_>(sacc, dpacc, dsw)
+#define FB_E(i_, m_) fb_ve<i_, m_, EDGE, DROP>(sacc, pfw, thr[(i_) & 1], mw, rkw[m_], ck2[(i_) % 3], th2)
+#define FB_M(i_, m_) fb_vm<i_, m_, DROP>(sacc, dpacc, dsw, mw, dl[(m_) >> 1][2 * ((m_) & 1)], dl[(m_) >> 1][2 * ((m_) & 1) + 1], drop_inv)
         // slot "G1(n) + E(e)": eight groups of one MFMA of G1(b_n) and one chunk of E(b_e)
 #define FB_SLOT_G1E(n_, e_)                                                                         \
-  FB_THR(e_);                                                                                       \
+  FB_THR(e_); FB_LD_RK(e_);                                                                         \
   FB_G1(n_, 0); FB_E(e_, 0); FB_FENCE(); FB_G1(n_, 1); FB_E(e_, 1); FB_FENCE(); FB_G1(n_, 2); FB_E(e_, 2); FB_FENCE();            \
   FB_G1(n_, 3); FB_E(e_, 3); FB_FENCE(); FB_G1(n_, 4); FB_E(e_, 4); FB_FENCE(); FB_G1(n_, 5); FB_E(e_, 5); FB_FENCE();            \
   FB_G1(n_, 6); FB_E(e_, 6); FB_FENCE(); FB_G1(n_, 7); FB_E(e_, 7); FB_FENCE();
         // slot "G2(i) + M(i)": dV^T MFMAs with two chunks of M each, then the dK^T MFMAs beside the dS^T stores
 #define FB_SLOT_G2M(i_)                                                                             \
+  FB_LD_DL(i_);                                                                                     \
   FB_G2(i_, 0); FB_M(i_, 0); FB_M(i_, 1); FB_FENCE(); FB_G2(i_, 1); FB_M(i_, 2); FB_M(i_, 3); FB_FENCE();                        \
   FB_G2(i_, 2); FB_M(i_, 4); FB_M(i_, 5); FB_FENCE(); FB_G2(i_, 3); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE();                        \
   FB_G2(i_, 4); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE();               \
@@ -393,11 +435,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // slot "G2(b4) + M(b4) + E(b5)": E(b5) only behind the dV^T MFMAs of b4, which still read the operand words of P(b4)
         FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_FENCE();
         FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_FENCE();
-        FB_THR(5);
+        FB_THR(5); FB_LD_RK(5);
         FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 0); FB_E(5, 1); FB_FENCE(); FB_G2(4, 5); FB_E(5, 2); FB_E(5, 3); FB_FENCE();
         FB_G2(4, 6); FB_E(5, 4); FB_E(5, 5); FB_FENCE(); FB_G2(4, 7); FB_E(5, 6); FB_E(5, 7); FB_FENCE();
         FB_SLOT_G2M(5);
 #undef FB_THR
+#undef FB_LD_RK
+#undef FB_LD_DL
 #undef FB_LD_QT
 #undef FB_ST_DS
 #undef FB_G1
@@ -451,11 +495,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
                 sacc[r] = ok ? sacc[r] : 0.f;
               }
             }
+            f32x16 pdrop = sacc;                             // P as dV sees it (dropped entries cleared)
+            if (DROP) {      // plain per-score form (this sweep only runs for key blocks beyond the static bound)
+              const uint32_t ck16 = ck2[kb] & 0xFFFFu;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dpacc[r] = sacc[r] * dpacc[r];
+              for (int r = 0; r < 16; ++r) {
+                int qg = qt * FB_QROWS + sb * 32 + acc_row(r, lh);
+                qg = qg < p.Lq ? qg : p.Lq - 1;
+                const bool keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg), ck16, p.drop_thresh);
+                // the chain was seeded with -delta: dP' = dP - delta;  dS = P (keep ? dP / (1-p) : 0) - P delta
+                const float nd = del_s[sb * 32 + acc_row(r, lh)];
+                dpacc[r] = sacc[r] * ((keep ? (dpacc[r] - nd) * drop_inv : 0.f) + nd);
+                pdrop[r] = keep ? sacc[r] : 0.f;
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dpacc[r] = sacc[r] * dpacc[r];
+            }
             bf16x8 pf[2], dsf[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { pf[s] = acc_to_frag(sacc, s); dsf[s] = acc_to_frag(dpacc, s); }
+            for (int s = 0; s < 2; ++s) { pf[s] = acc_to_frag(pdrop, s); dsf[s] = acc_to_frag(dpacc, s); }
             fb_mfma_dvdk(dvacc[kb][0], dvacc[kb][1], dkacc[kb][0], dkacc[kb][1], doT, qT, pf, dsf);
             // dS^T image: this lane's key row, queries sb*32 + 16s + {0..3, 8..11} + 4lh: two 8-byte stores per s
             char* dsrow = dsimg + 8 * lh;
@@ -584,8 +643,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             const int d = db * 32 + 8 * g + 4 * lh;
             bf16x4 k4 = {(bf16_t)(dkacc[kb][db][4 * g] * p.scale), (bf16_t)(dkacc[kb][db][4 * g + 1] * p.scale),
                          (bf16_t)(dkacc[kb][db][4 * g + 2] * p.scale), (bf16_t)(dkacc[kb][db][4 * g + 3] * p.scale)};
-            bf16x4 v4 = {(bf16_t)dvacc[kb][db][4 * g], (bf16_t)dvacc[kb][db][4 * g + 1], (bf16_t)dvacc[kb][db][4 * g + 2],
-                         (bf16_t)dvacc[kb][db][4 * g + 3]};
+            const float vs_ = DROP ? drop_inv : 1.f;
+            bf16x4 v4 = {(bf16_t)(dvacc[kb][db][4 * g] * vs_), (bf16_t)(dvacc[kb][db][4 * g + 1] * vs_), (bf16_t)(dvacc[kb][db][4 * g + 2] * vs_),
+                         (bf16_t)(dvacc[kb][db][4 * g + 3] * vs_)};
             *reinterpret_cast<bf16x4*>(dkp + d) = k4;
             *reinterpret_cast<bf16x4*>(dvp + d) = v4;
           }
@@ -648,14 +708,16 @@ __global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restri
 
 }  // namespace
 
-// Fused backward (bf16, no attention dropout): delta + housekeeping, the 5-product kernel (+ its tail launch, see
+// Fused backward (bf16): delta + housekeeping, the 5-product kernel (+ its tail launch, see
 // attn_dkdv_bf16.hip), the fp32 -> bf16 cast of dQ.
 int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, float* dq32, hipStream_t st) {
   AttnParams p = p_in;
   // > 64 KB of LDS per workgroup needs the opt-in; set on every call (idempotent, per device, no state of ours is kept)
-  const void* kernels[] = {reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 0>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 1>),
-                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 2>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 0>),
-                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 1>)};
+  const void* kernels[] = {reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 0, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 1, false>),
+                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 2, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 0, false>),
+                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 1, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 0, true>),
+                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 1, true>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 2, true>),
+                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 0, true>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 1, true>)};
   for (const void* k : kernels)
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
       t2s_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS per workgroup", FB_SMEM);
@@ -666,14 +728,18 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, float* dq32
                      dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.B, p.H, p.Lq, p.o_rs, p.o_bs, p.kv_rs, p.kv_bs);
   p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256), tail(attn_xcd_grid(1, p.H, p.B));
+#define FB_LAUNCH(IDX_, MODE_, grid_)                                                                                  \
+  if (p.drop_thresh) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, true>), grid_, block, FB_SMEM, st, p, dq32); \
+  else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, false>), grid_, block, FB_SMEM, st, p, dq32);
   if (p.kv_idx) {
-    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<true, 0>), grid, block, FB_SMEM, st, p, dq32);
-    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<true, 1>), grid, block, FB_SMEM, st, p, dq32);
-    if (p.kblocks * FB_KEYS < p.idx_cap) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<true, 2>), tail, block, FB_SMEM, st, p, dq32);
+    FB_LAUNCH(true, 0, grid);
+    FB_LAUNCH(true, 1, grid);
+    if (p.kblocks * FB_KEYS < p.idx_cap) { FB_LAUNCH(true, 2, tail); }
   } else {
-    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<false, 0>), grid, block, FB_SMEM, st, p, dq32);
-    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<false, 1>), grid, block, FB_SMEM, st, p, dq32);
+    FB_LAUNCH(false, 0, grid);
+    FB_LAUNCH(false, 1, grid);
   }
+#undef FB_LAUNCH
   const int width = p.H * 64;
   const int64_t total8 = rows * (width / 8);
   hipLaunchKernelGGL(attn_dq_cast_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, dq32, (bf16_t*)p.dq, (int64_t)p.Lq, width,

@@ -111,7 +111,7 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     # suit a handful of keys better than 384-key blocks at one wave per SIMD (tools/attn_probe.py: 0.88 vs 1.9 ms at 516 keys, B=8)
     if fused is None:
         fused = ATTN_BWD_FUSED and keys.cap_hint >= ATTN_BWD_FUSED_MIN_KEYS
-    use_fused = fused and qkv.dtype == torch.bfloat16 and drop_p == 0.0
+    use_fused = fused and qkv.dtype == torch.bfloat16
     global LAST_ATTN_BWD_PRODUCTS
     LAST_ATTN_BWD_PRODUCTS = 5 if use_fused else 7
     if use_fused:
@@ -119,7 +119,8 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
         dq32 = torch.empty(B * L * HID + 4096, dtype=torch.float32, device=qkv.device)
         global _LAST_DQ32
         _LAST_DQ32 = dq32
-        X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(dq32), *klist, X.ptr(keys.valid8) if fill_in_kernel else None, *dims, X.stream()),
+        X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(dq32), *klist, X.ptr(keys.valid8) if fill_in_kernel else None, *dims, float(drop_p), int(drop_seed),
+                                           X.stream()),
                 "t2s_attn_bwd_fused")
     elif fill_in_kernel:
         X.check(X.lib().t2s_attn_bwd_fill(*head, *klist, X.ptr(keys.valid8), *dims, float(drop_p), int(drop_seed), X.stream()), "t2s_attn_bwd_fill")
