@@ -13,7 +13,8 @@ out = os.path.join(ROOT, "tools", "ablate", "_build")
 os.makedirs(out, exist_ok=True)
 lib = os.path.join(out, "libt2s_stamp.so")
 from vitxt_gqa_amd import build as Bld  # noqa: E402
-subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-DFB_STAMP", "-o", lib] + Bld.sources())
+abl = os.environ.get("FB_ABL", "0")          # timing-only ablations: 1 = no dQ operand reads, 2 = no dQ MFMAs (results wrong)
+subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-DFB_STAMP", "-DFB_ABL=" + abl, "-o", lib] + Bld.sources())
 os.environ["T2S_HIP_LIB"] = lib
 import torch  # noqa: E402
 from vitxt_gqa_amd import ops  # noqa: E402

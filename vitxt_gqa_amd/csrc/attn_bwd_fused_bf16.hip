@@ -83,7 +83,8 @@ __device__ __forceinline__ void fb_mfma_dvdk(f32x16& dv0, f32x16& dv1, f32x16& d
 #define FB_MFMA_VA0(acc, a, ba, c) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(FB_U4(a)), "a"(ba), "v"(c))
 #define FB_MFMA_VA(acc, a, ba) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(FB_U4(a)), "a"(ba))
 #define FB_MFMA_VAZ(acc, a, ba) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(FB_U4(a)), "a"(ba))
-#define FB_MFMA_A(acc, a, b) asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(FB_U4(a)), "v"(b))
+// (no s_nop: the P / dS operand words are written by VALU code at least one MFMA group ahead of the MFMA that reads them)
+#define FB_MFMA_A(acc, a, b) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(FB_U4(a)), "v"(b))
 #define FB_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // transposed fragment from a row-block base and this lane's two precomputed offsets (rows r and r + 8 of the block)
@@ -533,6 +534,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       // ~3000-cycle round trip), the buffer was last read in phase A of the previous tile, and the barrier below publishes it,
       // so that phase B can already fetch the next tile's first operands.
       FB_TICK(0);                                            // phase A
+      // K^T fragments of the first two groups of the dQ product: they do not depend on this tile, so they are fetched ahead of
+      // the barrier (their registers were the transposed Q / dO fragments until a moment ago)
+      bf16x8 afA[4], bfA[4], afB[4], bfB[4];
+      if constexpr (PREF) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { bfA[u] = fb_tr(kimg + (16 * u) * 128, vad); bfB[u] = fb_tr(kimg + (16 * (4 + u)) * 128, vad); }
+      }
       FB_STAGE_WRITE(buf ^ 1);
       FB_TICK(1);                                            // stage write
       __syncthreads();                                       // the dS^T image of this query tile is complete
@@ -544,11 +552,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         for (int i = 0; i < 16; ++i) dqacc[i] = 0.f;
         // steps of 16 keys in groups of 4; full key blocks: 24 steps with the transposed reads of group g+1 in flight under the
         // MFMAs of group g, otherwise the steps that hold valid keys (rows past them may never have been written)
-#define FB_DQ_LOAD(af_, bf_, g_)                                                                    \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
-    af_[u] = fb_tr(dsimg + (16 * (4 * (g_) + u)) * 128, vaq);                                       \
-    bf_[u] = fb_tr(kimg + (16 * (4 * (g_) + u)) * 128, vad);                                        \
-  }
+#ifndef FB_ABL
+#define FB_ABL 0      // timing-only ablation switches of the diagnostic build (results are then wrong); 0 in every product build
+#endif
+#if FB_ABL & 1
+#define FB_DQ_LOAD_A(af_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(af_[u]));
+#define FB_DQ_LOAD_B(bf_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bf_[u]));
+#else
+#define FB_DQ_LOAD_A(af_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) af_[u] = fb_tr(dsimg + (16 * (4 * (g_) + u)) * 128, vaq);
+#define FB_DQ_LOAD_B(bf_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) bf_[u] = fb_tr(kimg + (16 * (4 * (g_) + u)) * 128, vad);
+#endif
+#define FB_DQ_LOAD(af_, bf_, g_) FB_DQ_LOAD_A(af_, g_) FB_DQ_LOAD_B(bf_, g_)
+#if FB_ABL & 2
+#define FB_DQ_MFMA(af_, bf_) _Pragma("unroll") for (int u = 0; u < 4; ++u) asm volatile("" :: "v"(af_[u]), "v"(bf_[u]));
+#else
 #define FB_DQ_MFMA(af_, bf_)                                                                        \
   asm("s_nop 1\n\t"                                                                                \
       "v_mfma_f32_32x32x16_bf16 %0, %1, %5, %0\n\t"                                                \
@@ -558,10 +575,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       : "+v"(dqacc)                                                                                 \
       : "v"(FB_U4(af_[0])), "v"(FB_U4(af_[1])), "v"(FB_U4(af_[2])), "v"(FB_U4(af_[3])), "v"(FB_U4(bf_[0])), "v"(FB_U4(bf_[1])),  \
         "v"(FB_U4(bf_[2])), "v"(FB_U4(bf_[3])));
+#endif
         if constexpr (PREF) {
-          bf16x8 afA[4], bfA[4], afB[4], bfB[4];
-          FB_DQ_LOAD(afA, bfA, 0);
-          FB_DQ_LOAD(afB, bfB, 1);
+          // 24 steps of 16 keys, eight steps of operands in flight: step k's MFMA is followed in the stream by the four transposed
+          // reads of step k + 8 (into the registers it just released), so the reads run under the MFMAs instead of between them
+          // (reads and MFMAs of this phase measured ADDITIVE in the grouped form: tools/fused_stamps.py, FB_ABL)
+          // afA/bfA hold steps k with (k & 7) < 4, afB/bfB those with (k & 7) >= 4; the K^T fragments of steps 0..7 were fetched
+          // ahead of the barrier
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (k < 4) afA[k] = fb_tr(dsimg + (16 * k) * 128, vaq);
+            else afB[k & 3] = fb_tr(dsimg + (16 * k) * 128, vaq);
+          }
           {   // the next tile's first operands (its stage buffer was published by the barrier above)
             const char* nq_ = stage + (buf ^ 1) * FB_STAGE;
             FB_LD_QF(nq_, nq_ + FB_TILE, 0);
@@ -569,12 +594,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             FB_LD_KF(0);
           }
           FB_FENCE();
-          FB_DQ_MFMA(afA, bfA); FB_DQ_LOAD(afA, bfA, 2); FB_FENCE();
-          FB_DQ_MFMA(afB, bfB); FB_DQ_LOAD(afB, bfB, 3); FB_FENCE();
-          FB_DQ_MFMA(afA, bfA); FB_DQ_LOAD(afA, bfA, 4); FB_FENCE();
-          FB_DQ_MFMA(afB, bfB); FB_DQ_LOAD(afB, bfB, 5); FB_FENCE();
-          FB_DQ_MFMA(afA, bfA); FB_FENCE();
-          FB_DQ_MFMA(afB, bfB);
+#pragma unroll
+          for (int k = 0; k < FB_KEYS / 16; ++k) {
+            const bool hiHalf = (k & 7) >= 4;
+            bf16x8& a_ = hiHalf ? afB[k & 3] : afA[k & 3];
+            bf16x8& b_ = hiHalf ? bfB[k & 3] : bfA[k & 3];
+#if !(FB_ABL & 2)
+            asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(a_)), "v"(FB_U4(b_)));
+#else
+            asm volatile("" :: "v"(a_), "v"(b_));
+#endif
+            if (k + 8 < FB_KEYS / 16) {
+#if !(FB_ABL & 1)
+              a_ = fb_tr(dsimg + (16 * (k + 8)) * 128, vaq);
+              b_ = fb_tr(kimg + (16 * (k + 8)) * 128, vad);
+#else
+              asm volatile("" : "+v"(a_), "+v"(b_));
+#endif
+            }
+            FB_FENCE();
+          }
         } else {
           const int nsteps = FULL ? (EDGE ? nks : FB_KEYS / 16) : nks;
           int k4 = 0;
@@ -589,6 +628,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
           }
         }
 #undef FB_DQ_LOAD
+#undef FB_DQ_LOAD_A
+#undef FB_DQ_LOAD_B
 #undef FB_DQ_MFMA
         asm volatile("s_nop 11" : "+v"(dqacc));              // MFMA result -> VALU read
         FB_TICK(3);                                          // phase B MFMAs
