@@ -159,7 +159,7 @@ __device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dp
 }
 
 // MODE 0: workgroups whose 384 keys are all valid prefix keys run the software-pipelined sweep, the others exit; MODE 1: the
-// complement (the same pipeline with the validity / decoder rule applied to P; waves without a valid key skip phase A); MODE 2:
+// complement (the same pipeline with the validity / decoder rule applied to P); MODE 2:
 // the tail launch (plain sweep, loops over the key blocks beyond the static bound).  Separate kernels, so that each is
 // register-allocated for one sweep.
 template <bool USE_IDX, int MODE, bool DROP>
@@ -360,7 +360,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       const float* del_s = lse_s + FB_QROWS;
       // ================= phase A: S, dP, dS, dV^T, dK^T per (query sub-block, key block) =================
       if constexpr (FULL) {
-        if (!EDGE || wave_u * FB_WKEYS < nkeys_wg) {        // EDGE: a wave whose 96 keys all lie past the list has nothing to add
+        {   // (EDGE: a wave whose 96 keys all lie past the list runs the phase as well - its P is forced to 0; a branch around the
+            // phase costs the edge kernel ~100 spilled registers, whose scratch reloads queue behind the atomics, for no gain: the
+            // workgroup waits for its busiest wave at the barrier anyway)
         // Software pipeline over the tile's six blocks b_i = (query sub-block i / 3, key block i % 3).  One wave per SIMD issues in
         // order, so an MFMA only overlaps VALU / LDS work that stands BETWEEN it and the next MFMA in the instruction stream.
         // Slots of 8 MFMAs each, fenced into one-MFMA groups:
