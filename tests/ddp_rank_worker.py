@@ -37,7 +37,8 @@ def main():
     s = to_device({k: v[idx] for k, v in fx.batch().items()}, dev)
     s.grounding_noise = (fx["E1"][idx], fx["E2"][idx])
     s.grounding_masks = {k: v[idx] for k, v in fx.masks().items()}
-    buckets = GradBuckets(model.named_parameters(), bucket_bytes=8 << 20)          # several buckets -> several collectives
+    # several buckets -> several collectives; a one-rank group (the RCCL rehearsal of a 1-GPU box) launches them all the same
+    buckets = GradBuckets(model.named_parameters(), bucket_bytes=8 << 20, single_rank_collectives=True)
     for _ in range(2):                                                             # the second pass checks reset()
         buckets.reset()
         out = model(s)
@@ -49,7 +50,7 @@ def main():
     if rank == 0:
         torch.save({"grads": {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None},
                     "mean_loss": lt.item() / world, "n_buckets": len(buckets.buckets), "world": dist.get_world_size(),
-                    "backend": dist.get_backend()}, out_path)
+                    "backend": dist.get_backend(), "collectives": buckets.launched}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -67,9 +67,10 @@ def _single_process(case):
     return loss.item(), grads, dead
 
 
-def _compare(res, case):
+def _compare(res, case, world=2):
     loss, ref, dead = _single_process(case)
-    assert res["world"] == 2 and res["n_buckets"] > 1
+    assert res["world"] == world and res["n_buckets"] > 1
+    assert res["collectives"] == 2 * res["n_buckets"]                        # two iterations, every bucket reduced in each
     assert abs(res["mean_loss"] - loss) < 1e-4 * abs(loss), (res["mean_loss"], loss)
     got = res["grads"]
     assert set(got) == set(ref) and not (set(got) & dead)                    # dead parameters are skipped, nothing else is
@@ -93,3 +94,14 @@ def test_two_ranks_rccl_equal_single_process_gradient(tmp_path):
     res = _run_ranks("tiny_b2_f6_p8", "nccl", False, tmp_path)
     assert res["backend"] == "nccl"
     _compare(res, "tiny_b2_f6_p8")
+
+
+def test_single_rank_rccl_collectives_on_the_card(tmp_path):
+    """What a 1-GPU box can show of the RCCL path: a ONE-rank ``nccl`` group on the card, the bucket all-reduces launched from
+    the backward hooks as in a multi-rank run (communicator set-up, RCCL kernels on the bucket memory, the hand-over between
+    RCCL's stream and the compute stream, barrier) - they must leave the gradients exactly as the plain backward made them."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    res = _run_ranks("tiny_b2_f6_p8", "nccl", True, tmp_path, world=1)
+    assert res["backend"] == "nccl"
+    _compare(res, "tiny_b2_f6_p8", world=1)

@@ -30,8 +30,11 @@ def shard_range(n_items, rank, world_size):
 
 
 class GradBuckets:
-    def __init__(self, params, bucket_bytes=48 << 20, group=None, average=True, names=None):
-        """``params``: parameters, or (name, parameter) pairs as from ``named_parameters()`` (names only serve error messages)."""
+    def __init__(self, params, bucket_bytes=48 << 20, group=None, average=True, names=None, single_rank_collectives=False):
+        """``params``: parameters, or (name, parameter) pairs as from ``named_parameters()`` (names only serve error messages).
+        ``single_rank_collectives``: launch the bucket all-reduces even in a one-rank group (an identity, but the whole
+        RCCL path - communicator, collective kernels on the bucket memory, stream hand-over - really runs: the rehearsal a
+        1-GPU box allows)."""
         params = list(params)
         self._names = {}
         if params and isinstance(params[0], tuple):
@@ -39,6 +42,8 @@ class GradBuckets:
             params = [p for _, p in params]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (single_rank_collectives and dist.is_initialized())
+        self.launched = 0          # collectives launched since construction
         self.average = average
         params = [p for p in params if p.requires_grad]
         # gradients become ready roughly in reverse construction order
@@ -73,10 +78,11 @@ class GradBuckets:
     def _make_hook(self, bi):
         def hook(_p):
             self._pending[bi] -= 1
-            if self._pending[bi] == 0 and self.world > 1:
+            if self._pending[bi] == 0 and self.collective:
                 flat = self.buckets[bi][0]
-                if self.average:
+                if self.average and self.world > 1:
                     flat.div_(self.world)
+                self.launched += 1
                 self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return hook
 
@@ -95,7 +101,7 @@ class GradBuckets:
         no gradient this iteration (a new unused parameter, a partial backward, an eval-style branch) would leave its bucket
         un-reduced and the ranks would step on different gradients - refuse instead of diverging silently (the reference
         pays for the same guarantee with ``find_unused_parameters=True``, base_trainer.py:134-137)."""
-        if self.world > 1 and any(self._pending):
+        if self.collective and any(self._pending):
             missing = [i for i, c in enumerate(self._pending) if c]
             names = []
             for bi in missing:

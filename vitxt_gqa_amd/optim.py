@@ -75,6 +75,7 @@ class FusedClipAdam(torch.optim.Adam):
             raise ValueError("FusedClipAdam does not take a closure")
         if len(self.param_groups) > 8:
             raise ValueError("FusedClipAdam supports at most 8 param groups")
+        self._opt_called = True            # what the wrapper lr_scheduler puts around step() records (its call-order check)
         live = []
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
