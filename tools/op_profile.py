@@ -11,7 +11,7 @@ from torch.profiler import ProfilerActivity, profile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vitxt_gqa_amd import training_config  # noqa: E402
 from vitxt_gqa_amd.ddp import GradBuckets  # noqa: E402
-from vitxt_gqa_amd.optim import build_optimizer, clip_gradients  # noqa: E402
+from vitxt_gqa_amd.optim import build_optimizer, clip_and_step  # noqa: E402
 from vitxt_gqa_amd.synth import make_batch, make_noise  # noqa: E402
 from vitxt_gqa_amd.testing import make_model, to_device  # noqa: E402
 
@@ -32,8 +32,7 @@ def step():
     buckets.reset()
     loss.backward()
     buckets.finish()
-    clip_gradients(model, cfg)
-    opt.step()
+    clip_and_step(model, opt, cfg)
 
 
 step()

@@ -422,6 +422,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
         FB_LD_KF(1); FB_FENCE();
         FB_SLOT_G1E(1, 0);
+        // the barrier that ends the PREVIOUS tile (every wave is done reading its dS^T image) stands here, ahead of the first dS^T
+        // store of this tile, instead of behind the atomics: a wave that got its atomics out early starts the next tile.  A bare
+        // s_barrier: it orders later LDS writes behind earlier LDS reads whose data has long been consumed by MFMAs - nothing
+        // to wait for (__syncthreads would drain the LDS loads in flight here)
+        asm volatile("s_barrier" ::: "memory");
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(0);
         FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         }
       }
       FB_TICK(4);                                            // atomics
-      __syncthreads();                                       // every wave is done reading the dS^T image
+      if constexpr (!FULL) __syncthreads();                  // every wave is done reading the dS^T image (pipelined form: see phase A)
       FB_TICK(5);                                            // barrier 2
     }
 #ifdef FB_STAMP
