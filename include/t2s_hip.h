@@ -86,8 +86,10 @@ int t2s_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
                  int64_t kv_row_stride, int64_t kv_batch_stride,
                  int64_t o_row_stride, int64_t o_batch_stride,
                  float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
-/* The same for the self-attention layout (Lq == idx_cap: query rows = prefix rows + decoder rows; bf16), with
- * the zero-fill done here: row_valid [B, idx_cap - n_dec] bytes is the mask the key list was compacted from
+/* The same for the self-attention layout (query rows = the idx_cap - n_dec prefix rows, then decoder rows, of which
+ * rows [dec_q0, dec_q0 + n_dec) are this call's; Lq >= idx_cap - in the shared-prefix layout of the three MMT passes
+ * of t2s.py:293-313 the decoder rows of the other two passes follow the prefix too and are never keys here; bf16),
+ * with the zero-fill done here: row_valid [B, idx_cap - n_dec] bytes is the mask the key list was compacted from
  * (t2s_compact_keys' input); the dQ kernel, which visits every (row, head) anyway, writes the zero dK / dV
  * slices of the rows no list entry points at, so dq/dk/dv may be uninitialised memory on entry. */
 int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, const void* out, const void* dout,

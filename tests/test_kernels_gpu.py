@@ -298,6 +298,52 @@ def test_attention_bwd_fills_unlisted_rows_in_kernel(keep, drop_p):
     assert a[:, :L1, 768:][unlisted].abs().max().item() == 0.0 if unlisted.any() else True
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_attention_shared_prefix_layout_equals_own_sequence(which, fused):
+    """The layout of functional.SharedPrefixEncoderFn: one sequence [prefix | dec rows of pass 0 | pass 1 | pass 2], a call lists
+    only ITS decoder rows as keys (dec_row0 = L1 + which * D).  For the prefix rows and the call's own decoder rows, forward
+    output and all three gradients must equal those of the call's own [prefix | dec] sequence; the other passes' decoder rows
+    get exact-zero dK / dV (written in-kernel: nothing of the uninitialised buffer survives) and, with a zero output
+    gradient, exact-zero dQ."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    torch.manual_seed(11 + which)
+    B, L1, D = 2, 1100, 12
+    L = L1 + 3 * D
+    qkv = torch.randn(B, L, 2304, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, device=DEV).to(torch.bfloat16)
+    own = slice(L1 + which * D, L1 + (which + 1) * D)
+    others = torch.ones(L, dtype=torch.bool, device=DEV)
+    others[:L1] = False
+    others[own] = False
+    dout[:, others] = 0                                  # nothing reads the other passes' decoder rows of this call's output
+    valid = torch.rand(B, L1, device=DEV) < 0.6
+    valid[:, 3] = True
+    keys = ops.compact_keys(valid, n_dec=D, dec_row0=L1 + which * D)
+    out, lse = ops.attn_fwd(qkv, keys)
+    junk = torch.full((B, L, 2304), float("nan"), device=DEV, dtype=torch.bfloat16)
+    del junk
+    g = ops.attn_bwd(qkv, out, dout, lse, keys, fused=fused)
+    assert torch.isfinite(g.float()).all()
+    # the same call on its own sequence
+    rows = torch.cat([torch.arange(L1, device=DEV), torch.arange(own.start, own.stop, device=DEV)])
+    qkv1, dout1 = qkv[:, rows].contiguous(), dout[:, rows].contiguous()
+    keys1 = ops.compact_keys(valid, n_dec=D, dec_row0=L1)
+    out1, lse1 = ops.attn_fwd(qkv1, keys1)
+    g1 = ops.attn_bwd(qkv1, out1, dout1, lse1, keys1, fused=fused)
+    assert torch.equal(out[:, rows], out1) and torch.equal(lse[:, :, rows], lse1)
+    if not fused and which == 0:                         # same rows in the same tiles: the same arithmetic
+        assert torch.equal(g[:, rows], g1)
+    else:       # the decoder rows sit in another query tile (dK / dV sum the tiles in order), fused: dQ is summed with float atomics -
+        for third in range(3):                           # equal up to the fp32 summation order, i.e. to a bf16 ulp of the result
+            a, b = g[:, rows, 768 * third:768 * (third + 1)].float(), g1[:, :, 768 * third:768 * (third + 1)].float()
+            assert (a - b).abs().max().item() <= 1e-2 * b.abs().max().item(), third
+            assert (a - b).norm().item() <= 2e-3 * b.norm().item(), third
+    assert g[:, others].abs().max().item() == 0.0
+    assert g[:, :L1, 768:][~valid].abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
 def test_attention_bwd_survives_a_wrong_static_key_bound(dtype, drop_p):

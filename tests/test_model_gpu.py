@@ -258,6 +258,7 @@ def test_batched_mmt_passes_equal_separate_passes():
     s = to_device(make_batch(B, F, P, V=V, seed=3, text_vocab=50), DEV)
     s.grounding_noise = tuple(t.to(DEV) for t in make_noise(B, F, P, seed=3))
     res = {}
+    model.share_mmt_prefix = False          # "separate" = the reference's literal three encoder calls
     for mode in (False, True):
         model.batch_mmt_passes = mode
         model.zero_grad(set_to_none=True)
@@ -272,6 +273,46 @@ def test_batched_mmt_passes_equal_separate_passes():
     for n, g in res[False][1].items():
         d = (g - res[True][1][n]).abs().max().item()
         assert d <= 1e-4 * max(1.0, g.abs().max().item()), (n, d)
+
+
+@pytest.mark.parametrize("dtype,tol_s,tol_g", [(torch.float32, 1e-4, 1e-4), (torch.bfloat16, 3e-2, 3e-2)])
+def test_shared_prefix_passes_equal_separate_passes(dtype, tol_s, tol_g):
+    """MMT.forward_shared_prefix (one sequence [prefix | dec(ref) | dec(pos) | dec(neg)]: one concatenation, one operand copy,
+    ONE layer-0 QKV projection for the three passes, their input / projection gradients summed in place) against the reference's
+    three separate encoder calls (t2s.py:293-313): same scores, same parameter gradients (dropout 0).  fp32 mode: equal up to
+    summation order; bf16 mode: the shared form sums the three passes' dQKV / residual gradients in bf16 before the one
+    weight-gradient GEMM - compared at gradient-norm level."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vitxt_gqa_amd.synth import make_batch, make_noise
+    from vitxt_gqa_amd.testing import make_model, to_device
+    F, P, V, B = 7, 9, 40, 3
+    model = make_model(F, P, V, text_vocab=50, dtype=dtype, attn_gain=4.0).to(DEV).train()
+    batch = make_batch(B, F, P, V=V, seed=3, text_vocab=50)
+    batch["train_prev_inds"][:, 2] = V + 5           # copied OCR tokens: the OCR branch of the decoder-step embeddings
+    batch["train_prev_inds"][:, 4] = V + F * P - 1
+    batch["ocr_mask"][0, -P:] = 0
+    s = to_device(batch, DEV)
+    s.grounding_noise = tuple(t.to(DEV) for t in make_noise(B, F, P, seed=3))
+    res = {}
+    for mode in (False, True):
+        model.share_mmt_prefix = mode
+        model.zero_grad(set_to_none=True)
+        out = model(s)
+        sum(l.mean() for l in out["losses"].values()).backward()
+        res[mode] = ({k: out[k].detach().float().clone() for k in ("ref_scores", "pos_scores", "neg_scores")},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    for k in res[False][0]:
+        assert (res[False][0][k] - res[True][0][k]).abs().max().item() < tol_s, k
+    assert res[False][1].keys() == res[True][1].keys()
+    tot = sum(g.double().norm().item() ** 2 for g in res[False][1].values()) ** 0.5
+    for n, g in res[False][1].items():
+        if dtype == torch.float32:
+            d = (g - res[True][1][n]).abs().max().item()
+            assert d <= tol_g * max(1.0, g.abs().max().item()), (n, d)
+        else:
+            d = (g.double() - res[True][1][n].double()).norm().item()
+            assert d <= tol_g * g.double().norm().item() + 1e-3 * tot, (n, d, g.double().norm().item())
 
 
 def test_model_call_appends_metrics_from_the_config_list():

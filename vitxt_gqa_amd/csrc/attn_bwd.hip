@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
     const int row = q0 + r;
     if (row < p.Lq) {
       *reinterpret_cast<uint4*>(DQ + (int64_t)row * p.q_rs + cc * 8) = *reinterpret_cast<const uint4*>(ob + r * 144 + cc * 16);
-      if (rv && row < p.valid_len && !rv[row]) {           // a row no key list entry points at: its dK / dV are exact zeros
+      // a row no key list entry points at (a prefix row with row_valid 0, or a row behind the prefix that is not one of this
+      // call's n_dec decoder rows - the decoder rows of the OTHER passes in the shared-prefix layout): its dK / dV are exact zeros
+      if (rv && (row < p.valid_len ? !rv[row] : (row < p.dec_q0 || row >= p.dec_q0 + p.n_dec))) {
         *reinterpret_cast<uint4*>(DK + (int64_t)row * p.kv_rs + cc * 8) = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(DV + (int64_t)row * p.kv_rs + cc * 8) = make_uint4(0, 0, 0, 0);
       }
@@ -584,7 +586,8 @@ extern "C" int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, co
                                  uint64_t drop_seed, t2s_stream_t stream) {
   T2S_CHECK_ARG(row_valid && kv_idx, "attn_bwd_fill: row_valid and the key list are required");
   T2S_CHECK_ARG(dtype == T2S_BF16, "attn_bwd_fill: bf16 only (the fp32 kernels leave unlisted rows to the caller)");
-  T2S_CHECK_ARG(Lq == idx_cap, "attn_bwd_fill: self-attention layout expected (query rows = prefix rows + decoder rows)");
+  T2S_CHECK_ARG(Lq >= idx_cap && (n_dec == 0 || (dec_q0 >= idx_cap - n_dec && dec_q0 + n_dec <= Lq)),
+                "attn_bwd_fill: self-attention layout expected (query rows = prefix rows, then decoder rows; this call's n_dec decoder rows at dec_q0)");
   return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
                        q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed,
                        row_valid, nullptr, stream);
@@ -598,7 +601,8 @@ extern "C" int t2s_attn_bwd_fused(const void* q, const void* k, const void* v, c
                                   t2s_stream_t stream) {
   T2S_CHECK_ARG(dq32, "attn_bwd_fused: the fp32 dQ accumulation buffer is required");
   T2S_CHECK_ARG(dtype == T2S_BF16, "attn_bwd_fused: bf16 only");
-  T2S_CHECK_ARG(!row_valid || (kv_idx && Lq == idx_cap), "attn_bwd_fused: row_valid needs the key list and the self-attention layout");
+  T2S_CHECK_ARG(!row_valid || (kv_idx && Lq >= idx_cap && (n_dec == 0 || (dec_q0 >= idx_cap - n_dec && dec_q0 + n_dec <= Lq))),
+                "attn_bwd_fused: row_valid needs the key list and the self-attention layout");
   return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
                        q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed,
                        row_valid, dq32, stream);

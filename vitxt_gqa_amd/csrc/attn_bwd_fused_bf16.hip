@@ -704,10 +704,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 
 // delta[b, h, q] = sum_d dO * O (one wave per token row, as attn_delta_kernel), plus the housekeeping of the fused backward in
 // the same pass over the rows: zero the row of the fp32 dQ accumulation buffer, and write the exact-zero dK / dV slices of
-// prefix rows that no key-list entry points at (row_valid == 0).
+// rows that no key-list entry points at (prefix rows with row_valid == 0; rows behind the prefix other than this call's decoder rows).
 __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
                                                               float* __restrict__ dq32, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
-                                                              const uint8_t* __restrict__ row_valid, int valid_len, int B, int H, int Lq,
+                                                              const uint8_t* __restrict__ row_valid, int valid_len, int dec_q0, int n_dec, int B, int H, int Lq,
                                                               int64_t o_rs, int64_t o_bs, int64_t kv_rs, int64_t kv_bs) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __re
   const bf16_t* dp = dout + (int64_t)b * o_bs + (int64_t)q * o_rs;
   const int nchunk = H * 16;              // 4-element chunks per row
   float* zrow = dq32 + row * (int64_t)(H * 64);
-  const bool fill = row_valid && q < valid_len && !row_valid[(int64_t)b * valid_len + q];
+  const bool fill = row_valid && (q < valid_len ? !row_valid[(int64_t)b * valid_len + q] : (q < dec_q0 || q >= dec_q0 + n_dec));
   for (int c0 = 0; c0 < nchunk; c0 += 64) {
     const int ci = c0 + lane;
     float s = 0.f;
@@ -773,7 +773,7 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, float* dq32
     }
   const int64_t rows = (int64_t)p.B * p.Lq;
   hipLaunchKernelGGL(attn_delta_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)p.o, (const bf16_t*)p.dout, p.delta,
-                     dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.B, p.H, p.Lq, p.o_rs, p.o_bs, p.kv_rs, p.kv_bs);
+                     dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs, p.kv_rs, p.kv_bs);
   p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256), tail(attn_xcd_grid(1, p.H, p.B));
 #define FB_LAUNCH(IDX_, MODE_, grid_)                                                                                  \

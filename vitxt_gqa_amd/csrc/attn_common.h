@@ -26,7 +26,8 @@ struct AttnParams {
   float drop_inv;                // 1 / (1 - thresh / 65536)
   // backward, optional: row_valid [B, valid_len] bytes, 0 = the prefix row is NOT in the key list.  The dQ kernel, which
   // visits every (row, head) anyway, then writes the zeros of that row's dK / dV slices, so the caller need not zero-fill
-  // the gradient buffer (rows >= valid_len, the decoder rows, are always listed)
+  // the gradient buffer (of the rows >= valid_len only this call's decoder rows [dec_q0, dec_q0 + n_dec) are listed; in the
+  // shared-prefix layout of the three MMT passes the decoder rows of the other two passes follow the prefix as well)
   const uint8_t* row_valid;
   int valid_len;
 };

@@ -94,7 +94,10 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     assert lse.shape == (B, HEADS, L) and lse.is_contiguous()
     _check_keys(keys, B, L)
     cap = keys.idx.shape[1]
-    fill_in_kernel = qkv.dtype == torch.bfloat16 and keys.valid8 is not None and cap == L and keys.valid8.shape == (B, L - keys.n_dec)
+    # self-attention layout: the rows the mask covers, then decoder rows - this call's n_dec of them at dec_q0 (cap == L), or those
+    # of all three MMT passes with only this call's listed (shared-prefix layout, cap < L)
+    fill_in_kernel = (qkv.dtype == torch.bfloat16 and keys.valid8 is not None and cap <= L and keys.valid8.shape == (B, cap - keys.n_dec)
+                      and (keys.n_dec == 0 or keys.dec_q0 >= cap - keys.n_dec))
     # rows outside the key list have exactly zero dK / dV: written by the dQ kernel when it is handed the mask (bf16 path),
     # otherwise by a zero fill of the whole buffer (3 GB at B=64) before the launch
     dqkv = torch.empty_like(qkv) if fill_in_kernel else torch.zeros_like(qkv)

@@ -15,6 +15,8 @@ Differences that are deliberate and documented:
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -291,6 +293,31 @@ class MMT(nn.Module):
         out = FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd, pa)
         return FN.split_rows(out, T + Fn, L1)
 
+    def forward_shared_prefix(self, txt_emb, txt_mask, obj_emb, obj_masks, ocr_emb, ocr_masks, fixed_ans_emb, prev_inds, dtype,
+                              max_keys=None):
+        """The reference's three MMT calls of one train step (ref / pos / neg masks, t2s.py:293-313) over ONE sequence
+        [q; frames; OCR | dec(ref) | dec(pos) | dec(neg)]: the prefix rows are identical in the three calls, so they are
+        concatenated, cast and projected to layer 0's Q/K/V once, and their input gradients are accumulated in one place
+        (functional.SharedPrefixEncoderFn).  Each pass keeps its own key list, its own decoder-step rows (their dropout draw
+        differs) and its own dropout seeds; the decoder rows of the other passes are never keys in it.  Returns one
+        (ocr_out, dec_out) pair per pass; ``max_keys``: static bound on the visible keys of each pass (or None)."""
+        pd, pa = _train_dropout(self)
+        T, Fn, N = txt_emb.size(1), obj_emb.size(1), ocr_emb.size(1)
+        L1 = T + Fn + N
+        decs = [self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd) for _ in obj_masks]
+        D = decs[0].size(1)
+        x = torch.cat([txt_emb, obj_emb, ocr_emb] + decs, dim=1)
+        keys = []
+        for i, (om, cm) in enumerate(zip(obj_masks, ocr_masks)):
+            valid = torch.cat([txt_mask > 0, om > 0, cm > 0], dim=1)
+            keys.append(ops.compact_keys(valid, n_dec=D, dec_row0=L1 + i * D, cap_hint=None if max_keys is None else max_keys[i]))
+        outs = FN.shared_prefix_encoder(x, keys, self.encoder.layer, dtype, pd, pa)
+        res = []
+        for i, out in enumerate(outs):
+            ocr_out, tail = FN.split_rows(out, T + Fn, L1)
+            res.append((ocr_out, tail[:, i * D:(i + 1) * D]))
+        return res
+
     def forward_passes(self, txt_emb, txt_mask, obj_emb, obj_masks, ocr_emb, ocr_masks, fixed_ans_emb, prev_inds, dtype):
         """The reference's three MMT calls of one train step (ref / pos / neg masks, t2s.py:293-313) as ONE encoder call on
         a 3B batch: the passes share every weight and differ only in their key lists (and in the dropout draw of the
@@ -384,6 +411,9 @@ class T2S(BaseModel):
         self.answer_processor = registry.get(self._datasets[0] + "_answer_processor")
         self.decode_with_prefix_cache = True      # eval: reuse the step-invariant prefix K/V (False = reference's loop)
         self.batch_mmt_passes = False             # train: True = the three MMT passes as one 3B-batch encoder call (MMT.forward_passes)
+        # train: the three MMT passes over one sequence with a shared prefix (MMT.forward_shared_prefix); T2S_SHARE_MMT_PREFIX=0
+        # runs them as three separate encoder calls, the reference's literal structure
+        self.share_mmt_prefix = os.environ.get("T2S_SHARE_MMT_PREFIX", "1") != "0"
         for n, p in self.named_parameters():
             if is_dead_param(n):
                 p.requires_grad_(False)
@@ -483,6 +513,13 @@ class T2S(BaseModel):
         passes = (("ref", fwd["obj_mask"], fwd["ocr_mask"]),
                   ("pos", fwd["pos_obj_mask"], fwd["pos_ocr_mask"]),
                   ("neg", fwd["neg_obj_mask"], fwd["neg_ocr_mask"]))
+        if self.training and self.share_mmt_prefix and not self.batch_mmt_passes:
+            outs = self.mmt.forward_shared_prefix(fwd["txt_emb"], fwd["txt_mask"], fwd["obj_mmt_in"], [p[1] for p in passes],
+                                                  fwd["ocr_mmt_in"], [p[2] for p in passes], self.classifier.module.weight, prev_inds, dt,
+                                                  max_keys=[bounds[p[0]] for p in passes])
+            for (name, _, cm), (ocr_out, dec_out) in zip(passes, outs):
+                fwd[name + "_scores"] = self._forward_output(ocr_out, dec_out, cm, dt)
+            return
         if self.training and self.batch_mmt_passes:
             outs = self.mmt.forward_passes(fwd["txt_emb"], fwd["txt_mask"], fwd["obj_mmt_in"], [p[1] for p in passes],
                                            fwd["ocr_mmt_in"], [p[2] for p in passes], self.classifier.module.weight, prev_inds, dt)
