@@ -20,6 +20,11 @@ if [ "$PART" != "core" ]; then
 timeout -k 10 900 python3 $REPO/bench.py --forward-only --no-cpu-baseline > $OUT/forward_only.json 2>> $OUT/bench.err
 timeout -k 10 900 python3 $REPO/bench.py --batch 2 --frames 300 --ocr 200 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stress_b2_300x200.json 2>> $OUT/bench.err
 timeout -k 10 900 python3 $REPO/bench.py --no-cpu-baseline --no-dropout0 --host-inputs --compact-wire > $OUT/host_inputs_compact.json 2>> $OUT/bench.err
+# 1c. measured ceilings of this box (library GEMM rates, HBM copy / read / fill rates) and the attention kernels alone
+timeout -k 10 300 python3 $REPO/tools/ceilings.py > $OUT/ceilings.json 2>> $OUT/bench.err
+timeout -k 10 300 python3 $REPO/tools/attn_probe.py 32 10120 0.7 12 5 0.1 > $OUT/attn_probe_b32.txt 2>> $OUT/bench.err
+timeout -k 10 300 python3 $REPO/tools/attn_probe.py 32 10120 0.7 12 5 0.0 >> $OUT/attn_probe_b32.txt 2>> $OUT/bench.err
+T2S_BENCH_FORCE_DIST=1 timeout -k 10 600 python3 $REPO/bench.py --no-cpu-baseline --no-dropout0 > $OUT/single_rank_rccl.json 2>> $OUT/bench.err
 fi
 if [ "$PART" != "extra" ]; then
 # 2. kernel trace + stats of the same command (fewer steps, no CPU baseline: identical GPU work per step)
