@@ -2,7 +2,7 @@
 """Where a query tile of the fused attention backward spends its cycles: builds a DIAGNOSTIC copy of the library with -DFB_STAMP
 (s_memtime stamps around the segments of the tile loop, summed per workgroup by wave 0), runs one launch and prints the
 shares.  The stamps serialise the segments (fences), so read the SHARES, not the total (cdna_hip_programming.md section 7).
-usage (GPU box): python tools/fused_stamps.py [B keep]"""
+usage (GPU box): [FB_SLOTS=1] [FB_ABL=n] python tools/fused_stamps.py [B keep drop_p]"""
 import os
 import subprocess
 import sys
@@ -14,7 +14,8 @@ os.makedirs(out, exist_ok=True)
 lib = os.path.join(out, "libt2s_stamp.so")
 from vitxt_gqa_amd import build as Bld  # noqa: E402
 abl = os.environ.get("FB_ABL", "0")          # timing-only ablations: 1 = no dQ operand reads, 2 = no dQ MFMAs (results wrong)
-subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-DFB_STAMP", "-DFB_ABL=" + abl, "-o", lib] + Bld.sources())
+slots = os.environ.get("FB_SLOTS", "0") == "1"   # stamp the slot classes of phase A instead of the tile's segments
+subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-DFB_STAMP", "-DFB_ABL=" + abl] + (["-DFB_STAMP_SLOTS"] if slots else []) + ["-o", lib] + Bld.sources())
 os.environ["T2S_HIP_LIB"] = lib
 import torch  # noqa: E402
 from vitxt_gqa_amd import ops  # noqa: E402
@@ -29,13 +30,17 @@ dout = torch.randn(B, L, 768, device="cuda", dtype=torch.bfloat16)
 valid = torch.rand(B, L1, device="cuda") < keep
 valid[:, 0] = True
 keys = ops.compact_keys(valid, n_dec=nd, dec_row0=L1)
-o, lse = ops.attn_fwd(qkv, keys)
+dp = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+kw = dict(drop_p=dp, drop_seed=77) if dp > 0 else {}
+o, lse = ops.attn_fwd(qkv, keys, **kw)
 for _ in range(3):
-    ops.attn_bwd(qkv, o, dout, lse, keys, fused=True)
+    ops.attn_bwd(qkv, o, dout, lse, keys, fused=True, **kw)
 torch.cuda.synchronize()
 d = ops._LAST_DQ32[B * L * 768:].view(torch.int64).view(-1, 8)[:256].cpu()
 d = d[d[:, 6] > 0]
 names = ["phase A", "stage write", "barrier 1", "phase B", "atomics", "barrier 2"]
+if slots:
+    names = ["G1(b0)  x1", "G1+E    x5", "G2+M    x4", "G2M4+E5 x1", "G2+M(b5) x1", "behind A"]
 tiles = d[:, 6].double()
 per = d[:, :6].double() / tiles.unsqueeze(1)
 print("workgroups sampled: %d, tiles per workgroup %d" % (len(d), int(tiles[0])))

@@ -351,6 +351,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #else
 #define FB_TICK(k_)
 #endif
+    // FB_STAMP_SLOTS (diagnostic build): the six counters are re-used for the slot classes of phase A instead of the tile's segments:
+    // 0 = slot G1(b0), 1 = the five G1+E slots, 2 = the G2+M slots of b0..b3, 3 = the G2(b4)+M(b4)+E(b5) slot, 4 = G2+M(b5),
+    // 5 = everything behind phase A
+#if defined(FB_STAMP) && defined(FB_STAMP_SLOTS)
+#undef FB_TICK
+#define FB_TICK(k_) { if ((k_) == 5) { FB_FENCE(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1) :: "memory"); st_sum[5] += st_t1 - st_t0; st_t0 = st_t1; FB_FENCE(); } }
+#define FB_TICKS(k_) { FB_FENCE(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1) :: "memory"); st_sum[k_] += st_t1 - st_t0; st_t0 = st_t1; FB_FENCE(); }
+#else
+#define FB_TICKS(k_)
+#endif
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
       FB_STAGE_LOAD();                                      // next tile in sequence (past the end: clamped rows, harmless)
@@ -420,8 +430,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // slot 0: G1(b0), nothing to pair yet; the transposed fragments of sub-block 0 arrive meanwhile
         FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
+        FB_TICKS(0);
         FB_LD_KF(1); FB_FENCE();
         FB_SLOT_G1E(1, 0);
+        FB_TICKS(1);
         // the barrier that ends the PREVIOUS tile (every wave is done reading its dS^T image) stands here, ahead of the first dS^T
         // store of this tile, instead of behind the atomics: a wave that got its atomics out early starts the next tile.  A bare
         // s_barrier: it orders later LDS writes behind earlier LDS reads whose data has long been consumed by MFMAs - nothing
@@ -429,24 +441,34 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         asm volatile("s_barrier" ::: "memory");
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(0);
+        FB_TICKS(2);
         FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
+        FB_TICKS(1);
         FB_LD_QF(qb_, dob_, 1); FB_LD_KF(0); FB_FENCE();
         FB_SLOT_G2M(1);
+        FB_TICKS(2);
         FB_SLOT_G1E(3, 2);
+        FB_TICKS(1);
         FB_LD_KF(1); FB_FENCE();
         FB_SLOT_G2M(2);                                      // last use of sub-block 0's transposed fragments
+        FB_TICKS(2);
         FB_LD_QT(1); FB_FENCE();
         FB_SLOT_G1E(4, 3);
+        FB_TICKS(1);
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(3);
+        FB_TICKS(2);
         FB_SLOT_G1E(5, 4);
+        FB_TICKS(1);
         // slot "G2(b4) + M(b4) + E(b5)": E(b5) only behind the dV^T MFMAs of b4, which still read the operand words of P(b4)
         FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_FENCE();
         FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_FENCE();
         FB_THR(5); FB_LD_RK(5);
         FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 0); FB_E(5, 1); FB_FENCE(); FB_G2(4, 5); FB_E(5, 2); FB_E(5, 3); FB_FENCE();
         FB_G2(4, 6); FB_E(5, 4); FB_E(5, 5); FB_FENCE(); FB_G2(4, 7); FB_E(5, 6); FB_E(5, 7); FB_FENCE();
+        FB_TICKS(3);
         FB_SLOT_G2M(5);
+        FB_TICKS(4);
 #undef FB_THR
 #undef FB_LD_RK
 #undef FB_LD_DL
