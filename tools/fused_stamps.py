@@ -40,7 +40,7 @@ d = ops._LAST_DQ32[B * L * 768:].view(torch.int64).view(-1, 8)[:256].cpu()
 d = d[d[:, 6] > 0]
 names = ["phase A", "stage write", "barrier 1", "phase B", "atomics", "barrier 2"]
 if slots:
-    names = ["G1(b0)  x1", "G1+E    x5", "G2+M    x4", "G2M4+E5 x1", "G2+M(b5) x1", "behind A"]
+    names = ["G1(b0)      x1", "G1+E        x5", "G2+M 1st half x5", "G2+M 2nd half x4", "G2M4+E5, G2M5 2nd", "behind A"]
 tiles = d[:, 6].double()
 per = d[:, :6].double() / tiles.unsqueeze(1)
 print("workgroups sampled: %d, tiles per workgroup %d" % (len(d), int(tiles[0])))

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #define FB_TICK(k_)
 #endif
     // FB_STAMP_SLOTS (diagnostic build): the six counters are re-used for the slot classes of phase A instead of the tile's segments:
-    // 0 = slot G1(b0), 1 = the five G1+E slots, 2 = the G2+M slots of b0..b3, 3 = the G2(b4)+M(b4)+E(b5) slot, 4 = G2+M(b5),
+    // 0 = slot G1(b0), 1 = the five G1+E slots, 2 / 3 = first (dV^T + M) / second (dK^T + LDS) halves of the G2+M slots of b0..b3 (and 2 also
+    // the first half of G2+M(b5)), 4 = the G2(b4)+M(b4)+E(b5) slot and the second half of G2+M(b5),
     // 5 = everything behind phase A
 #if defined(FB_STAMP) && defined(FB_STAMP_SLOTS)
 #undef FB_TICK
@@ -363,7 +364,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #endif
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
-      FB_STAGE_LOAD();                                      // next tile in sequence (past the end: clamped rows, harmless)
+      // global loads of the next tile in sequence (past the end: clamped rows, harmless).  Pipelined form: issued a third of the way
+      // into phase A instead of here - at the top of the tile the memory pipeline is still draining the 16 atomics per lane of the
+      // previous tile, and the loads are not needed before the end of the phase
+      if constexpr (!FULL) FB_STAGE_LOAD();
       const char* qb_ = stage + buf * FB_STAGE;
       const char* dob_ = qb_ + FB_TILE;
       const float* lse_s = reinterpret_cast<const float*>(qb_ + 2 * FB_TILE);
@@ -422,9 +426,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #define FB_SLOT_G2M(i_)                                                                             \
   FB_LD_DL(i_);                                                                                     \
   FB_G2(i_, 0); FB_M(i_, 0); FB_M(i_, 1); FB_FENCE(); FB_G2(i_, 1); FB_M(i_, 2); FB_M(i_, 3); FB_FENCE();                        \
-  FB_G2(i_, 2); FB_M(i_, 4); FB_M(i_, 5); FB_FENCE(); FB_G2(i_, 3); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE();                        \
-  FB_G2(i_, 4); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE();               \
-  FB_G2(i_, 6); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
+  FB_G2(i_, 2); FB_M(i_, 4); FB_FENCE(); FB_G2(i_, 3); FB_M(i_, 5); FB_FENCE();                                                   \
+  FB_TICKS(2);                                                                                                                    \
+  /* the dK^T MFMAs of s = 0 need chunks 0..3 only: chunks 6, 7 of dS are formed beside the first of them (an MFMA group ahead of */   \
+  /* the s = 1 MFMAs that read them: the asm MFMAs get no hazard nops), the seeds of block i + 2 are fetched once the last chunk */     \
+  /* has read this block's accumulators, the dS^T stores follow */                                                                   \
+  FB_G2(i_, 4); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE(); \
+  FB_G2(i_, 6); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
         if (!PREF) { FB_LD_QF(qb_, dob_, 0); FB_LD_SEEDS(lse_s, del_s, 0); FB_LD_KF(0); }
         FB_FENCE();
         // slot 0: G1(b0), nothing to pair yet; the transposed fragments of sub-block 0 arrive meanwhile
@@ -441,23 +449,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         asm volatile("s_barrier" ::: "memory");
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(0);
-        FB_TICKS(2);
+        FB_TICKS(3);
         FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
         FB_TICKS(1);
         FB_LD_QF(qb_, dob_, 1); FB_LD_KF(0); FB_FENCE();
         FB_SLOT_G2M(1);
-        FB_TICKS(2);
+        FB_TICKS(3);
+        FB_STAGE_LOAD(); FB_FENCE();
         FB_SLOT_G1E(3, 2);
         FB_TICKS(1);
         FB_LD_KF(1); FB_FENCE();
         FB_SLOT_G2M(2);                                      // last use of sub-block 0's transposed fragments
-        FB_TICKS(2);
+        FB_TICKS(3);
         FB_LD_QT(1); FB_FENCE();
         FB_SLOT_G1E(4, 3);
         FB_TICKS(1);
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(3);
-        FB_TICKS(2);
+        FB_TICKS(3);
         FB_SLOT_G1E(5, 4);
         FB_TICKS(1);
         // slot "G2(b4) + M(b4) + E(b5)": E(b5) only behind the dV^T MFMAs of b4, which still read the operand words of P(b4)
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         FB_THR(5); FB_LD_RK(5);
         FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 0); FB_E(5, 1); FB_FENCE(); FB_G2(4, 5); FB_E(5, 2); FB_E(5, 3); FB_FENCE();
         FB_G2(4, 6); FB_E(5, 4); FB_E(5, 5); FB_FENCE(); FB_G2(4, 7); FB_E(5, 6); FB_E(5, 7); FB_FENCE();
-        FB_TICKS(3);
+        FB_TICKS(4);
         FB_SLOT_G2M(5);
         FB_TICKS(4);
 #undef FB_THR
@@ -582,7 +591,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // steps of 16 keys in groups of 4; full key blocks: 24 steps with the transposed reads of group g+1 in flight under the
         // MFMAs of group g, otherwise the steps that hold valid keys (rows past them may never have been written)
 #ifndef FB_ABL
-#define FB_ABL 0      // timing-only ablation switches of the diagnostic build (results are then wrong); 0 in every product build
+#define FB_ABL 0      // timing-only ablation switches of the diagnostic build (results are then wrong; 1 / 2: no dQ operand reads / MFMAs,
+                      // 4: no atomics, 8: plain stores in their place); 0 in every product build
 #endif
 #if FB_ABL & 1
 #define FB_DQ_LOAD_A(af_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(af_[u]));
@@ -668,14 +678,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         const int rstep = p.H * 64;
         float* rowp = DQ + (int64_t)q0 * rstep + dq_db * 32;          // wave-uniform (dq_qb / dq_db come from readfirstlane)
         const int loff = lr + 4 * lh * rstep;                          // this lane's element offset
+#if FB_ABL & 4        // timing-only: no atomics (the accumulator is kept alive)
+#define FB_DQ_OUT(ptr_, v_) asm volatile("" :: "v"(v_))
+#elif FB_ABL & 8      // timing-only: plain stores in their place (same addresses, same bytes)
+#define FB_DQ_OUT(ptr_, v_) *(ptr_) = (v_)
+#else
+#define FB_DQ_OUT(ptr_, v_) unsafeAtomicAdd(ptr_, v_)
+#endif
         if (q0 + 32 <= p.Lq) {                               // whole sub-block inside the sequence
 #pragma unroll
-          for (int r = 0; r < 16; ++r) unsafeAtomicAdd(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
+          for (int r = 0; r < 16; ++r) FB_DQ_OUT(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (q0 + acc_row(r, lh) < p.Lq) unsafeAtomicAdd(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
+            if (q0 + acc_row(r, lh) < p.Lq) FB_DQ_OUT(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
         }
+#undef FB_DQ_OUT
       }
       FB_TICK(4);                                            // atomics
       if constexpr (!FULL) __syncthreads();                  // every wave is done reading the dS^T image (pipelined form: see phase A)
