@@ -2,7 +2,7 @@
 """Where a query tile of the fused attention backward spends its cycles: builds a DIAGNOSTIC copy of the library with -DFB_STAMP
 (s_memtime stamps around the segments of the tile loop, summed per workgroup by wave 0), runs one launch and prints the
 shares.  The stamps serialise the segments (fences), so read the SHARES, not the total (cdna_hip_programming.md section 7).
-usage (GPU box): [FB_SLOTS=1] [FB_ABL=n] python tools/fused_stamps.py [B keep drop_p]"""
+usage (GPU box): [FB_SLOTS=1] [FB_ABL=n] [FB_MODE=1 (stamp the edge-block kernel)] python tools/fused_stamps.py [B keep drop_p]"""
 import os
 import subprocess
 import sys
@@ -15,7 +15,7 @@ lib = os.path.join(out, "libt2s_stamp.so")
 from vitxt_gqa_amd import build as Bld  # noqa: E402
 abl = os.environ.get("FB_ABL", "0")          # timing-only ablations: 1 = no dQ operand reads, 2 = no dQ MFMAs (results wrong)
 slots = os.environ.get("FB_SLOTS", "0") == "1"   # stamp the slot classes of phase A instead of the tile's segments
-subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-DFB_STAMP", "-DFB_ABL=" + abl] + (["-DFB_STAMP_SLOTS"] if slots else []) + ["-o", lib] + Bld.sources())
+subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-DFB_STAMP", "-DFB_ABL=" + abl] + (["-DFB_STAMP_SLOTS"] if slots else []) + ["-DFB_STAMP_MODE=" + os.environ.get("FB_MODE", "0")] + ["-o", lib] + Bld.sources())
 os.environ["T2S_HIP_LIB"] = lib
 import torch  # noqa: E402
 from vitxt_gqa_amd import ops  # noqa: E402

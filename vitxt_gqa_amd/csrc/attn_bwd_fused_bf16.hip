@@ -700,7 +700,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       FB_TICK(5);                                            // barrier 2
     }
 #ifdef FB_STAMP
-    if (MODE == 0 && lane == 0 && wave == 0) {
+#ifndef FB_STAMP_MODE
+#define FB_STAMP_MODE 0      // which kernel of the launch records its stamps (0: full key blocks, 1: the edge blocks)
+#endif
+    if (MODE == FB_STAMP_MODE && lane == 0 && wave == 0) {
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(dq32 + (int64_t)p.B * p.Lq * (p.H * 64)) + (int64_t)(blockIdx.x & 255) * 8;
       for (int k = 0; k < 6; ++k) dbg[k] = st_sum[k];
       dbg[6] = (unsigned long long)nqt;
