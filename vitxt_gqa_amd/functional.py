@@ -307,10 +307,9 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
                 per[pi * n_layers + l] = None
                 if grads[l] is None:
                     grads[l] = list(g)
-                else:
-                    for i, t in enumerate(g):
-                        if t is not None:
-                            grads[l][i].add_(t)
+                else:                      # one multi-tensor add per layer and pass instead of ten small launches
+                    pairs = [(a, t) for a, t in zip(grads[l], g) if t is not None]
+                    torch._foreach_add_([a for a, _ in pairs], [t for _, t in pairs])
             dz1, dqkv = d
             # sums over the passes in the operand dtype, in place in the first pass's buffers
             dz1_sum = dz1 if dz1_sum is None else dz1_sum.add_(dz1)
