@@ -82,8 +82,11 @@ class AttnTimer:
         if not big:
             return None
         t, f, fx, fe = sum(x[0] for x in big), sum(x[1] for x in big), sum(x[2] for x in big), sum(x[3] for x in big)
+        fused = [x for x in big if x[4] == 5]
+        tf = sum(x[0] for x in fused)
         return dict(launches=len(big), avg_ms=1e3 * t / len(big), tflops_dense=f / t / 1e12, tflops=fx / t / 1e12, tflops_executed=fe / t / 1e12,
-                    total_ms=1e3 * t, fused_launches=sum(1 for x in big if x[4] == 5))
+                    total_ms=1e3 * t, fused_launches=len(fused), fused_avg_ms=(1e3 * tf / len(fused)) if fused else None,
+                    fused_tflops=(sum(x[2] for x in fused) / tf / 1e12) if fused else None)
 
     def summary_fwd(self):
         return self._summary(self.fwd, 2)
@@ -423,10 +426,13 @@ def main():
                      "bound": "mfma", "achieved": att_b["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": att_b["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic.get("attn_bwd"),
                      "launches": att_b["launches"], "fused_5_product_launches": att_b["fused_launches"], "avg_launch_ms": att_b["avg_ms"],
+                     "fused_avg_launch_ms": att_b["fused_avg_ms"], "fused_achieved": att_b["fused_tflops"],
                      "ms_per_step": att_b["total_ms"] / args.steps, "achieved_executed": att_b["tflops_executed"],
                      "note": "achieved = ALGORITHMIC backward FLOPs over the visible keys (5 products: 10*12*64*L*sum_b(visible keys) per "
                              "launch) / HIP-event time around ops.attn_bwd; achieved_executed counts the products the kernels really "
-                             "run (7 per (query, key) pair in the two-kernel form, which recomputes S and dP; 5 in the fused form)"}
+                             "run (7 per (query, key) pair in the two-kernel form, which recomputes S and dP; 5 in the fused form); "
+                             "fused_avg_launch_ms / fused_achieved: the launches that took the fused form alone (their group in a rocprofv3 "
+                             "kernel trace: attn_delta_prep + attn_bwd_fused<.,0,.> + attn_bwd_fused<.,1,.> + attn_dq_cast)"}
     # `roofline` = the dominant kernel group of the step (the attention backward in a train step, the forward otherwise)
     if bwd_block is not None:
         res["roofline"], res["roofline_fwd"] = bwd_block, fwd_block

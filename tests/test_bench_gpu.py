@@ -1,0 +1,52 @@
+"""bench.py's one-line JSON contract, on a small configuration (BASELINE configs[0]-sized: B=2, 20 frames x 30 OCR): the keys the
+driver reads, the roofline / cpu_baseline objects, null traffic for a configuration profiles/traffic.json does not hold."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "2", "--frames", "20", "--ocr", "30", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"] + list(extra)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_train_step():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "samples/s" and d["data"] == "synthetic" and d["dtype"] == "bf16" and d["vs_baseline"] is None
+    assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]            # value = samples of the K steps / their time
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["global_batch"] == 2
+    assert "configs[" not in d["config"]["workload"]                                           # not one of BASELINE's named shapes
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert r["traffic"] is None                                                               # measured for the B=64 100x100 configuration only
+    assert "dropout_0" in d and d["dropout_0"]["ms_per_step"] > 0
+    assert "cpu_baseline" not in d                                                            # --no-cpu-baseline
+
+
+def test_bench_line_contract_forward_only():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run("--forward-only")
+    assert "forward" in d["config"]["workload"] and "loss" not in d
+    assert d["roofline"]["bound"] == "mfma" and "roofline_fwd" not in d
