@@ -251,7 +251,10 @@ class PrevPredEmbeddings(nn.Module):
         self.ocr_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
         self.emb_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
 
-    def forward(self, ans_emb, ocr_emb, prev_inds, dtype, emb_dropout=0.0):
+    def forward(self, ans_emb, ocr_emb, prev_inds, dtype, emb_dropout=0.0, draws=None):
+        """``draws`` = n: a list of n results that share the gathered rows and differ in the dropout draw of the position /
+        type embedding only - the three MMT passes of a train step call this with the same inputs (t2s.py:293-313), and each
+        separate call costs a [B, N, 768] zero fill + scatter + accumulation in the backward of its OCR-row gather."""
         # LayerNorm is row-wise, so LN(table)[gather] == LN(table[gather]): only the 12 gathered rows per
         # sample are normalised instead of the whole [V, 768] table + [B, N, 768] OCR tensor (t2s.py:702-709).
         B, D = prev_inds.shape
@@ -265,6 +268,8 @@ class PrevPredEmbeddings(nn.Module):
         raw = torch.where(is_ocr.unsqueeze(-1), ocr_n, ans_n)
         emb = self.position_embeddings.weight[:D].unsqueeze(0) + self.token_type_embeddings(is_ocr.long())
         emb = FN.layer_norm(emb, self.emb_layer_norm.weight, self.emb_layer_norm.bias)
+        if draws is not None:
+            return [raw + (F.dropout(emb, emb_dropout, True) if emb_dropout > 0 else emb) for _ in range(draws)]
         if emb_dropout > 0:
             emb = F.dropout(emb, emb_dropout, True)         # emb_dropout, t2s.py:720
         return raw + emb
@@ -304,7 +309,7 @@ class MMT(nn.Module):
         pd, pa = _train_dropout(self)
         T, Fn, N = txt_emb.size(1), obj_emb.size(1), ocr_emb.size(1)
         L1 = T + Fn + N
-        decs = [self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd) for _ in obj_masks]
+        decs = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd, draws=len(obj_masks))
         D = decs[0].size(1)
         x = torch.cat([txt_emb, obj_emb, ocr_emb] + decs, dim=1)
         keys = []
