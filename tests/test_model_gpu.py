@@ -315,6 +315,39 @@ def test_shared_prefix_passes_equal_separate_passes(dtype, tol_s, tol_g):
             assert d <= tol_g * g.double().norm().item() + 1e-3 * tot, (n, d, g.double().norm().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_recompute_form_gives_the_same_gradients(dtype):
+    """functional.RECOMPUTE_ACTIVATIONS (the GELU output and the LN1 operand copy rebuilt in backward instead of stored - what
+    bench.py's memory guard switches to on a card without the room) runs the same kernels on the same inputs: same scores, same
+    gradients (scores bit for bit; these shapes take the atomics-free attention backward)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import vitxt_gqa_amd.functional as FNmod
+    from vitxt_gqa_amd.synth import make_batch, make_noise
+    from vitxt_gqa_amd.testing import make_model, to_device
+    F, P, V, B = 7, 9, 40, 3
+    model = make_model(F, P, V, text_vocab=50, dtype=dtype, attn_gain=4.0).to(DEV).train()
+    s = to_device(make_batch(B, F, P, V=V, seed=4, text_vocab=50), DEV)
+    s.grounding_noise = tuple(t.to(DEV) for t in make_noise(B, F, P, seed=4))
+    res = {}
+    try:
+        for mode in (False, True):
+            FNmod.RECOMPUTE_ACTIVATIONS = mode
+            model.zero_grad(set_to_none=True)
+            out = model(s)
+            sum(l.mean() for l in out["losses"].values()).backward()
+            res[mode] = ({k: out[k].detach().clone() for k in ("ref_scores", "pos_scores", "neg_scores")},
+                         {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        FNmod.RECOMPUTE_ACTIVATIONS = False
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    assert res[False][1].keys() == res[True][1].keys()
+    for n, g in res[False][1].items():      # (embedding-table gradients are scatter-adds with float atomics: equal up to their order)
+        d = (g.double() - res[True][1][n].double()).abs().max().item()
+        assert d <= 1e-5 * max(1.0, g.abs().max().item()), (n, d)
+
+
 def test_model_call_appends_metrics_from_the_config_list():
     """BaseModel.__call__ (base_model.py:119-149) appends ``metrics`` computed from the model's own outputs by the evaluators the
     yml lists: here textvqa_accuracy / stvqa_anls on the tiny fixture, against a direct evaluation of the same decoded answers."""
