@@ -274,10 +274,13 @@ def prev_pred_embeddings(sd, ans_emb, ocr_emb, prev_inds):
     return raw + emb
 
 
-def mmt(sd, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, prev_inds):
-    """MMT.forward t2s.py:556-633: [q;frames;ocr;dec], prefix-LM mask (Q4)."""
+def mmt(sd, txt_emb, txt_mask, obj_emb, obj_mask, ocr_emb, ocr_mask, prev_inds, keep=None):
+    """MMT.forward t2s.py:556-633: [q;frames;ocr;dec], prefix-LM mask (Q4).  ``keep``: optional dict that receives the
+    decoder-step embeddings (``dec_emb``)."""
     dt = txt_emb.dtype
     dec = prev_pred_embeddings(sd, sd["classifier.module.weight"], ocr_emb, prev_inds)
+    if keep is not None:
+        keep["dec_emb"] = dec
     B, D = prev_inds.shape
     x = torch.cat([txt_emb, obj_emb, ocr_emb, dec], dim=1)
     m = torch.cat([txt_mask.to(dt), obj_mask.to(dt), ocr_mask.to(dt), torch.zeros(B, D, dtype=dt)], dim=1)
@@ -336,6 +339,15 @@ def t2s_forward(sd: Dict[str, torch.Tensor], s: dict, cfg: dict, training: bool 
                       cfg["frame_topk"], cfg["ocr_topk"], cfg["frame_num"], cfg["ocr_frame_num"])
     if inject_masks is not None:
         g.update({k: v for k, v in inject_masks.items()})
+        # the outputs the reference derives from its masks follow the injected ones (spatio_temporal_grounding.py:65-66:
+        # frame ids at the nonzero positions of the pos frame mask, ascending; :139-140: boxes under the pos OCR mask)
+        if "ground_frame" not in inject_masks and "pos_obj_mask" in inject_masks:
+            pf = torch.nonzero(g["pos_obj_mask"], as_tuple=False)[:, 1].view(obj_in.size(0), -1)
+            g["ground_frame"] = torch.gather(s["frame_id"], 1, pf)
+        if "ground_box" not in inject_masks and "pos_ocr_mask" in inject_masks:
+            B_ = ocr_in.size(0)
+            g["ground_box"] = torch.masked_select(s["ocr_bbox_coordinates"],
+                                                  g["pos_ocr_mask"].unsqueeze(-1).expand(B_, -1, 4).bool()).view(B_, -1, 4)
     inter.update(g)
 
     def three_pass(prev_inds):
@@ -343,8 +355,10 @@ def t2s_forward(sd: Dict[str, torch.Tensor], s: dict, cfg: dict, training: bool 
         for name, om, cm in (("ref", obj_mask, ocr_mask),
                              ("pos", g["pos_obj_mask"], g["pos_ocr_mask"]),
                              ("neg", g["neg_obj_mask"], g["neg_ocr_mask"])):
-            ocr_out, dec_out = mmt(sd, txt_emb, txt_mask, obj_in, om, ocr_in, cm, prev_inds)
+            kp = {}
+            ocr_out, dec_out = mmt(sd, txt_emb, txt_mask, obj_in, om, ocr_in, cm, prev_inds, keep=kp)
             out[name + "_scores"] = forward_output(sd, ocr_out, dec_out, cm)
+            inter[name + "_mmt_ocr"], inter[name + "_mmt_dec"], inter[name + "_dec_emb"] = ocr_out, dec_out, kp["dec_emb"]
         return out
 
     if training:

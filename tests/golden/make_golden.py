@@ -99,7 +99,7 @@ def build_reference(F_, P, V, text_vocab):
     return m
 
 
-def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs):
+def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs, gains=None, ocr_prev_frac=0.0):
     from vitxt_gqa_amd.schema import state_dict_schema
     from vitxt_gqa_amd.init import make_state_dict, fingerprint
     from vitxt_gqa_amd.synth import make_batch
@@ -111,10 +111,10 @@ def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs):
     assert list(ref_sd.keys()) == list(schema.keys()), "schema key order mismatch"
     for k, v in ref_sd.items():
         assert tuple(v.shape) == tuple(schema[k]), (k, v.shape, schema[k])
-    sd = make_state_dict(schema, seed=seed, attn_gain=attn_gain)
+    sd = make_state_dict(schema, seed=seed, attn_gain=attn_gain, gains=gains)
     m.load_state_dict(sd)
 
-    batch = make_batch(B, F_, P, V=V, seed=seed, text_vocab=text_vocab)
+    batch = make_batch(B, F_, P, V=V, seed=seed, text_vocab=text_vocab, ocr_prev_frac=ocr_prev_frac)
     sl = AD(batch)
     sl.dataset_name, sl.dataset_type = "vtextgqa", "train"
 
@@ -230,6 +230,10 @@ def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs):
     res["eval_ref_scores"] = eo["ref_scores"]
     res["eval_neg_scores"] = eo["neg_scores"]
     res["eval_argmax"] = eo["pos_scores"].argmax(-1)
+    # decoder-step embeddings of the LAST greedy step (ref pass): built from the indices the loop itself fed back
+    # (t2s.py:315-354), OCR copies included when the pointer head wins steps
+    res["eval_dec_emb_last"] = dec_embs[-3]
+    res["eval_ground_box"], res["eval_ground_frame"] = eo["ground_box"], eo["ground_frame"]
     for k in ("pos_obj_mask", "neg_obj_mask", "pos_ocr_mask", "neg_ocr_mask"):
         res["eval_" + k] = cap[k]
 
@@ -239,7 +243,7 @@ def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs):
     t2s_mod.QTV.forward = orig_qtv
 
     meta = dict(name=name, B=B, F=F_, P=P, V=V, text_vocab=text_vocab, seed=seed, attn_gain=attn_gain,
-                noise_seed=noise_seed, grad_names=gnames,
+                gains=gains or {}, ocr_prev_frac=ocr_prev_frac, noise_seed=noise_seed, grad_names=gnames,
                 weight_fingerprint=fingerprint(sd, ["mmt.encoder.layer.0.attention.self.query.weight",
                                                     "classifier.module.weight", "ocr_ptr_net.key.bias",
                                                     "frame_embeddings.weight"]),
@@ -275,6 +279,11 @@ def main():
     # BASELINE.json configs[0]: batch=2, 20 frames x 30 OCR tokens per frame (N=600), reference init std
     keys, shapes = run_case("cfg1_b2_f20_p30", B=2, F_=20, P=30, V=1000, text_vocab=30522, seed=11,
                             attn_gain=1.0, store_inputs=False)
+    # pointer-competition case: half of the teacher-forced previous indices are OCR copies (>= V), the
+    # pointer projections are scaled up and the vocabulary head down until the reference's own greedy decode walks through
+    # OCR tokens and vocabulary tokens alike and several decoding rows are near-ties (top-2 gap < 0.05)
+    run_case("ptr_b3_f8_p10", B=3, F_=8, P=10, V=48, text_vocab=1000, seed=5, attn_gain=3.0, store_inputs=True,
+             gains={"ocr_ptr_net.": 4.0, "classifier.module.weight": 0.3}, ocr_prev_frac=0.5)
     # checkpoint schema at the real vocabulary sizes (names/order/shapes, Appendix D)
     from vitxt_gqa_amd.schema import state_dict_schema
     json.dump({"keys": keys, "note": "reference T2S.state_dict() key order; shapes at V=1000, text_vocab=30522",

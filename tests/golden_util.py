@@ -28,7 +28,7 @@ class Fixture:
     def state_dict(self, dtype=torch.float32):
         m = self.meta
         sd = make_state_dict(state_dict_schema(m["V"], text_vocab=m["text_vocab"]), seed=m["seed"],
-                             attn_gain=m["attn_gain"])
+                             attn_gain=m["attn_gain"], gains=m.get("gains") or None)
         fp = fingerprint(sd, list(m["weight_fingerprint"]))
         for k, v in m["weight_fingerprint"].items():
             assert np.allclose(fp[k], v, rtol=1e-9, atol=1e-9), \
@@ -39,7 +39,8 @@ class Fixture:
         m = self.meta
         if "in:text" in self.arr:
             return {k[3:]: v for k, v in self.arr.items() if k.startswith("in:")}
-        b = make_batch(m["B"], m["F"], m["P"], V=m["V"], seed=m["seed"], text_vocab=m["text_vocab"])
+        b = make_batch(m["B"], m["F"], m["P"], V=m["V"], seed=m["seed"], text_vocab=m["text_vocab"],
+                       ocr_prev_frac=m.get("ocr_prev_frac", 0.0))
         for k, v in m["input_fingerprint"].items():
             assert abs(float(b[k].double().sum()) - v) <= 1e-6 * max(1.0, abs(v)), \
                 "synthetic input generator mismatch for %s" % k

@@ -224,3 +224,69 @@ def test_attn_bwd_fill_equals_zero_fill_path_full_length():
     sc = a.float().abs().max().item()
     assert (fa[..., :768].float() - fb[..., :768].float()).abs().max().item() < 1e-2 * sc
     assert (fa.float() - a.float()).abs().max().item() < 3e-2 * sc
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_attention_bwd_fused_full_length_against_fp64_heads(drop_p):
+    """The fused five-product backward at the benchmark's length (L = 10 132: 27 key blocks of 384, 70 % of the prefix keys
+    visible, 12 decoder keys) against the fp64 gradient of whole heads: dQ of EVERY query over all keys, dK / dV of EVERY key over
+    all queries, for two (sample, head) pairs, both fill paths (rows outside the key list zeroed in the call / by the caller),
+    with and without attention dropout (the exported keep mask, indexed by key-LIST position, enters the fp64 restatement)."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    B = 1
+    keys, valid = _keys_and_mask(B, [0.7], seed=11)
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    kw = dict(drop_p=drop_p, drop_seed=991) if drop_p else {}
+    out, lse = ops.attn_fwd(x, keys, **kw)
+    cnt = int(keys.cnt[0])
+    npos = cnt + D
+    rows_of_pos = keys.idx[0, :npos].long()
+    assert torch.equal(rows_of_pos[cnt:], torch.arange(L1, L, device=DEV))            # the decoder keys close the list
+    vis = torch.zeros(L, L, dtype=torch.bool, device=DEV)
+    vis[:, :L1] = valid[0]
+    r = torch.arange(L, device=DEV)
+    vis[:, L1:] = (r.view(-1, 1) - L1) >= torch.arange(D, device=DEV).view(1, -1)
+    p_eff = round(65536 * drop_p) / 65536
+    keep_all = ops.attn_dropout_mask(B, L, npos, drop_p, kw["drop_seed"], DEV) if drop_p else None     # [1, 12, L, npos]
+    results = []
+    for kl in (keys, ops.KeyList(keys.idx, keys.cnt, keys.n_dec, keys.dec_q0, None, None)):
+        results.append(ops.attn_bwd(x, out, dout, lse, kl, fused=True, **kw))
+        assert ops.LAST_ATTN_BWD_PRODUCTS == 5
+    for h in (3, 10):
+        q, k, v = [x[0, :, c * 768 + h * 64:c * 768 + (h + 1) * 64].double() for c in range(3)]     # [L, 64]
+        do = dout[0, :, h * 64:(h + 1) * 64].double()
+        sc = (q @ k.t()) * 0.125
+        sc.masked_fill_(~vis, float("-inf"))
+        pr = torch.softmax(sc, -1)
+        del sc
+        if keep_all is not None:
+            m = torch.zeros(L, L, dtype=torch.float64, device=DEV)
+            m[:, rows_of_pos] = keep_all[0, h].double() / (1.0 - p_eff)
+        else:
+            m = None
+        a = pr * m if m is not None else pr
+        o = a @ v
+        dv = a.t() @ do
+        dp = do @ v.t()
+        if m is not None:
+            dp = dp * m
+        delta = (do * o).sum(-1, keepdim=True)
+        ds = pr * (dp - delta)
+        del dp, a
+        dq = (ds @ k) * 0.125
+        dk = (ds.t() @ q) * 0.125
+        del ds, pr, m
+        # the forward the kernel's delta comes from is this head too
+        assert (out[0, :, h * 64:(h + 1) * 64].double() - o).abs().max().item() < 3e-2
+        for got in results:
+            gq, gk, gv = [got[0, :, c * 768 + h * 64:c * 768 + (h + 1) * 64].double() for c in range(3)]
+            for name, gg, rr in (("dQ", gq, dq), ("dK", gk, dk), ("dV", gv, dv)):
+                err = (gg - rr).abs().max().item()
+                rel = (gg - rr).norm().item() / rr.norm().item()
+                assert err < 3e-2 * max(1.0, rr.abs().max().item()) and rel < 2e-2, \
+                    "head %d %s (dropout %g): max err %.3e at scale %.3e, relative L2 %.3e" % (h, name, drop_p, err, rr.abs().max().item(), rel)
+            inv = ~valid[0]
+            assert gk[:L1][inv].abs().max().item() == 0 and gv[:L1][inv].abs().max().item() == 0

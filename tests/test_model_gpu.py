@@ -10,10 +10,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+ALL_CASES = ["tiny_b2_f6_p8", "cfg1_b2_f20_p30", "ptr_b3_f8_p10"]
+
+
 def _run(fx, dtype, train=True, inject=True):
     from vitxt_gqa_amd.testing import build_model_for_fixture, to_device
     model = build_model_for_fixture(fx, dtype).to(DEV)
     model.train(train)
+    model.keep_intermediates = True
     s = to_device(fx.batch(), DEV)
     s.grounding_noise = (fx["E1"], fx["E2"])
     if inject:
@@ -21,7 +25,7 @@ def _run(fx, dtype, train=True, inject=True):
     return model, s
 
 
-@pytest.mark.parametrize("case", ["tiny_b2_f6_p8", "cfg1_b2_f20_p30"])
+@pytest.mark.parametrize("case", ALL_CASES)
 def test_forward_fp32_matches_reference(case):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -37,6 +41,27 @@ def test_forward_fp32_matches_reference(case):
     assert (f["ocr_mmt_in"].float().cpu()[:, ::st] - fx["ocr_in"]).abs().max().item() < 1e-3
     assert (f["frame_score"].cpu() - fx["frame_score"]).abs().max().item() < 1e-4
     assert torch.equal(out["frame_topk"].cpu(), fx["frame_topk"]) and torch.equal(out["ocr_topk"].cpu(), fx["ocr_topk"])
+    # every intermediate the reference fixture stores (tests/golden/make_golden.py): the encodings before QTV, the pooled
+    # question, the decoder-step embeddings (the ptr case feeds OCR copies: prev_inds >= V, OCR-row gather + type embedding 1,
+    # t2s.py:690-723), the MMT outputs of the three passes, and - masks injected - the outputs derived from them, EQUAL
+    cpu = lambda t: t.float().cpu()
+    assert (cpu(f["txt_emb0"]) - fx["txt_emb0"]).abs().max().item() < 1e-3
+    assert (cpu(f["obj_in0"]) - fx["obj_in0"]).abs().max().item() < 1e-3
+    assert (cpu(f["ocr_in0"])[:, ::st] - fx["ocr_in0"]).abs().max().item() < 1e-3
+    assert (cpu(f["obj_mmt_in"]) - fx["obj_in"]).abs().max().item() < 1e-3
+    assert (cpu(f["global_q"]) - fx["global_q"].view(fx.B, -1)).abs().max().item() < 1e-3
+    assert (cpu(f["ref_dec_emb"]) - fx["dec_emb"]).abs().max().item() < 1e-4
+    assert (cpu(f["ref_mmt_ocr"])[:, ::st] - fx["ref_mmt_ocr"]).abs().max().item() < 1e-3
+    for p in ("ref", "pos", "neg"):
+        assert (cpu(f[p + "_mmt_dec"]) - fx[p + "_mmt_dec"]).abs().max().item() < 1e-3, p
+    assert torch.equal(out["ground_frame"].cpu(), fx["ground_frame"])
+    assert torch.equal(out["ground_box"].cpu(), fx["ground_box"])
+    # the spatial scorer runs on the build's OWN grounded frames: comparable where those are the reference's (tie-free samples)
+    same = (f["new_ocr_mask"].cpu().float() == fx["new_ocr_mask"].float()).all(-1)
+    if same.any():
+        assert (f["ocr_score"].cpu()[same] - fx["ocr_score"][same]).abs().max().item() < 1e-4
+    if case == "ptr_b3_f8_p10":
+        assert same.any() and (s.train_prev_inds >= fx.V).float().mean().item() > 0.3
     # losses through BaseModel.__call__ (base_model.py:119-149) with the yml weights
     losses = out["losses"]
     assert set(losses) == {"train/vtextgqa/pos_bce_loss", "train/vtextgqa/InfoNCE"}
@@ -44,19 +69,37 @@ def test_forward_fp32_matches_reference(case):
     assert abs(losses["train/vtextgqa/InfoNCE"].item() / 1000 - fx["loss_nce"].item()) < 2e-4
 
 
-def test_forward_bf16_cfg1():
+# bf16 logit tolerance: the north star's 1e-2 holds for reference-std weights (cfg1).  The ptr fixture scales the pointer
+# projections by 4 (pointer logits x16, |logit| up to ~6) and the attention projections by 3, so its bf16 error is bounded
+# relative to that scale: 4e-2 absolute, stated here and asserted.
+BF16_TOL = {"cfg1_b2_f20_p30": 1e-2, "ptr_b3_f8_p10": 4e-2}
+
+
+@pytest.mark.parametrize("case", ["cfg1_b2_f20_p30", "ptr_b3_f8_p10"])
+def test_forward_bf16(case):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    fx = Fixture("cfg1_b2_f20_p30")
+    fx = Fixture(case)
     model, s = _run(fx, torch.bfloat16)
     out = model(s)
+    tol = BF16_TOL[case]
+    total = 0
     for k in ("ref_scores", "pos_scores", "neg_scores"):
         err = (out[k].float().cpu() - fx[k]).abs().max().item()
-        assert err < 1e-2, "%s max abs err %.3e" % (k, err)
+        assert err < tol, "%s max abs err %.3e" % (k, err)
         # pointer / copy indices (north star: bit-exact): the argmax of every decoding row equals the reference's wherever the
-        # reference's own top-2 logit gap exceeds what two logits within the bf16 tolerance (1e-2 each) can close
-        flips = _index_flips(out[k].float().cpu(), fx[k], 2e-2)
-        print("%s: %d of %d argmax indices differ, all inside the bf16 tolerance" % (k, flips, fx[k].shape[0] * fx[k].shape[1]))
+        # reference's own top-2 logit gap exceeds what two logits within the bf16 tolerance can close; the NUMBER of rows that
+        # differ is bounded by the number of such near-tie rows of the reference (asserted: a deviation from bit-exact stated as a count)
+        flips = _index_flips(out[k].float().cpu(), fx[k], 2 * tol)
+        t2 = fx[k].topk(2, -1).values
+        near = int(((t2[..., 0] - t2[..., 1]) < 2 * tol).sum())
+        assert flips <= near
+        total += flips
+        print("%s %s: %d of %d argmax indices differ (reference rows with a top-2 gap < %g: %d)" % (
+            case, k, flips, fx[k].shape[0] * fx[k].shape[1], 2 * tol, near))
+    if case == "ptr_b3_f8_p10":      # teacher-forced rows of this fixture: the winners are OCR tokens AND vocabulary tokens
+        am = fx["pos_scores"].argmax(-1)
+        assert (am >= fx.V).any() and (am < fx.V).any()
 
 
 def _index_flips(got, want, tol):
@@ -91,10 +134,13 @@ def test_own_selection_matches_reference_where_tie_free():
     assert out["ground_box"].shape == (fx.B, 5 * fx.F, 4)
 
 
-def test_gradients_fp32_match_reference():
+@pytest.mark.parametrize("case", ["tiny_b2_f6_p8", "ptr_b3_f8_p10"])
+def test_gradients_fp32_match_reference(case):
+    """ptr case: half of the decoder-step embeddings are OCR copies, so the gradient reaches the OCR rows through the gather of
+    PrevPredEmbeddings (t2s.py:702-709) as well as through the encoder."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    fx = Fixture("tiny_b2_f6_p8")
+    fx = Fixture(case)
     model, s = _run(fx, torch.float32)
     out = model(s)
     loss = sum(v.mean() for v in out["losses"].values())            # base_trainer.py:274-278
@@ -117,18 +163,81 @@ def test_gradients_fp32_match_reference():
             assert (g.float().cpu() - v).abs().max().item() < 5e-3 * sc + 1e-7 * total, k
 
 
-def test_eval_greedy_decode_indices_exact():
+@pytest.mark.parametrize("fused_everywhere", [True, False])
+def test_gradients_bf16_cfg1_match_reference(fused_everywhere, monkeypatch):
+    """Model-level bf16 gradient parity against the REFERENCE's fixture (cfg1: batch 2, 20 frames x 30 OCR, reference-std
+    weights): every parameter-gradient norm within 3 %, the total norm within 1 %.  ``fused_everywhere``: the five-product
+    fused attention backward (the benchmark's dominant kernel) takes EVERY launch (ops.ATTN_BWD_FUSED_MIN_KEYS = 0; by default
+    only launches with >= 2048 keys use it, and the fixtures have L <= 652)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    fx = Fixture("tiny_b2_f6_p8")
+    from vitxt_gqa_amd import ops
+    if fused_everywhere:
+        monkeypatch.setattr(ops, "ATTN_BWD_FUSED_MIN_KEYS", 0)
+        monkeypatch.setattr(ops, "ATTN_BWD_FUSED", True)
+    fx = Fixture("cfg1_b2_f20_p30")
+    model, s = _run(fx, torch.bfloat16)
+    out = model(s)
+    loss = sum(v.mean() for v in out["losses"].values())
+    assert abs(loss.item() - fx["loss_total"].item()) < 5e-3 * fx["loss_total"].item()
+    seen = []
+    orig = ops.attn_bwd
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        seen.append(ops.LAST_ATTN_BWD_PRODUCTS)
+        return r
+
+    monkeypatch.setattr(ops, "attn_bwd", spy)
+    loss.backward()
+    if fused_everywhere:
+        assert seen and all(p == 5 for p in seen[3:]), seen        # the 3 TextBert layers (L = 20) included or not: all MMT / QTV launches fused
+    params = dict(model.named_parameters())
+    names, ref, total = fx.meta["grad_names"], fx["grad_norms"], fx["grad_total_norm"].item()
+    assert {n for n, p in params.items() if p.grad is not None} == set(names)
+    worst = (0.0, "")
+    sq = 0.0
+    for n, r in zip(names, ref.tolist()):
+        g = params[n].grad.double().norm().item()
+        sq += g * g
+        # key-bias gradients are mathematically zero (softmax shift invariance): rounding noise on both sides, hence the floor
+        rel = abs(g - r) / (r + 1e-4 * total)
+        worst = max(worst, (rel, n))
+        assert rel < 3e-2, "%s grad norm %g vs reference %g" % (n, g, r)
+    assert abs(sq ** 0.5 - total) < 1e-2 * total, (sq ** 0.5, total)
+    for k, v in fx.arr.items():            # the stored gradient tensors themselves
+        if k.startswith("grad:"):
+            n = k[5:]
+            g = params[n[:-1].split("[:")[0]].grad[:int(n[:-1].split("[:")[1])] if n.endswith("]") else params[n].grad
+            d = (g.float().cpu() - v).norm().item()
+            assert d < 3e-2 * v.norm().item() + 1e-5 * total, (k, d, v.norm().item())
+    print("bf16 gradient norms vs reference (fused everywhere: %s): worst %.3f %% (%s), total %.4f %%" % (
+        fused_everywhere, 100 * worst[0], worst[1], 100 * abs(sq ** 0.5 - total) / total))
+
+
+@pytest.mark.parametrize("case", ["tiny_b2_f6_p8", "ptr_b3_f8_p10"])
+def test_eval_greedy_decode_indices_exact(case):
+    """fp32 mode: the greedy decode's indices are the reference's, bit-exact.  In the ptr case the reference's own sequence
+    walks through OCR tokens (83 % of the steps) and vocabulary tokens, 4 of its 36 rows have a top-2 gap below 0.05, and every
+    index it picks is fed back through the OCR-copy branch of the decoder-step embeddings (t2s.py:315-354, 690-723)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fx = Fixture(case)
     model, s = _run(fx, torch.float32, train=False)
     with torch.no_grad():
         out = model(s)
-    assert (out["pos_scores"].cpu() - fx["eval_pos_scores"]).abs().max().item() < 1e-3
+    for k in ("ref", "pos", "neg"):
+        assert (out[k + "_scores"].cpu() - fx["eval_%s_scores" % k]).abs().max().item() < 1e-3, k
     assert torch.equal(out["pos_scores"].argmax(-1).cpu(), fx["eval_argmax"])
+    f = model._last_fwd
+    assert torch.equal(f["prev_inds"][:, 1:].cpu(), fx["eval_argmax"][:, :-1])
+    assert (f["dec_emb_last"].float().cpu() - fx["eval_dec_emb_last"]).abs().max().item() < 1e-4
+    assert torch.equal(out["ground_frame"].cpu(), fx["eval_ground_frame"])
+    assert torch.equal(out["ground_box"].cpu(), fx["eval_ground_box"])
 
 
-@pytest.mark.parametrize("case,dtype,tol", [("tiny_b2_f6_p8", torch.float32, 1e-3), ("cfg1_b2_f20_p30", torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("case,dtype,tol", [("tiny_b2_f6_p8", torch.float32, 1e-3), ("cfg1_b2_f20_p30", torch.bfloat16, 1e-2),
+                                            ("ptr_b3_f8_p10", torch.float32, 1e-3), ("ptr_b3_f8_p10", torch.bfloat16, 4e-2)])
 def test_cached_decode_equals_reference_loop(case, dtype, tol):
     """Prefix-reuse greedy decoding == the reference's recompute-everything loop (same scores, same indices)."""
     if not torch.cuda.is_available():
@@ -142,13 +251,24 @@ def test_cached_decode_equals_reference_loop(case, dtype, tol):
         model.decode_with_prefix_cache = False
         b = model(s)
         pb = model._last_fwd["prev_inds"].clone()
-    for k in ("ref_scores", "pos_scores", "neg_scores"):
-        assert (a[k] - b[k]).abs().max().item() < (1e-4 if dtype == torch.float32 else 2e-2), k
-        assert (a[k].cpu() - fx["eval_" + k]).abs().max().item() < tol, k
     if dtype == torch.float32:
+        for k in ("ref_scores", "pos_scores", "neg_scores"):
+            assert (a[k] - b[k]).abs().max().item() < 1e-4, k
+            assert (a[k].cpu() - fx["eval_" + k]).abs().max().item() < tol, k
         assert torch.equal(pa, pb)
         assert torch.equal(a["pos_scores"].argmax(-1).cpu(), fx["eval_argmax"])
     else:
+        # Row t of the final scores was computed from the fed tokens 0..t (causal decoder): rows are comparable between two runs
+        # up to each sample's first differing fed token; later rows were fed another token.
+        def comparable(fed_a, fed_b):
+            return (fed_a.cpu() == fed_b.cpu()).long().cumprod(1).bool()
+
+        fed_ref = torch.cat([torch.full_like(fx["eval_argmax"][:, :1], 1), fx["eval_argmax"][:, :-1]], 1)      # BOS, then the reference's picks
+        for k in ("ref_scores", "pos_scores", "neg_scores"):
+            d = (a[k] - b[k]).abs().amax(-1).cpu()
+            assert d[comparable(pa, pb)].max().item() < 2 * tol, ("cached vs loop", k)
+            d = (a[k].cpu() - fx["eval_" + k]).abs().amax(-1)
+            assert d[comparable(pa, fed_ref)].max().item() < tol, ("cached vs reference", k)
         # bf16 operands (the throughput dtype): greedy-decode indices against the reference's, step by step.  Row t of the
         # final scores is the logit row that decided step t (causal decoder), so up to a sample's FIRST differing step the
         # rows are comparable: every earlier index must be equal, and the differing one must be a near-tie of the reference
@@ -162,10 +282,15 @@ def test_cached_decode_equals_reference_loop(case, dtype, tol):
             diff = (got[b_] != want[b_]).nonzero().flatten()
             if diff.numel():
                 t = int(diff[0])
-                assert gap[b_, t].item() < 2e-2, "sample %d step %d: index %d vs %d at reference gap %.3e" % (
+                assert gap[b_, t].item() < 2 * tol, "sample %d step %d: index %d vs %d at reference gap %.3e" % (
                     b_, t, int(got[b_, t]), int(want[b_, t]), gap[b_, t].item())
                 flipped += 1
-        print("bf16 greedy decode: %d of %d samples leave the reference's index sequence (at a near-tie)" % (flipped, got.shape[0]))
+        # the deviation from "bit-exact" as a number: samples that leave the reference's sequence <= samples whose reference
+        # sequence contains a near-tie row at all
+        near = int(((gap < 2 * tol).any(-1)).sum())
+        assert flipped <= near
+        print("bf16 greedy decode (%s): %d of %d samples leave the reference's index sequence, each at a near-tie (samples with a near-tie row: %d)"
+              % (case, flipped, got.shape[0], near))
 
 
 @pytest.mark.parametrize("B,F,P,V", [(1, 5, 5, 11), (3, 7, 9, 40), (2, 33, 6, 300), (2, 12, 1, 30), (2, 9, 3, 30)])

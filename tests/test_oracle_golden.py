@@ -7,7 +7,7 @@ import torch
 from golden_util import Fixture
 from oracle import t2s_oracle as O
 
-CASES = ["tiny_b2_f6_p8", "cfg1_b2_f20_p30"]
+CASES = ["tiny_b2_f6_p8", "cfg1_b2_f20_p30", "ptr_b3_f8_p10"]
 
 
 def _close(a, b, atol, rtol=1e-4, what=""):
@@ -39,6 +39,15 @@ def test_intermediates(run):
     _close(it["txt_emb"], fx["txt_emb"], 5e-5, what="qtv txt")
     _close(it["obj_in"], fx["obj_in"], 5e-5, what="qtv obj")
     _close(it["ocr_in"][:, ::st], fx["ocr_in"], 5e-5, what="qtv ocr")
+    # decoder-step embeddings (PrevPredEmbeddings, t2s.py:690-723; the ptr case feeds OCR copies, prev_inds >= V, through the
+    # OCR-row gather + type embedding 1) and the MMT outputs of the three passes (t2s.py:556-633)
+    _close(it["ref_dec_emb"], fx["dec_emb"], 2e-5, what="dec_emb")
+    _close(it["ref_mmt_ocr"][:, ::st], fx["ref_mmt_ocr"], 1e-4, what="ref_mmt_ocr")
+    for p in ("ref", "pos", "neg"):
+        _close(it[p + "_mmt_dec"], fx[p + "_mmt_dec"], 1e-4, what=p + "_mmt_dec")
+    # outputs derived from the (injected) masks: EQUAL
+    assert torch.equal(res["ground_frame"], fx["ground_frame"])
+    assert torch.equal(res["ground_box"].float(), fx["ground_box"])
 
 
 def test_grounding_scores_and_selection(run):
@@ -150,13 +159,35 @@ def test_adam_step():
             _close(sd[k[6:]].detach()[:8], v, atol=2e-6, rtol=1e-5, what=k)
 
 
-def test_eval_greedy_decode():
-    fx = Fixture("tiny_b2_f6_p8")
+@pytest.mark.parametrize("case", ["tiny_b2_f6_p8", "ptr_b3_f8_p10"])
+def test_eval_greedy_decode(case):
+    fx = Fixture(case)
     sd = fx.state_dict(torch.float64)
     s = {k: (v.double() if v.is_floating_point() else v) for k, v in fx.batch().items()}
     with torch.no_grad():
         res = O.t2s_forward(sd, s, fx.cfg, training=False, expo_frame=fx["E1"].double(), expo_ocr=fx["E2"].double(),
-                            inject_masks={k: v.double() for k, v in fx.masks("eval_").items()})
-    _close(res["pos_scores"], fx["eval_pos_scores"], 2e-4, what="eval pos")
-    _close(res["ref_scores"], fx["eval_ref_scores"], 2e-4, what="eval ref")
+                            inject_masks={k: v.double() for k, v in fx.masks("eval_").items()}, keep=True)
+    for k in ("pos", "ref", "neg"):
+        _close(res[k + "_scores"], fx["eval_%s_scores" % k], 2e-4, what="eval " + k)
     assert torch.equal(res["pos_scores"].argmax(-1), fx["eval_argmax"])     # pointer/copy indices bit-exact
+    # the indices the loop fed back (t2s.py:343-351) and the decoder-step embeddings built from them in the last step
+    assert torch.equal(res["prev_inds"][:, 1:], fx["eval_argmax"][:, :-1])
+    _close(res["_inter"]["ref_dec_emb"], fx["eval_dec_emb_last"], 2e-5, what="eval dec_emb (last step)")
+    assert torch.equal(res["ground_frame"], fx["eval_ground_frame"])
+    assert torch.equal(res["ground_box"].float(), fx["eval_ground_box"])
+
+
+def test_ptr_fixture_is_not_degenerate():
+    """The pointer-competition fixture pins what the other two cannot: the reference's own greedy decode
+    visits OCR tokens (>= V) on >= 30 % of the steps and vocabulary tokens too, several rows are near-ties, and the
+    teacher-forced indices contain OCR copies."""
+    fx = Fixture("ptr_b3_f8_p10")
+    am = fx["eval_argmax"]
+    assert (am >= fx.V).float().mean().item() >= 0.3 and (am < fx.V).any()
+    assert am.unique().numel() >= 12
+    t2 = fx["eval_pos_scores"].topk(2, -1).values
+    assert int(((t2[..., 0] - t2[..., 1]) < 0.05).sum()) >= 3
+    prev = fx.batch()["train_prev_inds"]
+    assert (prev >= fx.V).float().mean().item() >= 0.3
+    for name in ("tiny_b2_f6_p8", "cfg1_b2_f20_p30"):        # documented: these two ARE constant (the decoder echoes its input)
+        assert (Fixture(name)["eval_argmax"] == 1).all()

@@ -17,6 +17,7 @@ abl = os.environ.get("FB_ABL", "0")          # timing-only ablations: 1 = no dQ 
 slots = os.environ.get("FB_SLOTS", "0") == "1"   # stamp the slot classes of phase A instead of the tile's segments
 subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-DFB_STAMP", "-DFB_ABL=" + abl] + (["-DFB_STAMP_SLOTS"] if slots else []) + ["-DFB_STAMP_MODE=" + os.environ.get("FB_MODE", "0")] + ["-o", lib] + Bld.sources())
 os.environ["T2S_HIP_LIB"] = lib
+os.environ["T2S_KEEP_DQ32"] = "1"            # ops keeps the fused backward's workspace (the stamps sit in its tail)
 import torch  # noqa: E402
 from vitxt_gqa_amd import ops  # noqa: E402
 

@@ -817,11 +817,13 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, float* dq32
   const int64_t rows = (int64_t)p.B * p.Lq;
   hipLaunchKernelGGL(attn_delta_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)p.o, (const bf16_t*)p.dout, p.delta,
                      dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs, p.kv_rs, p.kv_bs);
+  T2S_CHECK_LAUNCH("attn_bwd_fused (delta prep)");
   p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256), tail(attn_xcd_grid(1, p.H, p.B));
 #define FB_LAUNCH(IDX_, MODE_, grid_)                                                                                  \
   if (p.drop_thresh) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, true>), grid_, block, FB_SMEM, st, p, dq32); \
-  else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, false>), grid_, block, FB_SMEM, st, p, dq32);
+  else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, false>), grid_, block, FB_SMEM, st, p, dq32);                \
+  T2S_CHECK_LAUNCH("attn_bwd_fused (five-product kernel)");
   if (p.kv_idx) {
     FB_LAUNCH(true, 0, grid);
     FB_LAUNCH(true, 1, grid);
@@ -835,5 +837,6 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, float* dq32
   const int64_t total8 = rows * (width / 8);
   hipLaunchKernelGGL(attn_dq_cast_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, dq32, (bf16_t*)p.dq, (int64_t)p.Lq, width,
                      p.q_rs, p.q_bs, total8);
+  T2S_CHECK_LAUNCH("attn_bwd_fused (dQ cast)");
   return 0;
 }

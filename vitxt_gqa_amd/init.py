@@ -25,8 +25,21 @@ def _rng(seed, name):
     return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
 
 
-def init_tensor(name, shape, seed=0, attn_gain=1.0):
-    """Return the float32 numpy init of parameter ``name``."""
+def _gain(name, gains):
+    g = 1.0
+    for sub, v in (gains or {}).items():
+        if sub in name:
+            g *= v
+    return g
+
+
+def init_tensor(name, shape, seed=0, attn_gain=1.0, gains=None):
+    """Return the float32 numpy init of parameter ``name``.  ``gains`` maps a name substring to a multiplier applied to
+    the drawn values (fixtures use it to make the pointer head compete with the vocabulary head: ``ocr_ptr_net.`` up,
+    ``classifier.module.weight`` down); the streams themselves do not depend on it."""
+    g = _gain(name, gains)
+    if g != 1.0:
+        return (init_tensor(name, shape, seed, attn_gain) * np.float32(g)).astype(np.float32)
     r = _rng(seed, name)
     leaf = name.rsplit(".", 1)[-1]
     is_ln = "LayerNorm" in name or "layer_norm" in name
@@ -62,9 +75,9 @@ def _linear_fan_in(name):
     return 768
 
 
-def make_state_dict(schema, seed=0, attn_gain=1.0, dtype=torch.float32):
+def make_state_dict(schema, seed=0, attn_gain=1.0, dtype=torch.float32, gains=None):
     """schema: name -> shape (``schema.state_dict_schema``).  Returns name -> CPU tensor."""
-    return {k: torch.from_numpy(init_tensor(k, tuple(s), seed, attn_gain)).to(dtype) for k, s in schema.items()}
+    return {k: torch.from_numpy(init_tensor(k, tuple(s), seed, attn_gain, gains)).to(dtype) for k, s in schema.items()}
 
 
 def fingerprint(sd, names=None):

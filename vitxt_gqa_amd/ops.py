@@ -79,11 +79,13 @@ def attn_fwd(qkv, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0):
     return out, lse
 
 
-# True: bf16 launches without attention dropout use the fused 5-product kernel (t2s_attn_bwd_fused: S and dP computed once, dQ summed
-# across key blocks with fp32 atomics); False: always the two-kernel 7-product form.
+# True: bf16 launches (with or without attention dropout) that may see >= ATTN_BWD_FUSED_MIN_KEYS keys use the fused 5-product kernel
+# (t2s_attn_bwd_fused: S and dP computed once, dQ summed across key blocks with fp32 atomics - dQ differs in its last fp32 bits from
+# run to run); False (T2S_ATTN_BWD_FUSED=0): always the two-kernel 7-product form, which is bit-reproducible.
 ATTN_BWD_FUSED = os.environ.get("T2S_ATTN_BWD_FUSED", "1") != "0"
 ATTN_BWD_FUSED_MIN_KEYS = 2048
-_LAST_DQ32 = None      # tools/fused_stamps.py reads the diagnostic build's cycle stamps from its tail
+_KEEP_DQ32 = os.environ.get("T2S_KEEP_DQ32", "0") == "1"     # tools/fused_stamps.py: keep the workspace, whose tail holds the diagnostic
+_LAST_DQ32 = None                                             # build's cycle stamps (otherwise it is freed with the call: 2 GB at B=64)
 
 
 def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, fused=None):
@@ -120,8 +122,9 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     if use_fused:
         # fp32 dQ accumulation workspace (zeroed in the call); 16 KB of slack behind it for the stamps of the diagnostic build
         dq32 = torch.empty(B * L * HID + 4096, dtype=torch.float32, device=qkv.device)
-        global _LAST_DQ32
-        _LAST_DQ32 = dq32
+        if _KEEP_DQ32:
+            global _LAST_DQ32
+            _LAST_DQ32 = dq32
         X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(dq32), *klist, X.ptr(keys.valid8) if fill_in_kernel else None, *dims, float(drop_p), int(drop_seed),
                                            X.stream()),
                 "t2s_attn_bwd_fused")

@@ -95,7 +95,13 @@ class FusedClipAdam(torch.optim.Adam):
             return None
         steps = {int(self.state[p]["step"].item() if torch.is_tensor(self.state[p]["step"]) else self.state[p]["step"]) for _, p in live}
         if len(steps) != 1:
-            raise RuntimeError("FusedClipAdam: parameters are at different step counts %s" % sorted(steps))
+            # uneven step counts (a parameter that got no gradient on some iterations, or a resumed reference checkpoint): the
+            # kernels carry ONE bias correction, torch's Adam keeps per-parameter steps (the reference) - take its path this step
+            norm = None
+            if max_norm is not None:
+                norm = torch.nn.utils.clip_grad_norm_([p for _, p in live], max_norm)
+            super().step()
+            return norm
         step = steps.pop() + 1
         tb = self._tables
         key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel())
@@ -132,10 +138,12 @@ def build_optimizer(model, config):
     if not hasattr(torch.optim, oc.type):
         raise ValueError("No optimizer class of type {} present in torch".format(oc.type))
     groups = get_optimizer_parameters(model, config)
-    if oc.type == "Adam" and torch.cuda.is_available() and params.get("weight_decay", 0) == 0 and not params.get("amsgrad", False):
+    every = [p for g in (groups if isinstance(groups[0], dict) else [{"params": groups}]) for p in g["params"]]
+    on_card = bool(every) and all(p.is_cuda and p.dtype == torch.float32 and not p.is_sparse for p in every)
+    if oc.type == "Adam" and on_card and params.get("weight_decay", 0) == 0 and not params.get("amsgrad", False):
         return FusedClipAdam(groups, **params)          # the reference's recipe: own multi-tensor clip + Adam kernels
     kw = {}
-    if oc.type in ("Adam", "AdamW") and torch.cuda.is_available():
+    if oc.type in ("Adam", "AdamW") and on_card:
         kw["fused"] = True          # one multi-tensor kernel over all parameters (same arithmetic)
     return getattr(torch.optim, oc.type)(groups, **params, **kw)
 

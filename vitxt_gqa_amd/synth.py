@@ -12,7 +12,7 @@ T_MAX = 20
 DEC_STEPS = 12
 
 
-def make_batch(B, F, P, V=5000, seed=0, text_vocab=30522, ocr_keep=0.7, bos_idx=1, full_targets=True):
+def make_batch(B, F, P, V=5000, seed=0, text_vocab=30522, ocr_keep=0.7, bos_idx=1, full_targets=True, ocr_prev_frac=0.0):
     g = torch.Generator().manual_seed(seed)
     N = F * P
     s = {}
@@ -33,6 +33,13 @@ def make_batch(B, F, P, V=5000, seed=0, text_vocab=30522, ocr_keep=0.7, bos_idx=
     if full_targets:
         s["targets"] = (torch.rand(B, DEC_STEPS, V + N, generator=g) < 1e-3).float()
     s["train_loss_mask"] = torch.ones(B, DEC_STEPS)
+    if ocr_prev_frac > 0:
+        # teacher-forced OCR copies: previous-step indices in [V, V+N) (PrevPredEmbeddings' OCR branch, t2s.py:690-723);
+        # drawn LAST so that every other field is the same stream as without them
+        pick = torch.rand(B, DEC_STEPS, generator=g) < ocr_prev_frac
+        pick[:, 0] = False
+        ocr_ix = V + torch.randint(0, N, (B, DEC_STEPS), generator=g)
+        s["train_prev_inds"] = torch.where(pick, ocr_ix, s["train_prev_inds"])
     return s
 
 

@@ -224,10 +224,17 @@ class Grounding_Module(nn.Module):
         inject = sample_list.get("grounding_masks", None)
         if inject is not None:
             masks.update({k_: v.to(ocr_feat.device).float() for k_, v in inject.items() if k_ in masks})
+            # the outputs the reference derives from its masks follow the injected masks (spatio_temporal_grounding.py:65-66:
+            # frame ids at the nonzero positions of the pos frame mask, ascending; :139-140: the boxes under the pos OCR mask)
             if "ground_frame" in inject:
                 ground_frame = inject["ground_frame"].to(ocr_feat.device)
+            elif "pos_obj_mask" in inject:
+                ground_frame = torch.gather(sample_list.frame_id, 1, torch.nonzero(masks["pos_obj_mask"])[:, 1].view(B, -1))
             if "ground_box" in inject:
                 ground_box = inject["ground_box"].to(ocr_feat.device)
+            elif "pos_ocr_mask" in inject:
+                ground_box = torch.masked_select(sample_list.ocr_bbox_coordinates.float(),
+                                                 masks["pos_ocr_mask"].unsqueeze(-1).expand(B, -1, 4) > 0).view(B, -1, 4)
         fwd["ground_frame"] = ground_frame
         fwd["ground_bbox"] = ground_box
         fwd["frame_topk"] = torch.tensor(self.frame_topk, device=frame_feat.device)
@@ -282,6 +289,7 @@ class MMT(nn.Module):
         super().__init__()
         self.prev_pred_embeddings = PrevPredEmbeddings()
         self.encoder = BertEncoderParams(config.get("num_hidden_layers", 12))
+        self.kept_dec_emb = None        # a list when T2S.keep_intermediates: the decoder-step embeddings of every call
         _dropout_cfg(self, config)
         _bert_init(self)
 
@@ -289,6 +297,8 @@ class MMT(nn.Module):
                 max_keys=None):
         pd, pa = _train_dropout(self)
         dec_emb = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd)
+        if self.kept_dec_emb is not None:
+            self.kept_dec_emb.append(dec_emb)
         x = torch.cat([txt_emb, obj_emb, ocr_emb, dec_emb], dim=1)
         T, Fn, N, D = txt_emb.size(1), obj_emb.size(1), ocr_emb.size(1), dec_emb.size(1)
         L1 = T + Fn + N
@@ -310,6 +320,8 @@ class MMT(nn.Module):
         T, Fn, N = txt_emb.size(1), obj_emb.size(1), ocr_emb.size(1)
         L1 = T + Fn + N
         decs = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd, draws=len(obj_masks))
+        if self.kept_dec_emb is not None:
+            self.kept_dec_emb.extend(decs)
         D = decs[0].size(1)
         x = torch.cat([txt_emb, obj_emb, ocr_emb] + decs, dim=1)
         keys = []
@@ -415,6 +427,9 @@ class T2S(BaseModel):
         self.classifier = _Classifier(HID, num_choices)
         self.answer_processor = registry.get(self._datasets[0] + "_answer_processor")
         self.decode_with_prefix_cache = True      # eval: reuse the step-invariant prefix K/V (False = reference's loop)
+        # diagnostics for the parity tests: _last_fwd also keeps the pre-QTV encodings (txt_emb0 / obj_in0 / ocr_in0), and per MMT
+        # pass the decoder-step embeddings and the encoder outputs ({ref,pos,neg}_dec_emb / _mmt_dec / _mmt_ocr)
+        self.keep_intermediates = False
         self.batch_mmt_passes = False             # train: True = the three MMT passes as one 3B-batch encoder call (MMT.forward_passes)
         # train: the three MMT passes over one sequence with a shared prefix (MMT.forward_shared_prefix); T2S_SHARE_MMT_PREFIX=0
         # runs them as three separate encoder calls, the reference's literal structure
@@ -438,9 +453,15 @@ class T2S(BaseModel):
                 if self.writer is not None:
                     self.writer.write("text_bert initialised from %s (%d tensors)" % (f, len(used)))
                 return True
+        # the reference's TextBert.from_pretrained raises when the checkpoint is missing (t2s.py:47-56); offline there is none, so
+        # this is a loud warning rather than an error unless the config opts out (text_bert_allow_random_init: true)
+        msg = ("text_bert_init_from_bert_base: no checkpoint under %s; text_bert keeps its RANDOM init while its learning rate "
+               "is the fine-tuning one (lr_scale_text_bert) - call model.text_bert.load_pretrained(state_dict)" % path)
+        if not self.config.get("text_bert_allow_random_init", False):
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
         if self.writer is not None:
-            self.writer.write("text_bert_init_from_bert_base: no checkpoint under %s; text_bert keeps its random init "
-                              "(call model.text_bert.load_pretrained(state_dict))" % path)
+            self.writer.write(msg)
         return False
 
     def set_dropout(self, p):
@@ -466,6 +487,9 @@ class T2S(BaseModel):
             self._forward_txt_encoding(sample_list, fwd, dt)
             self._forward_obj_encoding(sample_list, fwd, dt)
             self._forward_ocr_encoding(sample_list, fwd, dt)
+            if self.keep_intermediates:
+                fwd["txt_emb0"], fwd["obj_in0"], fwd["ocr_in0"] = fwd["txt_emb"], fwd["obj_mmt_in"], fwd["ocr_mmt_in"]
+            self.mmt.kept_dec_emb = [] if self.keep_intermediates else None
             self.TransLayer(fwd, dt)
             self.Grounding_Module(sample_list, fwd)
             self._forward_mmt_and_output(sample_list, fwd, dt)
@@ -524,6 +548,7 @@ class T2S(BaseModel):
                                                   max_keys=[bounds[p[0]] for p in passes])
             for (name, _, cm), (ocr_out, dec_out) in zip(passes, outs):
                 fwd[name + "_scores"] = self._forward_output(ocr_out, dec_out, cm, dt)
+                self._keep_pass(fwd, name, ocr_out, dec_out, -3 + ("ref", "pos", "neg").index(name))
             return
         if self.training and self.batch_mmt_passes:
             outs = self.mmt.forward_passes(fwd["txt_emb"], fwd["txt_mask"], fwd["obj_mmt_in"], [p[1] for p in passes],
@@ -535,6 +560,12 @@ class T2S(BaseModel):
             ocr_out, dec_out = self.mmt(fwd["txt_emb"], fwd["txt_mask"], fwd["obj_mmt_in"], om, fwd["ocr_mmt_in"], cm,
                                         self.classifier.module.weight, prev_inds, dt, max_keys=bounds[name])
             fwd[name + "_scores"] = self._forward_output(ocr_out, dec_out, cm, dt)
+            self._keep_pass(fwd, name, ocr_out, dec_out, -1)
+
+    def _keep_pass(self, fwd, name, ocr_out, dec_out, which):
+        if self.keep_intermediates:
+            fwd[name + "_mmt_ocr"], fwd[name + "_mmt_dec"] = ocr_out.detach(), dec_out.detach()
+            fwd[name + "_dec_emb"] = self.mmt.kept_dec_emb[which].detach()
 
     def _forward_mmt_and_output(self, s, fwd, dt):
         if self.training:
@@ -593,6 +624,7 @@ class T2S(BaseModel):
                 fwd[name + "_scores"] = scores(dec_out, k_ptr, cm)
             prev[:, 1:] = fwd["pos_scores"].argmax(dim=-1)[:, :-1]
         fwd["prev_inds"] = prev
+        fwd["dec_emb_last"] = dec                                  # decoder-step embeddings of the last step (same for the 3 passes)
 
     # -- optimizer hook (t2s.py:356-376) -------------------------------------------------------------
     def get_optimizer_parameters(self, config):
