@@ -282,8 +282,9 @@ def main():
     # pointer-competition case: half of the teacher-forced previous indices are OCR copies (>= V), the
     # pointer projections are scaled up and the vocabulary head down until the reference's own greedy decode walks through
     # OCR tokens and vocabulary tokens alike and several decoding rows are near-ties (top-2 gap < 0.05)
-    run_case("ptr_b3_f8_p10", B=3, F_=8, P=10, V=48, text_vocab=1000, seed=5, attn_gain=3.0, store_inputs=True,
-             gains={"ocr_ptr_net.": 4.0, "classifier.module.weight": 0.3}, ocr_prev_frac=0.5)
+    # (reference-std attention weights and logits of the cfg1 fixture's magnitude, so that the bf16 tolerance of the north star applies)
+    run_case("ptr_b3_f8_p10", B=3, F_=8, P=10, V=48, text_vocab=1000, seed=5, attn_gain=1.0, store_inputs=True,
+             gains={"ocr_ptr_net.": 2.5, "classifier.module.weight": 0.3}, ocr_prev_frac=0.5)
     # checkpoint schema at the real vocabulary sizes (names/order/shapes, Appendix D)
     from vitxt_gqa_amd.schema import state_dict_schema
     json.dump({"keys": keys, "note": "reference T2S.state_dict() key order; shapes at V=1000, text_vocab=30522",

@@ -60,8 +60,12 @@ def test_forward_fp32_matches_reference(case):
     same = (f["new_ocr_mask"].cpu().float() == fx["new_ocr_mask"].float()).all(-1)
     if same.any():
         assert (f["ocr_score"].cpu()[same] - fx["ocr_score"][same]).abs().max().item() < 1e-4
+    # ... and on the REFERENCE's grounded frames for every sample: the scorer kernel on the fixture's new_ocr_mask
+    from vitxt_gqa_amd import ops
+    sc = ops.attention_score(f["global_q"], f["ocr_mmt_in"].float().contiguous(), fx["new_ocr_mask"].float().to(DEV).contiguous())
+    assert (sc.cpu() - fx["ocr_score"]).abs().max().item() < 1e-4
     if case == "ptr_b3_f8_p10":
-        assert same.any() and (s.train_prev_inds >= fx.V).float().mean().item() > 0.3
+        assert (s.train_prev_inds >= fx.V).float().mean().item() > 0.3
     # losses through BaseModel.__call__ (base_model.py:119-149) with the yml weights
     losses = out["losses"]
     assert set(losses) == {"train/vtextgqa/pos_bce_loss", "train/vtextgqa/InfoNCE"}
@@ -69,10 +73,19 @@ def test_forward_fp32_matches_reference(case):
     assert abs(losses["train/vtextgqa/InfoNCE"].item() / 1000 - fx["loss_nce"].item()) < 2e-4
 
 
-# bf16 logit tolerance: the north star's 1e-2 holds for reference-std weights (cfg1).  The ptr fixture scales the pointer
-# projections by 4 (pointer logits x16, |logit| up to ~6) and the attention projections by 3, so its bf16 error is bounded
-# relative to that scale: 4e-2 absolute, stated here and asserted.
-BF16_TOL = {"cfg1_b2_f20_p30": 1e-2, "ptr_b3_f8_p10": 4e-2}
+# bf16 logit tolerance: the north star's 1e-2.  Both fixtures have reference-std attention weights; the ptr fixture scales the pointer
+# projections by 2.5 and the vocabulary head by 0.3 so that the two heads compete (|logit| up to 6.9; cfg1: up to 9.6).
+BF16_TOL = {"cfg1_b2_f20_p30": 1e-2, "ptr_b3_f8_p10": 1e-2}
+
+
+def _bf16_tol(fx, tol):
+    """Per-logit tolerance [V + N]: ``tol`` (the north star's 1e-2 at reference-std weights) times the gain the fixture applies to
+    the head that produces the logit: the pointer logits of the ptr fixture are q.k with BOTH projections scaled by 2.5, so a
+    reference-std error e shows up as 6.25 e there; its vocabulary head is scaled by 0.3 (kept at ``tol``)."""
+    g = fx.meta.get("gains") or {}
+    t = torch.full((fx.V + fx.F * fx.P,), tol)
+    t[fx.V:] *= max(1.0, g.get("ocr_ptr_net.", 1.0) ** 2)
+    return t
 
 
 @pytest.mark.parametrize("case", ["cfg1_b2_f20_p30", "ptr_b3_f8_p10"])
@@ -82,11 +95,12 @@ def test_forward_bf16(case):
     fx = Fixture(case)
     model, s = _run(fx, torch.bfloat16)
     out = model(s)
-    tol = BF16_TOL[case]
+    tolv = _bf16_tol(fx, BF16_TOL[case])
+    tol = tolv.max().item()
     total = 0
     for k in ("ref_scores", "pos_scores", "neg_scores"):
-        err = (out[k].float().cpu() - fx[k]).abs().max().item()
-        assert err < tol, "%s max abs err %.3e" % (k, err)
+        err = (out[k].float().cpu() - fx[k]).abs()
+        assert (err < tolv).all(), "%s max abs err: vocabulary logits %.3e, pointer logits %.3e" % (k, err[..., :fx.V].max().item(), err[..., fx.V:].max().item())
         # pointer / copy indices (north star: bit-exact): the argmax of every decoding row equals the reference's wherever the
         # reference's own top-2 logit gap exceeds what two logits within the bf16 tolerance can close; the NUMBER of rows that
         # differ is bounded by the number of such near-tie rows of the reference (asserted: a deviation from bit-exact stated as a count)
@@ -195,15 +209,22 @@ def test_gradients_bf16_cfg1_match_reference(fused_everywhere, monkeypatch):
     params = dict(model.named_parameters())
     names, ref, total = fx.meta["grad_names"], fx["grad_norms"], fx["grad_total_norm"].item()
     assert {n for n, p in params.items() if p.grad is not None} == set(names)
-    worst = (0.0, "")
+    worst, bad = (0.0, ""), []
     sq = 0.0
     for n, r in zip(names, ref.tolist()):
         g = params[n].grad.double().norm().item()
         sq += g * g
-        # key-bias gradients are mathematically zero (softmax shift invariance): rounding noise on both sides, hence the floor
-        rel = abs(g - r) / (r + 1e-4 * total)
+        if n.endswith("attention.self.key.bias"):
+            # mathematically zero (softmax shift invariance); the reference's fp32 value is rounding noise (1e-6 .. 1e-5), and
+            # so is the bf16 one: bounded absolutely, at 1e-5 of the total gradient norm
+            if g > 1e-5 * total:
+                bad.append((n, g, r))
+            continue
+        rel = abs(g - r) / (r + 1e-6 * total)
         worst = max(worst, (rel, n))
-        assert rel < 3e-2, "%s grad norm %g vs reference %g" % (n, g, r)
+        if rel >= 3e-2:
+            bad.append((n, g, r))
+    assert not bad, "gradient norms outside 3 %% of the reference: %s" % bad
     assert abs(sq ** 0.5 - total) < 1e-2 * total, (sq ** 0.5, total)
     for k, v in fx.arr.items():            # the stored gradient tensors themselves
         if k.startswith("grad:"):
@@ -237,7 +258,7 @@ def test_eval_greedy_decode_indices_exact(case):
 
 
 @pytest.mark.parametrize("case,dtype,tol", [("tiny_b2_f6_p8", torch.float32, 1e-3), ("cfg1_b2_f20_p30", torch.bfloat16, 1e-2),
-                                            ("ptr_b3_f8_p10", torch.float32, 1e-3), ("ptr_b3_f8_p10", torch.bfloat16, 4e-2)])
+                                            ("ptr_b3_f8_p10", torch.float32, 1e-3), ("ptr_b3_f8_p10", torch.bfloat16, 1e-2)])
 def test_cached_decode_equals_reference_loop(case, dtype, tol):
     """Prefix-reuse greedy decoding == the reference's recompute-everything loop (same scores, same indices)."""
     if not torch.cuda.is_available():
@@ -264,11 +285,13 @@ def test_cached_decode_equals_reference_loop(case, dtype, tol):
             return (fed_a.cpu() == fed_b.cpu()).long().cumprod(1).bool()
 
         fed_ref = torch.cat([torch.full_like(fx["eval_argmax"][:, :1], 1), fx["eval_argmax"][:, :-1]], 1)      # BOS, then the reference's picks
+        tolv = _bf16_tol(fx, tol)
+        tol = tolv.max().item()
         for k in ("ref_scores", "pos_scores", "neg_scores"):
-            d = (a[k] - b[k]).abs().amax(-1).cpu()
-            assert d[comparable(pa, pb)].max().item() < 2 * tol, ("cached vs loop", k)
-            d = (a[k].cpu() - fx["eval_" + k]).abs().amax(-1)
-            assert d[comparable(pa, fed_ref)].max().item() < tol, ("cached vs reference", k)
+            d = ((a[k] - b[k]).abs().cpu() / tolv).amax(-1)
+            assert d[comparable(pa, pb)].max().item() < 2, ("cached vs loop", k, d)
+            d = ((a[k].cpu() - fx["eval_" + k]).abs() / tolv).amax(-1)
+            assert d[comparable(pa, fed_ref)].max().item() < 1, ("cached vs reference", k, d)
         # bf16 operands (the throughput dtype): greedy-decode indices against the reference's, step by step.  Row t of the
         # final scores is the logit row that decided step t (causal decoder), so up to a sample's FIRST differing step the
         # rows are comparable: every earlier index must be equal, and the differing one must be a near-tie of the reference
