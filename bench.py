@@ -101,10 +101,10 @@ class _Budget(Exception):
 
 def cpu_baseline(V, seed=0, budget_s=240):
     """Reference semantics (CPU oracle) timed on the host cores on a bounded sample of the workload: the full train step at
-    B=1, 100 frames x {5, 20, 50} OCR tokens per frame (three MEASURED points, ~45 s of CPU work in all; the larger ones only
-    where the host has the memory for the eager [12, L, L] score tensors and the time budget allows), scaled to the 100 x 100
-    shape by the FLOP model; the measured scaling exponent in L is reported beside the model's.  Runs BEFORE the GPU is
-    touched, under a hard wall-clock budget."""
+    B=1, 100 frames x {5, 20} OCR tokens per frame, 1 warm-up + 3 TIMED steps at each point (mean and std reported; BASELINE.md
+    section 3's protocol), about 30 s of CPU work; the 100 x 100 step itself needs ~100 GB of eager autograd state and > 300 s, so
+    ``value`` is the largest measured point EXTRAPOLATED to the 100 x 100 shape by the FLOP model (``kind`` says so; the measured
+    scaling exponent in L is reported beside the model's).  Runs BEFORE the GPU is touched, under a hard wall-clock budget."""
     import signal
     from oracle import t2s_oracle as O
     from vitxt_gqa_amd.init import make_state_dict
@@ -126,7 +126,7 @@ def cpu_baseline(V, seed=0, budget_s=240):
     sd = make_state_dict(state_dict_schema(V), seed=seed)
     for k, v in sd.items():
         v.requires_grad_(not O.is_dead(k))
-    result = {"value": None, "unit": "samples/s", "cores": cores, "kind": "port", "sample": "not measured (budget exceeded)"}
+    result = {"value": None, "unit": "samples/s", "cores": cores, "kind": "port, extrapolated", "sample": "not measured (budget exceeded)"}
     points = []
 
     def on_alarm(signum, frame):
@@ -136,29 +136,31 @@ def cpu_baseline(V, seed=0, budget_s=240):
     signal.alarm(int(budget_s))
     t_start = time.time()
     try:
-        for Ps, min_steps, max_steps in ((5, 1, 3), (20, 2, 3), (50, 1, 1)):
+        for Ps, min_steps, max_steps in ((5, 3, 3), (20, 3, 3)):
             L = T_Q + Fs + Fs * Ps + DEC
             f_s, _ = flops_per_sample_fwd(Fs, Ps, V)
             if points:
                 est = points[-1]["s_per_step"] * f_s / points[-1]["flops"]              # FLOP-model estimate of one step here
                 need_gb = 11 * 5 * 12 * L * L * 4 / 2 ** 30                            # ~5 live [12, L, L] fp32 tensors x 11 layers
-                if (time.time() - t_start) + est * min_steps > budget_s * 0.9 or need_gb > 0.5 * free_gb:
+                if (time.time() - t_start) + est * (min_steps + 1) > budget_s * 0.9 or need_gb > 0.5 * free_gb:
                     result["skipped_point"] = "B=1 x 100 x %d (L=%d): est. %.0f s/step, ~%.0f GB of autograd state vs %.0f GB free" % (Ps, L, est, need_gb, free_gb)
                     break
             batch = make_batch(Bs, Fs, Ps, V=V, seed=seed)
             e1, e2 = make_noise(Bs, Fs, Ps, seed)
             cfg = dict(frame_topk=5, ocr_topk=5, frame_num=Fs, ocr_frame_num=Ps)
             st = {}
-            if not points:      # one warm-up step, at the smallest point (thread pool, allocator, first-touch of the weights)
-                O.train_step(sd, batch, cfg, st, 1, expo_frame=e1, expo_ocr=e2)
-            t0 = time.time()
+            O.train_step(sd, batch, cfg, st, 1, expo_frame=e1, expo_ocr=e2)      # one untimed warm-up step at each shape
+            times = []
             n = 0
-            while n < min_steps or (time.time() - t0 < 8 and n < max_steps):
+            while n < min_steps or n < max_steps:
+                t0 = time.time()
                 O.train_step(sd, batch, cfg, st, n + 2, expo_frame=e1, expo_ocr=e2)
+                times.append(time.time() - t0)
                 n += 1
-            dt = (time.time() - t0) / n
-            points.append({"frames": Fs, "ocr_per_frame": Ps, "L": L, "s_per_step": dt, "steps": n, "flops": f_s,
-                           "samples_per_s": Bs / dt})
+            dt = sum(times) / n
+            sd_t = (sum((x - dt) ** 2 for x in times) / max(1, n - 1)) ** 0.5
+            points.append({"frames": Fs, "ocr_per_frame": Ps, "L": L, "s_per_step": dt, "s_per_step_std": sd_t, "steps": n, "flops": f_s,
+                           "samples_per_s": Bs / dt, "samples_per_s_std": Bs * sd_t / (dt * dt)})
     except _Budget:
         result["sample"] = "stopped by the %ds wall-clock budget" % budget_s
     finally:
@@ -167,12 +169,14 @@ def cpu_baseline(V, seed=0, budget_s=240):
     if points:
         big = points[-1]
         result.update(value=big["samples_per_s"] * big["flops"] / f_full, measured_samples_per_s_at_sample_shape=big["samples_per_s"],
-                      measured_points=[{k: p[k] for k in ("frames", "ocr_per_frame", "L", "s_per_step", "steps")} for p in points],
+                      measured_samples_per_s_std=big["samples_per_s_std"],
+                      measured_points=[{k: p[k] for k in ("frames", "ocr_per_frame", "L", "s_per_step", "s_per_step_std", "steps")} for p in points],
                       sample="oracle (plain-torch CPU restatement of the reference) full train step, fp32, %d threads, "
-                             "B=%d x %d frames x %d OCR/frame (L=%d): %.2f s/step over %d steps = %.3f samples/s "
-                             "measured; scaled by the FLOP model (x%.4f) to the 100x100 workload"
-                             % (cores, Bs, Fs, big["ocr_per_frame"], big["L"], big["s_per_step"], big["steps"], big["samples_per_s"],
-                                big["flops"] / f_full))
+                             "B=%d x %d frames x %d OCR/frame (L=%d): 1 warm-up + %d timed steps, %.2f +- %.2f s/step = %.3f samples/s "
+                             "MEASURED; value = that rate EXTRAPOLATED by the FLOP model (x%.4f) to the 100x100 workload, which "
+                             "does not fit the host (eager [12, L, L] scores)"
+                             % (cores, Bs, Fs, big["ocr_per_frame"], big["L"], big["steps"], big["s_per_step"], big["s_per_step_std"],
+                                big["samples_per_s"], big["flops"] / f_full))
         if len(points) >= 2:
             import math
             a, b = points[-2], points[-1]
@@ -271,7 +275,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from vitxt_gqa_amd import training_config
-    from vitxt_gqa_amd.ddp import GradBuckets
+    from vitxt_gqa_amd.ddp import DistributedSampler, GradBuckets, reduce_dict
     from vitxt_gqa_amd.optim import build_optimizer, clip_and_step, lr_lambda_update
     from vitxt_gqa_amd.synth import make_batch, make_noise
     from vitxt_gqa_amd.testing import make_model, to_device
@@ -297,15 +301,26 @@ def main():
     opt = build_optimizer(model, cfg)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda it: lr_lambda_update(it, cfg))
     buckets = GradBuckets(model.parameters(), single_rank_collectives=dist_on)
-    # each rank draws its own shard of questions (weak scaling: B per GPU)
-    batch = to_device(make_batch(B, F, P, V=V, seed=100 + rank), dev)
-    batch.grounding_noise = tuple(t.to(dev) for t in make_noise(B, F, P, seed=100 + rank))
+    # each rank takes its shard of the global batch of world * B questions (weak scaling: B per GPU) the way the reference's
+    # loader does: DistributedSampler, epoch-seeded permutation + contiguous chunk (samplers.py:42-60, seeded with the epoch by
+    # base_trainer.py:221).  The synthetic "dataset" is B-question blocks; block g is generated from seed 100 + g.
+    sampler = DistributedSampler(world, num_replicas=world, rank=rank, shuffle=True)
+    sampler.set_epoch(1)
+    block = int(sampler.indices()[0])
+    batch = to_device(make_batch(B, F, P, V=V, seed=100 + block), dev)
+    batch.grounding_noise = tuple(t.to(dev) for t in make_noise(B, F, P, seed=100 + block))
+    scalar_reduces = [0]
 
     def step(batch=batch):
         if args.forward_only:
             with torch.no_grad():
                 return model.forward(batch)
         out = model(batch)
+        if dist_on:
+            # the logging exchange of the reference's loop (_update_meter, base_trainer.py:293-301: reduce_dict of the losses and of
+            # the metrics every iteration) as ONE stacked reduce to rank 0
+            reduce_dict({**out["losses"], **{"metric/" + k: v for k, v in out.get("metrics", {}).items()}})
+            scalar_reduces[0] += 1
         loss = sum(l.mean() for l in out["losses"].values())
         buckets.reset()
         loss.backward()
@@ -324,12 +339,14 @@ def main():
             step()
         sync()
         timer.enabled = True
+        sr0 = scalar_reduces[0]
         t0 = time.perf_counter()
         for _ in range(args.steps):
             last = step()
         sync()
         elapsed = time.perf_counter() - t0
         timer.enabled = False
+        scalar_reduces_per_step = (scalar_reduces[0] - sr0) / max(1, args.steps)
     collectives_per_step = buckets.launched / max(1, args.steps + args.warmup)        # gradient all-reduces launched per step
     if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -408,9 +425,13 @@ def main():
                    "precision": "bf16 MFMA operands, fp32 accumulate / residual stream / master weights" if args.dtype == "bf16" else "fp32"},
         "ranks_seen": dist.get_world_size() if dist_on else 1,
         "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist_on else None,
-        "collectives_per_step": collectives_per_step,
+        "collectives_per_step": collectives_per_step, "n_buckets": len(buckets.buckets),
+        "scalar_reduces_per_step": scalar_reduces_per_step,
+        "sampler": "DistributedSampler(shuffle=True, epoch 1): rank %d of %d took question block %d" % (rank, world, block),
         "model_flops_per_sample": mult * f_total,
-        "model_tflops": sps * mult * f_total / 1e12 / world,
+        # priced at the reference's DENSE-mask FLOPs although the pos / neg passes see <= 537 of the 10 132
+        # keys: a dense-equivalent rate per GPU for comparison with the FLOP model, NOT a utilisation (roofline.* is)
+        "model_tflops_dense_mask_equivalent": sps * mult * f_total / 1e12 / world,
         "attention_gemm_fraction_of_flops": f_attn / f_total,
         "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30, "recompute_activations": bool(recompute),
     }

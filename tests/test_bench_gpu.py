@@ -50,3 +50,27 @@ def test_bench_line_contract_forward_only():
     d = _run("--forward-only")
     assert "forward" in d["config"]["workload"] and "loss" not in d
     assert d["roofline"]["bound"] == "mfma" and "roofline_fwd" not in d
+
+
+def test_bench_two_ranks_end_to_end_on_one_card():
+    """`python bench.py --gpus 2` END TO END: the parent spawns torch.distributed.run, two fresh ranks share the one
+    card of the test box (T2S_BENCH_ONE_GPU=1) over gloo (T2S_BENCH_BACKEND=gloo: RCCL needs one GPU per rank), shard the
+    questions with the reference's sampler, run the bucketed gradient exchange from the backward hooks, the fused scalar reduce
+    of the logged losses, the barrier and the MAX-over-ranks timing, and rank 0 prints the one JSON line."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, T2S_BENCH_BACKEND="gloo", T2S_BENCH_ONE_GPU="1")
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--frames", "20", "--ocr", "30", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-dropout0"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0 only)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["collectives_per_step"] == d["n_buckets"] and d["n_buckets"] >= 1           # every bucket reduced once per step
+    assert d["scalar_reduces_per_step"] == 1
+    assert abs(d["value"] - 2 * 2 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]    # whole-job samples of the K steps / MAX time
+    assert "cpu_baseline" not in d and d["loss"] == d["loss"]

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vitxt_gqa_amd.ddp import GradBuckets, shard_range
+from vitxt_gqa_amd.ddp import DistributedSampler, GradBuckets, reduce_dict, shard_range
 
 
 def test_shard_range_matches_distributed_sampler_chunks():
@@ -18,6 +18,77 @@ def test_shard_range_matches_distributed_sampler_chunks():
     for n, w in ((7, 2), (512, 8), (5, 8)):
         per = (n + w - 1) // w
         assert all(len(shard_range(n, r, w)) == per for r in range(w))
+
+
+def test_sampler_matches_torch_distributed_sampler_every_epoch():
+    """The reference's sampler is ``torch.utils.data.distributed.DistributedSampler`` of its era, copied
+    (pythia/datasets/samplers.py:1-3): epoch-seeded randperm, wrap padding, CONTIGUOUS chunk per rank.  Today's torch class
+    strides the ranks (indices[rank::world]) instead, so the pin is the restated arithmetic of samplers.py:42-60 plus the
+    properties both share: every rank sees the same permutation, the chunks tile it, set_epoch reshuffles reproducibly."""
+    for n, w in ((10, 4), (64, 8), (7, 2), (5, 8), (513, 8)):
+        for epoch in (0, 1, 13):
+            g = torch.Generator()
+            g.manual_seed(epoch)
+            perm = torch.randperm(n, generator=g).tolist()
+            per = (n + w - 1) // w
+            padded = perm + perm[: per * w - n]
+            chunks = []
+            for r in range(w):
+                sm = DistributedSampler(n, num_replicas=w, rank=r, shuffle=True)
+                sm.set_epoch(epoch)
+                got = list(iter(sm))
+                assert got == padded[r * per:(r + 1) * per] and len(sm) == per
+                chunks += got
+            assert chunks == padded and set(chunks) == set(range(n))
+        sm = DistributedSampler(list(range(n)), num_replicas=w, rank=w - 1, shuffle=False)
+        assert list(iter(sm)) == shard_range(n, w - 1, w)
+    a = DistributedSampler(100, 2, 0)
+    e0 = list(a)
+    a.set_epoch(1)
+    e1 = list(a)
+    a.set_epoch(0)
+    assert e0 != e1 and list(a) == e0
+
+
+def test_sampler_equals_the_reference_class():
+    """Against the reference's own class where its checkout is present (this container; not on the GPU box)."""
+    ref = "/root/reference/pythia/datasets/samplers.py"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_samplers", ref)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for n, w, shuffle in ((10, 4, True), (64, 8, True), (7, 2, False), (513, 8, True)):
+        for epoch in (0, 3):
+            for r in range(w):
+                a = mod.DistributedSampler(list(range(n)), num_replicas=w, rank=r, shuffle=shuffle)
+                b = DistributedSampler(n, num_replicas=w, rank=r, shuffle=shuffle)
+                a.set_epoch(epoch)
+                b.set_epoch(epoch)
+                assert list(a) == list(b) and len(a) == len(b)
+
+
+def _reduce_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = {"train/vtextgqa/pos_bce_loss": torch.tensor([1.0 + rank]), "train/vtextgqa/InfoNCE": torch.tensor(10.0 * (rank + 1)),
+         "a_metric": torch.tensor(0.25 * rank)}
+    r = reduce_dict(d)
+    out[rank] = {k: float(v) for k, v in r.items()}
+    dist.destroy_process_group()
+
+
+def test_reduce_dict_is_one_mean_reduce_to_rank_0():
+    """distributed_utils.py:91-110: stacked in sorted-key order, ONE reduce, rank 0 divides by the world size."""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_reduce_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[0] == {"a_metric": 0.125, "train/vtextgqa/InfoNCE": 15.0, "train/vtextgqa/pos_bce_loss": 1.5}
+    assert list(out[0]) == sorted(out[0])
+    d = {"x": torch.tensor(2.0)}
+    assert reduce_dict(d) is d                      # no process group: returned untouched (world_size < 2 branch)
 
 
 def _free_port():

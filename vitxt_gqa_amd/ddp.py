@@ -29,6 +29,61 @@ def shard_range(n_items, rank, world_size):
     return idx[rank * per:(rank + 1) * per]
 
 
+class DistributedSampler:
+    """The reference's sampler (``pythia/datasets/samplers.py:10-66``, wired by ``multi_dataset.py:285-304``): every epoch
+    all ranks draw the SAME permutation of the dataset from a generator seeded with the epoch number (``shuffle=True``; the
+    identity order otherwise), pad it to a multiple of the world size by wrapping around to its own head, and rank r takes the
+    contiguous chunk [r n, (r + 1) n).  ``set_epoch`` (the trainer's ``seed_sampler``) re-seeds the next iteration.
+    ``dataset`` may be anything with a length, or the length itself."""
+
+    def __init__(self, dataset, num_replicas=None, rank=None, shuffle=True):
+        if num_replicas is None:
+            num_replicas = dist.get_world_size() if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if not 0 <= rank < num_replicas:
+            raise ValueError("rank %d outside a world of %d" % (rank, num_replicas))
+        self.n = int(dataset) if isinstance(dataset, int) else len(dataset)
+        self.num_replicas, self.rank, self.shuffle, self.epoch = num_replicas, rank, shuffle, 0
+        self.num_samples = (self.n + num_replicas - 1) // num_replicas
+        self.total_size = self.num_samples * num_replicas
+
+    def indices(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.epoch)
+            order = torch.randperm(self.n, generator=g)
+        else:
+            order = torch.arange(self.n)
+        order = torch.cat([order, order[: self.total_size - self.n]])
+        return order[self.rank * self.num_samples:(self.rank + 1) * self.num_samples]
+
+    def __iter__(self):
+        return iter(self.indices().tolist())
+
+    def __len__(self):
+        return self.num_samples
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+
+def reduce_dict(dictionary, group=None):
+    """The scalar exchange of the logging path (``pythia/utils/distributed_utils.py:91-110``, called on the losses / metrics of
+    a report): ONE reduce of the stacked values to rank 0, which divides by the world size; the other ranks keep their local
+    values (as in the reference, only the main process logs).  Keys are sorted so that every rank stacks in the same order."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world < 2 or len(dictionary) == 0:
+        return dictionary
+    with torch.no_grad():
+        keys = sorted(dictionary)
+        values = torch.stack([dictionary[k].detach().reshape(()).float() for k in keys], dim=0)
+        dist.reduce(values, dst=0, group=group)
+        if dist.get_rank(group) == 0:
+            values /= world
+        return {k: v for k, v in zip(keys, values)}
+
+
 class GradBuckets:
     def __init__(self, params, bucket_bytes=48 << 20, group=None, average=True, names=None, single_rank_collectives=False):
         """``params``: parameters, or (name, parameter) pairs as from ``named_parameters()`` (names only serve error messages).
