@@ -187,8 +187,10 @@ def test_gradients_bf16_cfg1_match_reference(fused_everywhere, monkeypatch):
         pytest.skip("no GPU")
     from vitxt_gqa_amd import ops
     if fused_everywhere:
+        import vitxt_gqa_amd.functional as FNmod
         monkeypatch.setattr(ops, "ATTN_BWD_FUSED_MIN_KEYS", 0)
         monkeypatch.setattr(ops, "ATTN_BWD_FUSED", True)
+        monkeypatch.setattr(FNmod, "PRUNE_KV_MAX_KEYS", 0)      # (the pruned pos / neg launches take the two-kernel form)
     fx = Fixture("cfg1_b2_f20_p30")
     model, s = _run(fx, torch.bfloat16)
     out = model(s)
@@ -461,6 +463,47 @@ def test_shared_prefix_passes_equal_separate_passes(dtype, tol_s, tol_g):
         else:
             d = (g.double() - res[True][1][n].double()).norm().item()
             assert d <= tol_g * g.double().norm().item() + 1e-3 * tot, (n, d, g.double().norm().item())
+
+
+@pytest.mark.parametrize("share_prefix", [True, False])
+def test_pruned_kv_projection_equals_the_full_projection(share_prefix, monkeypatch):
+    """The pos / neg MMT passes project K and V only for the rows their top-k masks make keys (functional.PRUNE_KV_MAX_KEYS; masked
+    keys contribute exactly nothing, t2s.py:609-618 with exp(-10000) == 0): same scores and same parameter gradients as with the
+    full fused QKV projection, on the cfg1 fixture (bf16 operands; the two forms run different library GEMM shapes, so equal up to
+    bf16 rounding of the operands' products, not bit for bit), and both within the reference's tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import vitxt_gqa_amd.functional as FNmod
+    fx = Fixture("cfg1_b2_f20_p30")
+    res = {}
+    for prune in (0, 1024):
+        monkeypatch.setattr(FNmod, "PRUNE_KV_MAX_KEYS", prune)
+        model, s = _run(fx, torch.bfloat16)
+        model.share_mmt_prefix = share_prefix
+        seen = []
+        orig = FNmod.ops.attn_fwd
+        monkeypatch.setattr(FNmod.ops, "attn_fwd", lambda *a, **k: (seen.append(k.get("kv") is not None), orig(*a, **k))[1])
+        out = model(s)
+        monkeypatch.setattr(FNmod.ops, "attn_fwd", orig)
+        # shared prefix: layers 1, 2 of the pos and neg passes; separate calls: all three layers of both
+        assert sum(seen) == (0 if prune == 0 else (4 if share_prefix else 6)), seen
+        sum(v.mean() for v in out["losses"].values()).backward()
+        res[prune] = ({k: out[k].detach().float().cpu() for k in ("ref_scores", "pos_scores", "neg_scores")},
+                      {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None})
+    for k in res[0][0]:
+        assert (res[0][0][k] - res[1024][0][k]).abs().max().item() < 1e-2, k
+        assert (res[1024][0][k] - fx[k]).abs().max().item() < 1e-2, k
+    assert res[0][1].keys() == res[1024][1].keys()
+    tot = sum(g.norm().item() ** 2 for g in res[0][1].values()) ** 0.5
+    for n, g in res[0][1].items():          # two bf16 runs through different GEMM shapes: equal at bf16-noise level ...
+        d = (g - res[1024][1][n]).norm().item()
+        assert d <= 4e-2 * g.norm().item() + 1e-5 * tot, (n, d, g.norm().item())
+    for k, v in fx.arr.items():             # ... and the pruned form is as close to the REFERENCE's gradient tensors as the full form
+        if k.startswith("grad:"):
+            n = k[5:]
+            base, rows = (n[:-1].split("[:")[0], int(n[:-1].split("[:")[1])) if n.endswith("]") else (n, None)
+            e = [(res[pr][1][base][:rows].float() - v).norm().item() if rows else (res[pr][1][base].float() - v).norm().item() for pr in (0, 1024)]
+            assert e[1] <= 1.5 * e[0] + 1e-6 * tot and e[1] <= 3e-2 * v.norm().item() + 1e-5 * tot, (k, e, v.norm().item())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

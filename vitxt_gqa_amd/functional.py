@@ -13,6 +13,7 @@ attention output, log-sum-exp, the two pre-LayerNorm sums (+ statistics) and the
 LayerNorm outputs and GELU outputs are recomputed in backward (HBM-cheap) instead of stored.
 """
 import contextlib
+import os
 import threading
 
 import torch
@@ -24,6 +25,11 @@ F32 = torch.float32
 # True: keep only the FFN pre-activation and rebuild GELU / LN1 outputs in backward (-5 GB per layer at B=64,
 # +2 HBM passes); False (default): keep them -- 288 GB of HBM3E leave the room (peak ~210 GB at B=64).
 RECOMPUTE_ACTIVATIONS = False
+# A pass whose key list has a small STRUCTURAL bound (the pos / neg MMT passes: <= 537 / 62 of the 10 132 rows are ever keys,
+# guaranteed by the top-k masks) projects K and V only for the rows that are keys: masked keys contribute exactly nothing
+# (deviation 1), so their K / V rows - two thirds of the QKV GEMM, of its input-gradient and of its
+# weight-gradient GEMM - are never read.  Lists with a bound above this many keys keep the fused [B, L, 2304] projection.
+PRUNE_KV_MAX_KEYS = int(os.environ.get("T2S_PRUNE_KV_MAX_KEYS", "1024"))
 
 
 def _mm_bias(x2, w, b):
@@ -52,9 +58,17 @@ def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute,
     ``ops.NormRes`` unless ``materialise`` (last layer of a stack)."""
     w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2 = W
     lo = w_qkv.dtype != F32
-    if qkv is None:          # (given: the projection of layer 0, shared by the passes of SharedPrefixEncoderFn)
-        qkv = _mm_bias(xl, w_qkv, b_qkv).view(B, L, 3 * HID)
-    att, lse = ops.attn_fwd(qkv, keys, drop_p=attn_drop_p, drop_seed=seeds[2])
+    kvc = None
+    if qkv is None and _prunable(keys, lo):
+        # Q for every row, K | V for the key rows only (KeyList.compact): [B, capK, 1536] instead of [B, L, 1536]
+        keys_c, flat_rows, capK = keys.compact(L)
+        qkv = _mm_bias(xl, w_qkv[:HID], b_qkv[:HID]).view(B, L, HID)
+        kvc = _mm_bias(xl.index_select(0, flat_rows), w_qkv[HID:], b_qkv[HID:]).view(B, capK, 2 * HID)
+        att, lse = ops.attn_fwd(qkv, keys_c, drop_p=attn_drop_p, drop_seed=seeds[2], kv=kvc)
+    else:
+        if qkv is None:      # (given: the projection of layer 0, shared by the passes of SharedPrefixEncoderFn)
+            qkv = _mm_bias(xl, w_qkv, b_qkv).view(B, L, 3 * HID)
+        att, lse = ops.attn_fwd(qkv, keys, drop_p=attn_drop_p, drop_seed=seeds[2])
     a = _mm_bias(att.view(B * L, HID), w_ao, b_ao)
     y1, y1_lo, z1, st1 = ops.add_layernorm_fwd(a, x2, g1, be1, stream_dtype=F32, want_lo=lo, want_y=not lo, drop_p=drop_p, drop_seed=seeds[0])
     del a
@@ -69,14 +83,18 @@ def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute,
         y2 = ops.NormRes(z2, st2, g2, be2)
     if recompute:      # store less: GELU output and the LN1 operand copy are rebuilt in backward
         gact = y1_op = None
-    return y2, (y2_lo if lo else None), (xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op)
+    return y2, (y2_lo if lo else None), (xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op, kvc)
+
+
+def _prunable(keys, lo):
+    return lo and keys.bound_is_structural and keys.cap_hint <= PRUNE_KV_MAX_KEYS and keys.cap_hint * 4 <= keys.idx.shape[1]
 
 
 def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p, stop_at_qkv=False):
     """dy: [B*L, 768] gradient of the layer output (fp32 or the operand dtype).  Returns (dx [B*L, 768] in the operand
     dtype, the 12 parameter gradients in the order of W, all fp32: they are gradients of the fp32 master parameters).  The bias gradients of the two projections that feed a
     residual+LayerNorm block come out of that block's backward kernel (column sums in the same pass)."""
-    xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op = saved
+    xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op, kvc = saved
     B, L, _ = qkv.shape
     dt = w_qkv.dtype
     lo = dt != F32
@@ -103,6 +121,18 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p, stop_at_qkv=Fal
     datt = (dz1x @ w_ao).view(B, L, HID)
     del dz1x
     # ---- attention
+    if kvc is not None:          # pruned K / V (see _layer_forward): gradients of Q for every row, of K | V for the key rows
+        assert not stop_at_qkv
+        keys_c, flat_rows, capK = keys.compact(L)
+        dq, dkv = ops.attn_bwd(qkv, att, datt, lse, keys_c, drop_p=attn_drop_p, drop_seed=seeds[2], kv=kvc)
+        del datt
+        dq, dkv = dq.view(B * L, HID), dkv.view(B * capK, 2 * HID)
+        xc = xl.index_select(0, flat_rows)
+        dw_qkv = torch.cat([_wgrad(dq, xl, B), (dkv.t() @ xc).float()], 0)
+        db_qkv = torch.cat([dq.sum(0, dtype=F32), dkv.sum(0, dtype=F32)], 0)
+        dx = dz1.addmm_(dq, w_qkv[:HID])                                 # + residual branch of LN1 (in place)
+        dx.index_add_(0, flat_rows, dkv @ w_qkv[HID:])                   # the key rows' share (positions behind a list: zeros onto row 0)
+        return dx, (dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1, dw_i, db_i, dw_o, db_o, dg2, dbe2)
     dqkv = ops.attn_bwd(qkv, att, datt, lse, keys, drop_p=attn_drop_p, drop_seed=seeds[2]).view(B * L, 3 * HID)
     del datt
     if stop_at_qkv:          # SharedPrefixEncoderFn sums dqkv over the passes that share this projection and finishes once

@@ -32,6 +32,25 @@ class KeyList:
         self.valid8 = valid8        # [B, L] uint8 mask the list was compacted from (lets the backward skip its zero fill)
         # static upper bound on (#valid prefix keys + n_dec): lets the dK/dV grid skip empty key blocks
         self.cap_hint = cap_hint if cap_hint is not None else idx.shape[1]
+        self.bound_is_structural = False   # the caller vouches that cap_hint can never be exceeded (top-k masks): allows compact()
+        self._compact = {}
+
+    def compact(self, L):
+        """For a list whose static bound is structural and small (the pos / neg MMT passes: <= 537 / 62 of 10 132 rows are
+        ever keys): the rows of a [B * L, .] row tensor that are keys (-> ``flat_rows`` int64 [B * capK], list order, the
+        positions behind a sample's list point at its row 0) and the key list of a [B, capK, .] buffer gathered that way
+        (``keys_c``: position p is row p; same counts, same decoder rule, same dropout positions).  K and V - and their
+        gradients - then only ever exist for those rows."""
+        if L not in self._compact:
+            B = self.idx.shape[0]
+            capK = min(self.idx.shape[1], (self.cap_hint + 63) // 64 * 64)
+            pos = torch.arange(capK, device=self.idx.device, dtype=torch.int32)
+            live = pos.unsqueeze(0) < (self.cnt + self.n_dec).unsqueeze(1)
+            rows = torch.where(live, self.idx[:, :capK], torch.zeros((), dtype=torch.int32, device=self.idx.device)).long()
+            flat = (rows + torch.arange(B, device=rows.device).unsqueeze(1) * L).reshape(-1)
+            keys_c = KeyList(pos.unsqueeze(0).expand(B, capK).contiguous(), self.cnt, self.n_dec, self.dec_q0, min(self.cap_hint, capK), None)
+            self._compact[L] = (keys_c, flat, capK)
+        return self._compact[L]
 
 
 def compact_keys(valid, n_dec=0, dec_row0=0, cap_hint=None):
@@ -63,17 +82,26 @@ def attn_dropout_mask(B, Lq, Lk, drop_p, drop_seed, device):
     return out
 
 
-def attn_fwd(qkv, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0):
-    """Self-attention over a fused QKV buffer [B, L, 2304].  Returns (ctx [B, L, 768], lse [B, 12, L])."""
+def _split_views(q, kv, keys):
+    """q [B, L, 768] + kv [B, capK, 1536] (K | V of the gathered key rows, ``keys`` = the compact list) -> (q, k, v) views."""
+    B, L, _ = q.shape
+    assert q.shape == (B, L, HID) and q.is_contiguous() and kv.dim() == 3 and kv.shape[0] == B and kv.shape[2] == 2 * HID and kv.is_contiguous()
+    assert kv.dtype == q.dtype and kv.shape[1] == keys.idx.shape[1] and keys.valid8 is None
+    return q, kv[..., :HID], kv[..., HID:]
+
+
+def attn_fwd(qkv, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, kv=None):
+    """Self-attention over a fused QKV buffer [B, L, 2304]; or, with ``kv`` [B, capK, 1536], over queries ``qkv`` = Q [B, L, 768]
+    and the K | V rows of a compact key buffer (KeyList.compact).  Returns (ctx [B, L, 768], lse [B, 12, L])."""
     B, L, _ = qkv.shape
-    q, k, v = _attn_views(qkv)
+    q, k, v = _attn_views(qkv) if kv is None else _split_views(qkv, kv, keys)
     out = torch.empty(B, L, HID, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, HEADS, L, dtype=torch.float32, device=qkv.device)
     _check_keys(keys, B, L)
     X.check(X.lib().t2s_attn_fwd(
         X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(lse), X.ptr(keys.idx), X.ptr(keys.cnt),
         B, HEADS, L, keys.idx.shape[1], keys.n_dec, keys.dec_q0,
-        qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
+        q.stride(1), q.stride(0), k.stride(1), k.stride(0), out.stride(1), out.stride(0),
         scale, X.dtype_code(qkv), float(drop_p), int(drop_seed), X.stream()),
         "t2s_attn_fwd")
     return out, lse
@@ -88,13 +116,26 @@ _KEEP_DQ32 = os.environ.get("T2S_KEEP_DQ32", "0") == "1"     # tools/fused_stamp
 _LAST_DQ32 = None                                             # build's cycle stamps (otherwise it is freed with the call: 2 GB at B=64)
 
 
-def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, fused=None):
-    """Returns dqkv [B, L, 2304] (rows of keys outside the key list get exact zeros in the K/V thirds)."""
+def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, fused=None, kv=None):
+    """Returns dqkv [B, L, 2304] (rows of keys outside the key list get exact zeros in the K/V thirds); with ``kv`` (see
+    attn_fwd) returns (dq [B, L, 768], dkv [B, capK, 1536]) - the two-kernel form, positions behind a sample's list zero."""
+    global LAST_ATTN_BWD_PRODUCTS
     B, L, _ = qkv.shape
-    q, k, v = _attn_views(qkv)
     assert out.is_contiguous() and dout.is_contiguous() and out.shape == (B, L, HID) and dout.shape == (B, L, HID)
     assert lse.shape == (B, HEADS, L) and lse.is_contiguous()
     _check_keys(keys, B, L)
+    if kv is not None:
+        q, k, v = _split_views(qkv, kv, keys)
+        dq_, dkv = torch.empty_like(qkv), torch.zeros_like(kv)
+        delta = torch.empty_like(lse)
+        LAST_ATTN_BWD_PRODUCTS = 7
+        X.check(X.lib().t2s_attn_bwd(X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(dout), X.ptr(lse), X.ptr(delta),
+                                     X.ptr(dq_), X.ptr(dkv[..., :HID]), X.ptr(dkv[..., HID:]), X.ptr(keys.idx), X.ptr(keys.cnt),
+                                     B, HEADS, L, keys.idx.shape[1], keys.n_dec, keys.dec_q0, keys.cap_hint,
+                                     q.stride(1), q.stride(0), k.stride(1), k.stride(0), out.stride(1), out.stride(0),
+                                     scale, X.dtype_code(qkv), float(drop_p), int(drop_seed), X.stream()), "t2s_attn_bwd")
+        return dq_, dkv
+    q, k, v = _attn_views(qkv)
     cap = keys.idx.shape[1]
     # self-attention layout: the rows the mask covers, then decoder rows - this call's n_dec of them at dec_q0 (cap == L), or those
     # of all three MMT passes with only this call's listed (shared-prefix layout, cap < L)
@@ -117,7 +158,6 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     if fused is None:
         fused = ATTN_BWD_FUSED and keys.cap_hint >= ATTN_BWD_FUSED_MIN_KEYS
     use_fused = fused and qkv.dtype == torch.bfloat16
-    global LAST_ATTN_BWD_PRODUCTS
     LAST_ATTN_BWD_PRODUCTS = 5 if use_fused else 7
     if use_fused:
         # fp32 dQ accumulation workspace (zeroed in the call); 16 KB of slack behind it for the stamps of the diagnostic build

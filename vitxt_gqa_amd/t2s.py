@@ -224,6 +224,12 @@ class Grounding_Module(nn.Module):
         inject = sample_list.get("grounding_masks", None)
         if inject is not None:
             masks.update({k_: v.to(ocr_feat.device).float() for k_, v in inject.items() if k_ in masks})
+            # the MMT passes rely on the cardinalities the top-k selection guarantees (static key bounds, K / V projected for the
+            # key rows only): injected masks (tests) must obey them too - checked here, on the host, because nothing else would
+            lim = {"pos_obj_mask": k, "neg_obj_mask": k, "pos_ocr_mask": min(P, ot) * Fn, "neg_ocr_mask": min(P, ot) * k}
+            for k_, cap_ in lim.items():
+                if k_ in inject and int((masks[k_] > 0).sum(1).max()) > cap_:
+                    raise ValueError("injected %s selects more than %d entries in a sample" % (k_, cap_))
             # the outputs the reference derives from its masks follow the injected masks (spatio_temporal_grounding.py:65-66:
             # frame ids at the nonzero positions of the pos frame mask, ascending; :139-140: the boxes under the pos OCR mask)
             if "ground_frame" in inject:
@@ -305,6 +311,7 @@ class MMT(nn.Module):
         valid = torch.cat([txt_mask > 0, obj_mask > 0, ocr_mask > 0], dim=1)
         # decoder keys: step j visible to decoder row i iff i >= j; prefix rows never see them (t2s.py:574-618)
         keys = ops.compact_keys(valid, n_dec=D, dec_row0=L1, cap_hint=max_keys)
+        keys.bound_is_structural = max_keys is not None          # top-k masks: the bound holds by construction (Grounding_Module)
         out = FN.bert_encoder(x, keys, self.encoder.layer, dtype, pd, pa)
         return FN.split_rows(out, T + Fn, L1)
 
@@ -328,6 +335,7 @@ class MMT(nn.Module):
         for i, (om, cm) in enumerate(zip(obj_masks, ocr_masks)):
             valid = torch.cat([txt_mask > 0, om > 0, cm > 0], dim=1)
             keys.append(ops.compact_keys(valid, n_dec=D, dec_row0=L1 + i * D, cap_hint=None if max_keys is None else max_keys[i]))
+            keys[-1].bound_is_structural = max_keys is not None and max_keys[i] is not None
         outs = FN.shared_prefix_encoder(x, keys, self.encoder.layer, dtype, pd, pa)
         res = []
         for i, out in enumerate(outs):
