@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2S_ABI_VERSION 2
+#define T2S_ABI_VERSION 3
 #define T2S_F32 0
 #define T2S_BF16 1
 #define T2S_HEAD_DIM 64
@@ -183,11 +183,13 @@ int t2s_ptr_scores(const float* q, const void* k, const float* mask, float* out,
  *   question qp = q_linear(txt_emb) [B, T, 768] fp32: att = softmax(qp.w + bias) over all T, * qmask,
  *   / (sum + 1e-12); out[b] = sum_t att[t] qp[b, t]  -> [B, 768].
  * t2s_attention_score: AttentionScore.forward spatio_temporal_grounding.py:15-23:
- *   score = softmax_M(q . k^T) * mask / (sum + 1e-12), -10000 where mask == 0.  k: [B, M, 768]. */
+ *   score = softmax_M(q . k^T) * mask / (sum + 1e-12), -10000 where mask == 0.  k: [B, M, 768] rows of 768, sample b at
+ *   k + b * k_batch_stride elements (>= M * 768: the M rows may be a slice of a longer sequence, e.g. the frame / OCR rows
+ *   of the [question; frames; OCR] buffer QTV leaves). */
 int t2s_question_pool(const float* qp, const float* w, const float* bias, const float* qmask, float* out,
                       int B, int T, t2s_stream_t stream);
-int t2s_attention_score(const float* q, const void* k, const float* mask, float* score, int B, int M,
-                        int k_dtype, t2s_stream_t stream);
+int t2s_attention_score(const float* q, const void* k, int64_t k_batch_stride, const float* mask, float* score,
+                        int B, int M, int k_dtype, t2s_stream_t stream);
 
 /* t2s_ground_select: Temporal_Grounding_Indicator.forward (spatio_temporal_grounding.py:34-68),
  * Grounding_Module.forward t2s.py:486-494 and Spatial_Grounding_Indicator.forward (:79-142) in one
@@ -200,7 +202,8 @@ int t2s_attention_score(const float* q, const void* k, const float* mask, float*
  * [B, F*ocr_topk, 4].  Ties among equal scores go to the LOWEST index (the reference's ATen order is
  * implementation defined). */
 int t2s_ground_select(const float* frame_score, const float* frame_mask, const float* expo_frame,
-                      const int64_t* frame_id, const float* q_global, const void* ocr_feat, int ocr_dtype,
+                      const int64_t* frame_id, const float* q_global, const void* ocr_feat,
+                      int64_t ocr_batch_stride, int ocr_dtype,
                       const float* expo_ocr, const int64_t* temporal_id, const float* bbox,
                       float* pos_obj_mask, float* neg_obj_mask, int64_t* ground_frame, float* new_ocr_mask,
                       float* ocr_score, float* pos_ocr_mask, float* neg_ocr_mask, float* ground_box,
@@ -215,6 +218,18 @@ int t2s_ground_select(const float* frame_score, const float* frame_mask, const f
 int t2s_embed_rows(const float* f0, int d0, const float* f1, int d1, const int64_t* id0, const float* emb0,
                    const int64_t* id1, const float* emb1, int emb_dim, int emb_rows, void* out, int ld_out,
                    int64_t rows, int out_dtype, t2s_stream_t stream);
+
+/* ---- elementwise passes around the encoders (csrc/glue.hip).  Tensors are [B, rows, 768] fp32 unless noted; a pointer paired
+ * with a batch stride (elements) may be a slice of a larger buffer.
+ * t2s_tanh_residual_fwd: QTV's modality residual y = x + tanh(enc_out) (pythia/models/t2s.py:428-432, the three slices as one
+ *   tensor).  t2s_tanh_residual_bwd: g_enc = gy * (1 - tanh(enc_out)^2) in g_dtype (the encoder's output gradient).
+ * t2s_add_cast: out = a + b with b in b_dtype (a residual-path gradient meeting the operand-dtype input gradient of an encoder). */
+int t2s_tanh_residual_fwd(const float* x, const float* enc_out, float* y, int64_t B, int64_t rows,
+                          int64_t y_batch_stride, t2s_stream_t stream);
+int t2s_tanh_residual_bwd(const float* gy, int64_t gy_batch_stride, const float* enc_out, void* g_enc, int g_dtype,
+                          int64_t B, int64_t rows, t2s_stream_t stream);
+int t2s_add_cast(const float* a, int64_t a_batch_stride, const void* b, int b_dtype, float* out, int64_t B,
+                 int64_t rows, t2s_stream_t stream);
 
 /* ---- losses (pythia/modules/losses.py).
  * t2s_bce_masked: POSBCEWithMaskLoss.forward :329-343.  scores/targets/grad: [rows, cols] fp32,

@@ -456,3 +456,41 @@ def test_attention_bwd_fused_five_products(B, L1, n_dec, keep, drop_p):
             assert got[..., 768:][~kvalid].abs().max().item() == 0
         # dK / dV are deterministic and computed by the same arithmetic as the two-kernel form up to the K pre-scaling path
         assert (got[..., 768:].double() - two[..., 768:].double()).abs().max().item() < 2e-2 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_glue_passes_tanh_residual_and_add_cast(dtype):
+    """csrc/glue.hip: QTV's residual x + tanh(enc) (t2s.py:428-432) forward / backward and the fp32 + operand-dtype add, against the
+    framework ops they replace; the gradient input as a ROW SLICE of a longer buffer (how it arrives from the MMT input gradient)."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, L, extra = 3, 37, 9
+    x = torch.randn(B, L, 768, generator=g).to(DEV)
+    enc = (torch.randn(B, L, 768, generator=g) * 1.5).to(DEV)
+    y = ops.tanh_residual_fwd(x, enc)
+    assert (y - (x + torch.tanh(enc))).abs().max().item() < 2e-6
+    big = torch.randn(B, L + extra, 768, generator=g).to(DEV)
+    gy = big[:, :L]                                            # batch stride (L + extra) * 768
+    assert not gy.is_contiguous()
+    ge = ops.tanh_residual_bwd(gy, enc, dtype)
+    ref = gy * (1 - torch.tanh(enc) ** 2)
+    assert ge.dtype == dtype and (ge.float() - ref).abs().max().item() < (2e-6 if dtype == torch.float32 else 2e-2)
+    d = torch.randn(B * L, 768, generator=g).to(DEV).to(dtype)
+    out = ops.add_cast(gy, d)
+    assert out.is_contiguous() and torch.equal(out, gy + d.float().view(B, L, 768))
+    with pytest.raises(AssertionError):
+        ops.tanh_residual_bwd(big[:, :L, :767], enc[..., :767], dtype)
+
+
+def test_attention_score_on_a_row_slice_of_a_longer_sequence():
+    """The grounding scorers read the frame / OCR rows in place inside QTV's [question; frames; OCR] output (batch stride)."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    g = torch.Generator().manual_seed(6)
+    B, T, M = 3, 20, 50
+    buf = torch.randn(B, T + M + 7, 768, generator=g).to(DEV)
+    q = torch.randn(B, 768, generator=g).to(DEV) * 0.05
+    mask = (torch.rand(B, M, generator=g) < 0.7).float().to(DEV)
+    view = buf[:, T:T + M]
+    assert torch.equal(ops.attention_score(q, view, mask), ops.attention_score(q, view.contiguous(), mask))

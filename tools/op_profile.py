@@ -46,8 +46,10 @@ print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time
 # where the big copies / adds / fills come from: python stacks of the ops on [B, ~N, 768]-sized operands
 big = {}
 for e in prof.events():
-    if e.name in ("aten::copy_", "aten::add_", "aten::add", "aten::fill_", "aten::cat", "aten::_to_copy", "aten::mul", "aten::tanh") and e.device_time_total > 200:
-        st = [f for f in (e.stack or []) if "vitxt_gqa_amd" in f or "bench" in f or "op_profile" in f][:3]
+    if e.name in ("aten::copy_", "aten::add_", "aten::add", "aten::fill_", "aten::cat", "aten::_to_copy", "aten::mul", "aten::tanh", "aten::sum", "aten::zero_",
+                  "aten::index_select", "aten::index_add_", "aten::gather", "aten::where", "aten::tanh_backward", "aten::native_dropout", "aten::masked_fill_",
+                  "aten::div_", "aten::mul_", "aten::clone", "aten::contiguous", "aten::zeros", "aten::zeros_like", "aten::sub", "aten::neg") and e.device_time_total > 100:
+        st = [f for f in (e.stack or []) if ".py" in f and "torch/" not in f][:4]
         key = (e.name, str(e.input_shapes)[:60], " <- ".join(s.split("/")[-1] for s in st))
         t = big.setdefault(key, [0, 0.0])
         t[0] += 1

@@ -138,17 +138,18 @@ __global__ __launch_bounds__(256) void question_pool_kernel(const float* __restr
 
 // dots[b, m] = q[b] . k[b, m]: one wavefront per key row (12 elements per lane, coalesced)
 template <typename TK>
-__global__ __launch_bounds__(256) void score_dot_kernel(const float* __restrict__ q, const TK* __restrict__ k,
+__global__ __launch_bounds__(256) void score_dot_kernel(const float* __restrict__ q, const TK* __restrict__ k, int64_t k_bs,
                                                         float* __restrict__ dots, int M, int64_t rows) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int b = (int)(row / M);
+  const TK* __restrict__ krow = k + (int64_t)b * k_bs + (row - (int64_t)b * M) * T2S_HIDDEN;       // the M rows of a sample may sit inside a longer sequence
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int e = (i * 64 + lane) * 4;
-    const f32x4 kv = Vec4<TK>::load(k + row * T2S_HIDDEN + e);
+    const f32x4 kv = Vec4<TK>::load(krow + e);
     const f32x4 qv = *reinterpret_cast<const f32x4*>(q + (int64_t)b * T2S_HIDDEN + e);
     s += kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
   }
@@ -355,23 +356,23 @@ extern "C" int t2s_question_pool(const float* qp, const float* w, const float* b
   return 0;
 }
 
-extern "C" int t2s_attention_score(const float* q, const void* k, const float* mask, float* score, int B, int M, int k_dtype,
-                                   t2s_stream_t stream) {
+extern "C" int t2s_attention_score(const float* q, const void* k, int64_t k_batch_stride, const float* mask, float* score, int B, int M,
+                                   int k_dtype, t2s_stream_t stream) {
   T2S_CHECK_ARG(q && k && mask && score, "attention_score: null pointer");
-  T2S_CHECK_ARG(B > 0 && M > 0, "attention_score: bad shape");
+  T2S_CHECK_ARG(B > 0 && M > 0 && k_batch_stride >= (int64_t)M * T2S_HIDDEN && k_batch_stride % 4 == 0, "attention_score: bad shape");
   T2S_CHECK_ARG(k_dtype == T2S_F32 || k_dtype == T2S_BF16, "attention_score: bad dtype %d", k_dtype);
   const int64_t rows = (int64_t)B * M;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (k_dtype == T2S_BF16) hipLaunchKernelGGL(score_dot_kernel<bf16_t>, grid, block, 0, st, q, (const bf16_t*)k, score, M, rows);
-  else hipLaunchKernelGGL(score_dot_kernel<float>, grid, block, 0, st, q, (const float*)k, score, M, rows);
+  if (k_dtype == T2S_BF16) hipLaunchKernelGGL(score_dot_kernel<bf16_t>, grid, block, 0, st, q, (const bf16_t*)k, k_batch_stride, score, M, rows);
+  else hipLaunchKernelGGL(score_dot_kernel<float>, grid, block, 0, st, q, (const float*)k, k_batch_stride, score, M, rows);
   hipLaunchKernelGGL(score_softmax_kernel, dim3(B), block, 0, st, score, mask, M);
   T2S_CHECK_LAUNCH("attention_score");
   return 0;
 }
 
 extern "C" int t2s_ground_select(const float* frame_score, const float* frame_mask, const float* expo_frame, const int64_t* frame_id,
-                                 const float* q_global, const void* ocr_feat, int ocr_dtype, const float* expo_ocr,
+                                 const float* q_global, const void* ocr_feat, int64_t ocr_batch_stride, int ocr_dtype, const float* expo_ocr,
                                  const int64_t* temporal_id, const float* bbox, float* pos_obj_mask, float* neg_obj_mask,
                                  int64_t* ground_frame, float* new_ocr_mask, float* ocr_score, float* pos_ocr_mask,
                                  float* neg_ocr_mask, float* ground_box, int B, int F, int P, int frame_topk, int ocr_topk,
@@ -386,7 +387,7 @@ extern "C" int t2s_ground_select(const float* frame_score, const float* frame_ma
   hipLaunchKernelGGL(select_frames_kernel, dim3(B), dim3(64), 4 * F * sizeof(float), st, frame_score, frame_mask, expo_frame, frame_id,
                      pos_obj_mask, neg_obj_mask, ground_frame, F, frame_topk);
   hipLaunchKernelGGL(new_ocr_mask_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, temporal_id, ground_frame, new_ocr_mask, N, frame_topk);
-  if (int e = t2s_attention_score(q_global, ocr_feat, new_ocr_mask, ocr_score, B, N, ocr_dtype, stream)) return e;
+  if (int e = t2s_attention_score(q_global, ocr_feat, ocr_batch_stride, new_ocr_mask, ocr_score, B, N, ocr_dtype, stream)) return e;
   hipLaunchKernelGGL(select_ocr_kernel, dim3(F, B), dim3(64), 4 * P * sizeof(float), st, ocr_score, new_ocr_mask, expo_ocr, bbox,
                      pos_ocr_mask, neg_ocr_mask, ground_box, F, P, ocr_topk);
   T2S_CHECK_LAUNCH("ground_select");

@@ -221,6 +221,49 @@ class BertLayerFn(torch.autograd.Function):
         return (dx.view(B, L, HID).float(), None, None, None, None, None, None) + _master_grads(g)
 
 
+def _encoder_forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, masters, extra=()):
+    """A stack of layers on x [B, L, 768] fp32; what backward needs goes into ctx (``extra``: further tensors to save).
+    Returns the output rows [B * L, 768] fp32."""
+    B, L, _ = x.shape
+    flat_w = []
+    for l in range(n_layers):
+        flat_w.extend(operand_weights(masters[MASTERS_PER_LAYER * l:MASTERS_PER_LAYER * (l + 1)], dt))
+    x2 = x.contiguous().view(B * L, HID)
+    xl = x2.to(dt) if dt != F32 else x2
+    keep, counts = [], []
+    for l in range(n_layers):
+        x2, x_lo, saved = _layer_forward(x2, xl, keys, B, L, flat_w[12 * l:12 * l + 12], drop_p, seeds[l], attn_drop_p,
+                                         RECOMPUTE_ACTIVATIONS, materialise=(l == n_layers - 1))
+        xl = x_lo if x_lo is not None else x2
+        counts.append([t is not None for t in saved])
+        keep.extend(t for t in saved if t is not None)
+    ctx.keys, ctx.drop, ctx.counts, ctx.n_extra = keys, (drop_p, seeds, attn_drop_p), counts, len(extra)
+    ctx.save_for_backward(*extra, *keep)
+    return x2
+
+
+def _encoder_backward(ctx, d):
+    """d: [B * L, 768] gradient of the stack's output (fp32 or the operand dtype).  Returns (dx [B * L, 768] in the operand
+    dtype, the master gradients of every layer as one flat tuple)."""
+    drop_p, seeds, attn_drop_p = ctx.drop
+    flat = list(ctx.saved_tensors)[ctx.n_extra:]
+    per_layer, pos = [], 0
+    for mask in ctx.counts:
+        cur = []
+        for present in mask:
+            cur.append(flat[pos] if present else None)
+            pos += present
+        per_layer.append(cur)
+    grads = [None] * len(per_layer)
+    for l in reversed(range(len(per_layer))):
+        d, grads[l] = _layer_backward(per_layer[l], ctx.keys, d, drop_p, seeds[l], attn_drop_p)
+        per_layer[l] = None
+    out = ()
+    for g in grads:
+        out += _master_grads(g)
+    return d, out
+
+
 class BertEncoderFn(torch.autograd.Function):
     """y = BertEncoder(x; keys) for a stack of layers as ONE autograd node.  Between layers the backward hands the
     operand-dtype dx of layer l+1 straight to the LayerNorm-backward kernel of layer l; as separate nodes autograd casts
@@ -230,43 +273,39 @@ class BertEncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, *masters):
         B, L, _ = x.shape
-        flat_w = []
-        for l in range(n_layers):
-            flat_w.extend(operand_weights(masters[MASTERS_PER_LAYER * l:MASTERS_PER_LAYER * (l + 1)], dt))
-        x2 = x.contiguous().view(B * L, HID)
-        xl = x2.to(dt) if dt != F32 else x2
-        keep, counts = [], []
-        for l in range(n_layers):
-            x2, x_lo, saved = _layer_forward(x2, xl, keys, B, L, flat_w[12 * l:12 * l + 12], drop_p, seeds[l], attn_drop_p,
-                                             RECOMPUTE_ACTIVATIONS, materialise=(l == n_layers - 1))
-            xl = x_lo if x_lo is not None else x2
-            counts.append([t is not None for t in saved])
-            keep.extend(t for t in saved if t is not None)
-        ctx.keys, ctx.drop, ctx.counts = keys, (drop_p, seeds, attn_drop_p), counts
-        ctx.save_for_backward(*keep)
-        return x2.view(B, L, HID)
+        return _encoder_forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, masters).view(B, L, HID)
 
     @staticmethod
     def backward(ctx, dy):
         B, L, _ = dy.shape
-        drop_p, seeds, attn_drop_p = ctx.drop
-        flat = list(ctx.saved_tensors)
-        per_layer, pos = [], 0
-        for mask in ctx.counts:
-            cur = []
-            for present in mask:
-                cur.append(flat[pos] if present else None)
-                pos += present
-            per_layer.append(cur)
-        d = dy.contiguous().view(B * L, HID)
-        grads = [None] * len(per_layer)
-        for l in reversed(range(len(per_layer))):
-            d, grads[l] = _layer_backward(per_layer[l], ctx.keys, d, drop_p, seeds[l], attn_drop_p)
-            per_layer[l] = None
-        out = (d.view(B, L, HID).float(), None, None, None, None, None, None)
-        for g in grads:
-            out += _master_grads(g)
-        return out
+        d, g = _encoder_backward(ctx, dy.contiguous().view(B * L, HID))
+        return (d.view(B, L, HID).float(), None, None, None, None, None, None) + g
+
+
+class QTVFn(torch.autograd.Function):
+    """y = x + tanh(BertEncoder(x; keys)): QTV.forward (t2s.py:384-432, Q5) on the concatenated [question; frames; OCR] rows as
+    ONE node.  The reference slices the encoder output per modality, applies tanh and adds each slice to its input: as framework
+    ops that is three slice-backward nodes (a zero fill + copy of the full [B, L1, 768] gradient each, then two adds), tanh and
+    add passes, and an fp32 cast + add where the encoder's input gradient meets the residual path.  Here: one pass forward
+    (t2s_tanh_residual_fwd), two backward (g_enc = gy (1 - tanh^2) in the operand dtype; dx = gy + dx_enc), gy read in place
+    even when it arrives as a row slice of the MMT input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, *masters):
+        B, L, _ = x.shape
+        enc = _encoder_forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, masters).view(B, L, HID)
+        ctx.enc, ctx.dt = enc, dt             # a plain attribute: the tensor is this node's own intermediate, nobody else sees it
+        return ops.tanh_residual_fwd(x.contiguous(), enc)
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, L, _ = gy.shape
+        if gy.dtype != F32 or gy.stride(2) != 1 or gy.stride(1) != HID:
+            gy = gy.float().contiguous()
+        g_enc = ops.tanh_residual_bwd(gy, ctx.enc, ctx.dt)
+        d, g = _encoder_backward(ctx, g_enc.view(B * L, HID))
+        del g_enc
+        return (ops.add_cast(gy, d), None, None, None, None, None, None) + g
 
 
 class SharedPrefixEncoderFn(torch.autograd.Function):
@@ -278,7 +317,8 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
     (one GEMM over the rows instead of three); in backward the three passes' gradients of that projection are summed first and
     its weight / input gradients are computed once, and the input gradient of the sequence is accumulated here instead of by
     three autograd adds.  24 extra rows per sample ride along in every pass (+0.24 % of the row work at L1 = 10 120).
-    Returns one [B, L, 768] output per pass (the caller reads the OCR rows and the pass's own decoder rows)."""
+    Returns one [B, L, 768] fp32 output per pass (the caller reads the OCR rows and the pass's own decoder rows), followed - in
+    the bf16 operand mode - by the bf16 copy of each (the last LayerNorm kernel writes both)."""
 
     @staticmethod
     def forward(ctx, x, keys_list, n_layers, dt, drop_p, seeds_list, attn_drop_p, *masters):
@@ -289,7 +329,7 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
         x2 = x.contiguous().view(B * L, HID)
         xl = x2.to(dt) if dt != F32 else x2
         qkv0 = _mm_bias(xl, flat_w[0], flat_w[1]).view(B, L, 3 * HID)
-        keep, counts, outs = [], [], []
+        keep, counts, outs, los = [], [], [], []
         for keys, seeds in zip(keys_list, seeds_list):
             c2, cl = x2, xl
             for l in range(n_layers):
@@ -302,9 +342,12 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
                 counts.append([t is not None for t in saved])
                 keep.extend(t for t in saved if t is not None)
             outs.append(c2.view(B, L, HID))
+            if dt != F32:
+                los.append(cl.view(B, L, HID))
         ctx.keys_list, ctx.drop, ctx.counts, ctx.n_layers = keys_list, (drop_p, seeds_list, attn_drop_p), counts, n_layers
         ctx.save_for_backward(xl, qkv0, *keep)
-        return tuple(outs)
+        # operand-dtype mode: the bf16 copies of the outputs follow the fp32 outputs; a consumer may send its gradient through either
+        return tuple(outs) + tuple(los)
 
     @staticmethod
     def backward(ctx, *dys):
@@ -324,10 +367,16 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
         w_qkv0 = per[0][9]                 # the fused QKV operand weight of layer 0 (same tensor in every pass's list)
         grads = [None] * n_layers          # parameter gradients summed over the passes, per layer (12-tuples, fp32)
         dz1_sum = dqkv_sum = None
+        n_pass = len(ctx.keys_list)
         for pi, (keys, seeds) in enumerate(zip(ctx.keys_list, seeds_list)):
             dy = dys[pi]
-            if dy is None:
+            d_lo = dys[n_pass + pi] if len(dys) > n_pass else None
+            if dy is None and d_lo is None:
                 continue
+            if dy is None:
+                dy = d_lo                    # the whole gradient of this pass came through the operand-dtype copy (PassHeadFn)
+            elif d_lo is not None:
+                dy = dy + d_lo.to(dy.dtype)
             d = dy.contiguous().view(B * L, HID)
             for l in reversed(range(n_layers)):
                 saved = per[pi * n_layers + l]
@@ -414,6 +463,50 @@ class PtrLogitsFn(torch.autograd.Function):
         dq = torch.bmm(dsl, k).float()                                    # [B, D, 768]
         dk = torch.bmm(dsl.transpose(1, 2), q.to(k.dtype))                # [B, N, 768]
         return dlogits[:, :, :V], dq, dk, None
+
+
+class PassHeadFn(torch.autograd.Function):
+    """What the heads of one MMT pass read from its encoder output (t2s.py:628-631 -> :279-286, :648-670): the pointer-network
+    KEYS k = Linear_key(out[:, a:b]) of the OCR rows and the decoder rows out[:, d0:d1].  ``out_lo`` is the operand-dtype copy of
+    ``out`` that the last LayerNorm kernel wrote anyway: the key projection reads its OCR rows in place (a batched GEMM over the
+    row slice; no cast of 2 GB of fp32 rows, no contiguous copy), and in backward the input gradient dk W_key is written by the
+    GEMM straight into rows [a, b) of ONE [B, L, 768] operand-dtype buffer that also takes the decoder rows' gradient - instead
+    of a bf16 -> fp32 cast, a slice copy and zero fills per pass.  The gradient leaves through ``out_lo`` when it is given."""
+
+    @staticmethod
+    def forward(ctx, out, out_lo, w_key, b_key, a, b, d0, d1):
+        src = out_lo if out_lo is not None else out
+        B, L, _ = src.shape
+        wk = w_key.detach().to(src.dtype)
+        rows = src[:, a:b]
+        k = torch.baddbmm(b_key.detach().to(src.dtype), rows, wk.t().unsqueeze(0).expand(B, HID, wk.shape[0]))
+        ctx.save_for_backward(src, wk)
+        ctx.geom = (a, b, d0, d1, out_lo is not None)
+        return k, out[:, d0:d1]
+
+    @staticmethod
+    def backward(ctx, g_k, g_dec):
+        src, wk = ctx.saved_tensors
+        a, b, d0, d1, via_lo = ctx.geom
+        B, L, _ = src.shape
+        g = torch.empty(B, L, HID, dtype=src.dtype, device=src.device)
+        g[:, :a].zero_()
+        g[:, b:].zero_()
+        dw = db = None
+        if g_k is not None:
+            g_k = g_k.contiguous()
+            torch.bmm(g_k, wk.unsqueeze(0).expand(B, wk.shape[0], HID), out=g[:, a:b])
+            dw = torch.bmm(g_k.transpose(1, 2), src[:, a:b]).sum(0, dtype=F32)
+            db = g_k.sum((0, 1), dtype=F32)
+        else:
+            g[:, a:b].zero_()
+        if g_dec is not None:
+            g[:, d0:d1] = g_dec
+        return (None, g, dw, db, None, None, None, None) if via_lo else (g, None, dw, db, None, None, None, None)
+
+
+def pass_head(out, out_lo, key_linear, a, b, d0, d1):
+    return PassHeadFn.apply(out, out_lo, key_linear.weight, key_linear.bias, a, b, d0, d1)
 
 
 class EmbedRowsFn(torch.autograd.Function):
@@ -507,16 +600,30 @@ def bert_encoder(x, keys, layers, dtype, hidden_dropout=0.0, attn_dropout=0.0):
     return BertEncoderFn.apply(x, keys, len(layers), dtype, float(hidden_dropout), seeds, float(attn_dropout), *masters)
 
 
+def qtv_encoder(x, keys, layers, dtype, hidden_dropout=0.0, attn_dropout=0.0):
+    """x + tanh(BertEncoder(x)) on fp32 [B, L, 768] (QTVFn)."""
+    layers = list(layers)
+    masters = []
+    for lp in layers:
+        masters.extend(layer_masters(lp))
+    drop = hidden_dropout > 0 or attn_dropout > 0
+    seeds = tuple((_fresh_seed(), _fresh_seed(), _fresh_seed()) if drop else (0, 0, 0) for _ in layers)
+    return QTVFn.apply(x, keys, len(layers), dtype, float(hidden_dropout), seeds, float(attn_dropout), *masters)
+
+
 def shared_prefix_encoder(x, keys_list, layers, dtype, hidden_dropout=0.0, attn_dropout=0.0):
     """x: fp32 [B, L1 + n_pass * D, 768] = [prefix | decoder rows of each pass]; keys_list[i]: the key list of pass i (its decoder
-    rows at L1 + i * D).  Returns one fp32 [B, L, 768] per pass (SharedPrefixEncoderFn)."""
+    rows at L1 + i * D).  Returns a list of (out fp32 [B, L, 768], out_lo = its operand-dtype copy or None) per pass
+    (SharedPrefixEncoderFn)."""
     layers = list(layers)
     masters = []
     for lp in layers:
         masters.extend(layer_masters(lp))
     drop = hidden_dropout > 0 or attn_dropout > 0
     seeds_list = tuple(tuple((_fresh_seed(), _fresh_seed(), _fresh_seed()) if drop else (0, 0, 0) for _ in layers) for _ in keys_list)
-    return SharedPrefixEncoderFn.apply(x, tuple(keys_list), len(layers), dtype, float(hidden_dropout), seeds_list, float(attn_dropout), *masters)
+    res = SharedPrefixEncoderFn.apply(x, tuple(keys_list), len(layers), dtype, float(hidden_dropout), seeds_list, float(attn_dropout), *masters)
+    n = len(keys_list)
+    return [(res[i], res[n + i] if len(res) > n else None) for i in range(n)]
 
 
 # ------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2S_HIP_LIB") or os.path.join(_HERE, "libt2s_hip.so")      # override: kernel build experiments only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 T2S_F32, T2S_BF16 = 0, 1
 
@@ -36,8 +36,11 @@ _SIGS = {
     "t2s_gelu_bwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
     "t2s_ptr_scores": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64, c_int, c_float, c_int, c_int, c_void_p]),
     "t2s_question_pool": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
-    "t2s_attention_score": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p]),
-    "t2s_ground_select": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
+    "t2s_attention_score": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "t2s_ground_select": (c_int, [c_void_p] * 6 + [c_int64, c_int] + [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
+    "t2s_tanh_residual_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "t2s_tanh_residual_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    "t2s_add_cast": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p]),
     "t2s_embed_rows": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "t2s_bce_masked": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),
     "t2s_infonce_stats": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p]),

@@ -321,15 +321,52 @@ def question_pool(qp, w, bias, qmask):
     return out
 
 
-def attention_score(q, k, mask):
-    """q: [B, 768] fp32, k: [B, M, 768], mask: [B, M] fp32 -> [B, M] fp32 (spatio_temporal_grounding.py:15-23)."""
+def _rows_view(k):
+    """[B, M, 768] with contiguous rows; the samples may be slices of a longer sequence (batch stride >= M * 768)."""
     B, M, _ = k.shape
-    assert q.shape == (B, HID) and q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous()
+    assert k.shape[2] == HID and k.stride(2) == 1 and k.stride(1) == HID and (B == 1 or k.stride(0) >= M * HID), \
+        "expected [B, M, 768] with dense rows, got strides %s" % (k.stride(),)
+    return k.stride(0) if B > 1 else M * HID
+
+
+def attention_score(q, k, mask):
+    """q: [B, 768] fp32, k: [B, M, 768] (a row slice of a longer [B, L, 768] buffer is fine), mask: [B, M] fp32 -> [B, M] fp32
+    (spatio_temporal_grounding.py:15-23)."""
+    B, M, _ = k.shape
+    assert q.shape == (B, HID) and q.dtype == torch.float32 and q.is_contiguous()
     assert mask.shape == (B, M) and mask.dtype == torch.float32 and mask.is_contiguous()
     score = torch.empty(B, M, dtype=torch.float32, device=k.device)
-    X.check(X.lib().t2s_attention_score(X.ptr(q), X.ptr(k), X.ptr(mask), X.ptr(score), B, M, X.dtype_code(k), X.stream()),
+    X.check(X.lib().t2s_attention_score(X.ptr(q), X.ptr(k), _rows_view(k), X.ptr(mask), X.ptr(score), B, M, X.dtype_code(k), X.stream()),
             "t2s_attention_score")
     return score
+
+
+def tanh_residual_fwd(x, enc_out):
+    """x + tanh(enc_out): [B, L, 768] fp32 contiguous (QTV's residual, t2s.py:428-432)."""
+    B, L, _ = x.shape
+    assert x.shape == enc_out.shape and x.shape[2] == HID and x.dtype == enc_out.dtype == torch.float32 and x.is_contiguous() and enc_out.is_contiguous()
+    y = torch.empty_like(x)
+    X.check(X.lib().t2s_tanh_residual_fwd(X.ptr(x), X.ptr(enc_out), X.ptr(y), B, L, L * HID, X.stream()), "t2s_tanh_residual_fwd")
+    return y
+
+
+def tanh_residual_bwd(gy, enc_out, out_dtype):
+    """gy * (1 - tanh(enc_out)^2) -> [B, L, 768] in out_dtype; gy fp32, possibly a row slice of a longer buffer."""
+    B, L, _ = enc_out.shape
+    assert gy.shape == enc_out.shape and gy.dtype == torch.float32 and enc_out.dtype == torch.float32 and enc_out.is_contiguous()
+    g = torch.empty(B, L, HID, dtype=out_dtype, device=gy.device)
+    X.check(X.lib().t2s_tanh_residual_bwd(X.ptr(gy), _rows_view(gy), X.ptr(enc_out), X.ptr(g), X.dtype_code(g), B, L, X.stream()),
+            "t2s_tanh_residual_bwd")
+    return g
+
+
+def add_cast(a, b):
+    """a (fp32 [B, L, 768], possibly a row slice of a longer buffer) + b (contiguous, fp32 or bf16) -> fp32 contiguous."""
+    B, L, _ = a.shape
+    assert a.dtype == torch.float32 and b.numel() == a.numel() and b.is_contiguous()
+    out = torch.empty(B, L, HID, dtype=torch.float32, device=a.device)
+    X.check(X.lib().t2s_add_cast(X.ptr(a), _rows_view(a), X.ptr(b), X.dtype_code(b), X.ptr(out), B, L, X.stream()), "t2s_add_cast")
+    return out
 
 
 def ground_select(frame_score, frame_mask, expo_frame, frame_id, q_global, ocr_feat, expo_ocr, temporal_id, bbox,
@@ -348,7 +385,7 @@ def ground_select(frame_score, frame_mask, expo_frame, frame_id, q_global, ocr_f
     assert frame_id.dtype == torch.int64 and temporal_id.dtype == torch.int64 and temporal_id.shape == (B, N)
     for t in (frame_score, frame_mask, expo_frame, expo_ocr, q_global, bbox):
         assert t.dtype == torch.float32 and t.is_contiguous()
-    assert ocr_feat.is_contiguous() and frame_id.is_contiguous() and temporal_id.is_contiguous()
+    assert frame_id.is_contiguous() and temporal_id.is_contiguous()
     o = dict(pos_obj_mask=torch.empty(B, F, **f32), neg_obj_mask=torch.empty(B, F, **f32),
              ground_frame=torch.empty(B, frame_topk, dtype=torch.int64, device=dev),
              new_ocr_mask=torch.empty(B, N, **f32), ocr_score=torch.empty(B, N, **f32),
@@ -356,7 +393,7 @@ def ground_select(frame_score, frame_mask, expo_frame, frame_id, q_global, ocr_f
              ground_box=torch.empty(B, F * ocr_topk, 4, **f32))
     X.check(X.lib().t2s_ground_select(
         X.ptr(frame_score), X.ptr(frame_mask), X.ptr(expo_frame), X.ptr(frame_id), X.ptr(q_global), X.ptr(ocr_feat),
-        X.dtype_code(ocr_feat), X.ptr(expo_ocr), X.ptr(temporal_id), X.ptr(bbox), X.ptr(o["pos_obj_mask"]),
+        _rows_view(ocr_feat), X.dtype_code(ocr_feat), X.ptr(expo_ocr), X.ptr(temporal_id), X.ptr(bbox), X.ptr(o["pos_obj_mask"]),
         X.ptr(o["neg_obj_mask"]), X.ptr(o["ground_frame"]), X.ptr(o["new_ocr_mask"]), X.ptr(o["ocr_score"]),
         X.ptr(o["pos_ocr_mask"]), X.ptr(o["neg_ocr_mask"]), X.ptr(o["ground_box"]), B, F, P, frame_topk, ocr_topk,
         X.stream()), "t2s_ground_select")

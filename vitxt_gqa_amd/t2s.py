@@ -155,11 +155,12 @@ class QTV(nn.Module):
         txt, obj, ocr = fwd["txt_emb"], fwd["obj_mmt_in"], fwd["ocr_mmt_in"]
         x = torch.cat([txt, obj, ocr], dim=1)
         valid = torch.cat([fwd["txt_mask"] > 0, fwd["obj_mask"] > 0, fwd["ocr_mask"] > 0], dim=1)
-        out = FN.bert_encoder(x, ops.compact_keys(valid), self.encoder.layer, dtype, *_train_dropout(self))
+        # x + tanh(encoder(x)) per modality (t2s.py:428-432) as one node on the concatenated rows; the three results are row
+        # slices of ONE [B, L1, 768] tensor, which the MMT passes take whole (``qtv_out``) as the prefix of their sequence
+        y = FN.qtv_encoder(x, ops.compact_keys(valid), self.encoder.layer, dtype, *_train_dropout(self))
         T, Fn = txt.size(1), obj.size(1)
-        fwd["txt_emb"] = txt + torch.tanh(out[:, :T])
-        fwd["obj_mmt_in"] = obj + torch.tanh(out[:, T:T + Fn])
-        fwd["ocr_mmt_in"] = ocr + torch.tanh(out[:, T + Fn:])
+        fwd["qtv_out"] = y
+        fwd["txt_emb"], fwd["obj_mmt_in"], fwd["ocr_mmt_in"] = y[:, :T], y[:, T:T + Fn], y[:, T + Fn:]
 
 
 class _AttentionScoreParams(nn.Module):
@@ -213,9 +214,10 @@ class Grounding_Module(nn.Module):
         # scorer, per-frame OCR top-k, boxes (spatio_temporal_grounding.py:15-142, t2s.py:486-494) on the HIP kernels
         P, ot, k = self.frame_ocr_num, self.ocr_topk, self.frame_topk
         assert Fn == self.frame_num and N == self.frame_num * P, "OCR slots must equal frame_num * ocr_frame_num"
-        f_score = ops.attention_score(gq, frame_feat.contiguous(), frame_mask.contiguous())
+        # (frame_feat / ocr_feat are row slices of QTV's one output tensor: the scorer kernels take the batch stride)
+        f_score = ops.attention_score(gq, frame_feat, frame_mask.contiguous())
         sel = ops.ground_select(f_score, frame_mask.contiguous(), e1.contiguous(), sample_list.frame_id.contiguous(), gq,
-                                ocr_feat.contiguous(), e2.contiguous(), sample_list.temporal_id.contiguous(),
+                                ocr_feat, e2.contiguous(), sample_list.temporal_id.contiguous(),
                                 sample_list.ocr_bbox_coordinates.float().contiguous(), Fn, P, k, ot)
         ground_frame, ground_box = sel["ground_frame"], sel["ground_box"]
         o_score, new_mask = sel["ocr_score"], sel["new_ocr_mask"]
@@ -264,7 +266,7 @@ class PrevPredEmbeddings(nn.Module):
         self.ocr_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
         self.emb_layer_norm = nn.LayerNorm(HID, eps=LN_EPS)
 
-    def forward(self, ans_emb, ocr_emb, prev_inds, dtype, emb_dropout=0.0, draws=None):
+    def forward(self, ans_emb, ocr_emb, prev_inds, dtype, emb_dropout=0.0, draws=None, ocr_row0=0):
         """``draws`` = n: a list of n results that share the gathered rows and differ in the dropout draw of the position /
         type embedding only - the three MMT passes of a train step call this with the same inputs (t2s.py:293-313), and each
         separate call costs a [B, N, 768] zero fill + scatter + accumulation in the backward of its OCR-row gather."""
@@ -274,7 +276,10 @@ class PrevPredEmbeddings(nn.Module):
         V = ans_emb.size(0)
         is_ocr = prev_inds.ge(V)
         ans_rows = ans_emb[prev_inds.clamp(max=V - 1)]                                            # [B, D, 768] fp32
-        ocr_idx = (prev_inds - V).clamp(min=0)
+        # ``ocr_emb`` may be the whole [question; frames; OCR] prefix with the OCR rows starting at ``ocr_row0``: gathering from the
+        # tensor the passes also take whole keeps its gradient one accumulation (a gather from a row slice adds a slice-backward
+        # node: a zero fill + copy of the full gradient)
+        ocr_idx = (prev_inds - V).clamp(min=0) + ocr_row0
         ocr_rows = torch.gather(ocr_emb, 1, ocr_idx.unsqueeze(-1).expand(-1, -1, HID))
         ans_n = FN.layer_norm(ans_rows, self.ans_layer_norm.weight, self.ans_layer_norm.bias)
         ocr_n = FN.layer_norm(ocr_rows, self.ocr_layer_norm.weight, self.ocr_layer_norm.bias)
@@ -316,7 +321,7 @@ class MMT(nn.Module):
         return FN.split_rows(out, T + Fn, L1)
 
     def forward_shared_prefix(self, txt_emb, txt_mask, obj_emb, obj_masks, ocr_emb, ocr_masks, fixed_ans_emb, prev_inds, dtype,
-                              max_keys=None):
+                              max_keys=None, prefix=None):
         """The reference's three MMT calls of one train step (ref / pos / neg masks, t2s.py:293-313) over ONE sequence
         [q; frames; OCR | dec(ref) | dec(pos) | dec(neg)]: the prefix rows are identical in the three calls, so they are
         concatenated, cast and projected to layer 0's Q/K/V once, and their input gradients are accumulated in one place
@@ -326,22 +331,24 @@ class MMT(nn.Module):
         pd, pa = _train_dropout(self)
         T, Fn, N = txt_emb.size(1), obj_emb.size(1), ocr_emb.size(1)
         L1 = T + Fn + N
-        decs = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd, draws=len(obj_masks))
+        # ``prefix``: [q; frames; OCR] as ONE tensor (QTV's output, of which txt_emb / obj_emb / ocr_emb are row slices)
+        if prefix is not None:
+            decs = self.prev_pred_embeddings(fixed_ans_emb, prefix, prev_inds, dtype, pd, draws=len(obj_masks), ocr_row0=T + Fn)
+        else:
+            decs = self.prev_pred_embeddings(fixed_ans_emb, ocr_emb, prev_inds, dtype, pd, draws=len(obj_masks))
         if self.kept_dec_emb is not None:
             self.kept_dec_emb.extend(decs)
         D = decs[0].size(1)
-        x = torch.cat([txt_emb, obj_emb, ocr_emb] + decs, dim=1)
+        x = torch.cat(([prefix] if prefix is not None else [txt_emb, obj_emb, ocr_emb]) + decs, dim=1)
         keys = []
         for i, (om, cm) in enumerate(zip(obj_masks, ocr_masks)):
             valid = torch.cat([txt_mask > 0, om > 0, cm > 0], dim=1)
             keys.append(ops.compact_keys(valid, n_dec=D, dec_row0=L1 + i * D, cap_hint=None if max_keys is None else max_keys[i]))
             keys[-1].bound_is_structural = max_keys is not None and max_keys[i] is not None
+        # per pass: (encoder output fp32 [B, L, 768], its operand-dtype copy or None, first OCR row, end of the prefix, the pass's
+        # decoder rows) - the heads read it through functional.pass_head
         outs = FN.shared_prefix_encoder(x, keys, self.encoder.layer, dtype, pd, pa)
-        res = []
-        for i, out in enumerate(outs):
-            ocr_out, tail = FN.split_rows(out, T + Fn, L1)
-            res.append((ocr_out, tail[:, i * D:(i + 1) * D]))
-        return res
+        return [(out, out_lo, T + Fn, L1, L1 + i * D, L1 + (i + 1) * D) for i, (out, out_lo) in enumerate(outs)]
 
     def forward_passes(self, txt_emb, txt_mask, obj_emb, obj_masks, ocr_emb, ocr_masks, fixed_ans_emb, prev_inds, dtype):
         """The reference's three MMT calls of one train step (ref / pos / neg masks, t2s.py:293-313) as ONE encoder call on
@@ -553,10 +560,14 @@ class T2S(BaseModel):
         if self.training and self.share_mmt_prefix and not self.batch_mmt_passes:
             outs = self.mmt.forward_shared_prefix(fwd["txt_emb"], fwd["txt_mask"], fwd["obj_mmt_in"], [p[1] for p in passes],
                                                   fwd["ocr_mmt_in"], [p[2] for p in passes], self.classifier.module.weight, prev_inds, dt,
-                                                  max_keys=[bounds[p[0]] for p in passes])
-            for (name, _, cm), (ocr_out, dec_out) in zip(passes, outs):
-                fwd[name + "_scores"] = self._forward_output(ocr_out, dec_out, cm, dt)
-                self._keep_pass(fwd, name, ocr_out, dec_out, -3 + ("ref", "pos", "neg").index(name))
+                                                  max_keys=[bounds[p[0]] for p in passes], prefix=fwd.get("qtv_out"))
+            for (name, _, cm), (out, out_lo, a, b, d0, d1) in zip(passes, outs):
+                # pointer-network keys straight from the operand-dtype copy of the encoder output + the decoder rows (one node)
+                k_ptr, dec_out = FN.pass_head(out, out_lo, self.ocr_ptr_net.key, a, b, d0, d1)
+                fixed = F.linear(dec_out, self.classifier.module.weight, self.classifier.module.bias)      # fp32, 12 rows/sample
+                q = F.linear(dec_out, self.ocr_ptr_net.query.weight, self.ocr_ptr_net.query.bias)
+                fwd[name + "_scores"] = FN.ptr_logits(fixed, q, k_ptr, cm.float())
+                self._keep_pass(fwd, name, out[:, a:b], dec_out, -3 + ("ref", "pos", "neg").index(name))
             return
         if self.training and self.batch_mmt_passes:
             outs = self.mmt.forward_passes(fwd["txt_emb"], fwd["txt_mask"], fwd["obj_mmt_in"], [p[1] for p in passes],
