@@ -468,18 +468,20 @@ class PtrLogitsFn(torch.autograd.Function):
 class PassHeadFn(torch.autograd.Function):
     """What the heads of one MMT pass read from its encoder output (t2s.py:628-631 -> :279-286, :648-670): the pointer-network
     KEYS k = Linear_key(out[:, a:b]) of the OCR rows and the decoder rows out[:, d0:d1].  ``out_lo`` is the operand-dtype copy of
-    ``out`` that the last LayerNorm kernel wrote anyway: the key projection reads its OCR rows in place (a batched GEMM over the
-    row slice; no cast of 2 GB of fp32 rows, no contiguous copy), and in backward the input gradient dk W_key is written by the
-    GEMM straight into rows [a, b) of ONE [B, L, 768] operand-dtype buffer that also takes the decoder rows' gradient - instead
-    of a bf16 -> fp32 cast, a slice copy and zero fills per pass.  The gradient leaves through ``out_lo`` when it is given."""
+    ``out`` that the last LayerNorm kernel wrote anyway: the key projection reads its OCR rows from it (one bf16 row copy instead
+    of a cast of 2 GB of fp32 rows), and in backward the input gradient dk W_key goes into rows [a, b) of ONE [B, L, 768]
+    operand-dtype buffer that also takes the decoder rows' gradient - instead of a bf16 -> fp32 cast, an fp32 slice copy and zero
+    fills per pass.  The gradient leaves through ``out_lo`` when it is given.
+    (The GEMMs run on contiguous [B * N, 768] row copies: a batched GEMM straight on the row slice - batch stride L * 768, weight
+    broadcast with batch stride 0 - returned wrong values from the library at B=64, N=10 000: tools/glue_probe.py.)"""
 
     @staticmethod
     def forward(ctx, out, out_lo, w_key, b_key, a, b, d0, d1):
         src = out_lo if out_lo is not None else out
         B, L, _ = src.shape
         wk = w_key.detach().to(src.dtype)
-        rows = src[:, a:b]
-        k = torch.baddbmm(b_key.detach().to(src.dtype), rows, wk.t().unsqueeze(0).expand(B, HID, wk.shape[0]))
+        rows = src[:, a:b].reshape(B * (b - a), HID)
+        k = torch.addmm(b_key.detach().to(src.dtype), rows, wk.t()).view(B, b - a, wk.shape[0])
         ctx.save_for_backward(src, wk)
         ctx.geom = (a, b, d0, d1, out_lo is not None)
         return k, out[:, d0:d1]
@@ -494,10 +496,10 @@ class PassHeadFn(torch.autograd.Function):
         g[:, b:].zero_()
         dw = db = None
         if g_k is not None:
-            g_k = g_k.contiguous()
-            torch.bmm(g_k, wk.unsqueeze(0).expand(B, wk.shape[0], HID), out=g[:, a:b])
-            dw = torch.bmm(g_k.transpose(1, 2), src[:, a:b]).sum(0, dtype=F32)
-            db = g_k.sum((0, 1), dtype=F32)
+            gk2 = g_k.contiguous().view(B * (b - a), wk.shape[0])
+            g[:, a:b].copy_((gk2 @ wk).view(B, b - a, HID))
+            dw = _wgrad(gk2, src[:, a:b].reshape(B * (b - a), HID), B)
+            db = gk2.sum(0, dtype=F32)
         else:
             g[:, a:b].zero_()
         if g_dec is not None:
