@@ -231,6 +231,20 @@ int t2s_tanh_residual_bwd(const float* gy, int64_t gy_batch_stride, const float*
 int t2s_add_cast(const float* a, int64_t a_batch_stride, const void* b, int b_dtype, float* out, int64_t B,
                  int64_t rows, t2s_stream_t stream);
 
+/* ---- tail of the OCR-token encoding, T2S._forward_ocr_encoding pythia/models/t2s.py:221-258:
+ *   out = dropout(LN_feat(a) + LN_bbox(bbox W_box^T + b_box))   with a [rows, 768] = linear_ocr_feat_to_mmt_in(...) (a_dtype),
+ * bbox [rows, 4] fp32, W_box [768, 4] / b_box [768] = linear_ocr_bbox_to_mmt_in, the two LayerNorm affines fp32; out [rows, 768]
+ * fp32, stats [rows, 4] = (mean_a, rstd_a, mean_b, rstd_b).  Backward: d_a [rows, 768] in a_dtype and partial sums
+ * part [t2s_ocr_tail_parts(rows), 9, 768] fp32 = dgamma_a | dbeta_a | dgamma_b | dbeta_b | db_box | dW_box[:, 0..3]
+ * (the caller sums over the first axis).  Dropout: the stateless mask of t2s_dropout_mask over element indices row * 768 + col. */
+int t2s_ocr_tail_parts(int64_t rows);
+int t2s_ocr_tail_fwd(const void* a, int a_dtype, const float* bbox, const float* w_box, const float* b_box,
+                     const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b, float* out,
+                     float* stats, int64_t rows, float eps, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
+int t2s_ocr_tail_bwd(const float* g_out, const void* a, int a_dtype, const float* bbox, const float* w_box,
+                     const float* b_box, const float* gamma_a, const float* gamma_b, const float* stats, void* d_a,
+                     float* part, int64_t rows, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
+
 /* ---- losses (pythia/modules/losses.py).
  * t2s_bce_masked: POSBCEWithMaskLoss.forward :329-343.  scores/targets/grad: [rows, cols] fp32,
  *   row_mask: [rows]; row_loss[r] = mask[r] * sum_c BCEWithLogits(x, t); grad = (sigmoid(x)-t)*mask[r]

@@ -494,3 +494,35 @@ def test_attention_score_on_a_row_slice_of_a_longer_sequence():
     mask = (torch.rand(B, M, generator=g) < 0.7).float().to(DEV)
     view = buf[:, T:T + M]
     assert torch.equal(ops.attention_score(q, view, mask), ops.attention_score(q, view.contiguous(), mask))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("drop_p", [0.0, 0.25])
+def test_ocr_encoding_tail_matches_the_framework_ops(dtype, tol, drop_p):
+    """t2s_ocr_tail_fwd / _bwd against the ops of T2S._forward_ocr_encoding they replace (t2s.py:249-257): LN(a) + LN(Linear(bbox)),
+    dropout with the exported mask; every gradient (a, the two LayerNorm affines, the box weight and bias) against autograd."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rows, seed = 1037, 987654
+    a = (torch.randn(rows, 768, generator=g) * 0.7 + 0.1).to(DEV).to(dtype)
+    bbox = torch.rand(rows, 4, generator=g).to(DEV)
+    wb = (torch.randn(768, 4, generator=g) * 0.5).to(DEV)
+    bb = (torch.randn(768, generator=g) * 0.1).to(DEV)
+    ga, gb = [(1 + 0.1 * torch.randn(768, generator=g)).to(DEV) for _ in range(2)]
+    ba, be = [(0.1 * torch.randn(768, generator=g)).to(DEV) for _ in range(2)]
+    gout = torch.randn(rows, 768, generator=g).to(DEV)
+    out, stats = ops.ocr_tail_fwd(a, bbox, wb, bb, ga, ba, gb, be, drop_p=drop_p, drop_seed=seed)
+    keep = ops.dropout_mask(rows * 768, drop_p, seed, DEV).view(rows, 768).double() / (1 - drop_p) if drop_p else 1.0
+    P = [t.double().requires_grad_(True) for t in (a, wb, bb, ga, ba, gb, be)]
+    ar, wbr, bbr, gar, bar_, gbr, ber = P
+    ln = lambda x, w, b: (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-12) * w + b
+    ref = (ln(ar, gar, bar_) + ln(bbox.double() @ wbr.t() + bbr, gbr, ber)) * keep
+    assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    grads = torch.autograd.grad(ref, P, gout.double())
+    d_a, dga, dba, dgb, dbe, db_box, dw_box = ops.ocr_tail_bwd(gout, a, bbox, wb, bb, ga, gb, stats, drop_p=drop_p, drop_seed=seed)
+    assert d_a.dtype == dtype and (d_a.double() - grads[0]).abs().max().item() < tol * max(1.0, grads[0].abs().max().item())
+    for name, got, want in (("dw_box", dw_box, grads[1]), ("db_box", db_box, grads[2]), ("dga", dga, grads[3]), ("dba", dba, grads[4]),
+                            ("dgb", dgb, grads[5]), ("dbe", dbe, grads[6])):
+        assert got.shape == want.shape, name
+        assert (got.double() - want).norm().item() < 1e-4 * want.norm().item() + 1e-6, name

@@ -173,6 +173,160 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const TDY* __res
   }
 }
 
+// ---- tail of the OCR-token encoding (T2S._forward_ocr_encoding, pythia/models/t2s.py:221-258):
+//   out = dropout( LN_feat(a) + LN_bbox(bbox W_b^T + b_b) )
+// with a [rows, 768] the output of linear_ocr_feat_to_mmt_in (a library GEMM) and bbox [rows, 4].  As framework ops this is two
+// LayerNorm calls (each keeping an fp32 copy of its input for backward), a K = 4 "GEMM" that writes 2 GB of fp32, an add and a
+// dropout: ~26 GB of HBM traffic at B=64 forward and about as much backward.  Here the 768-wide box projection is recomputed per
+// row from its 4 inputs (48 weights per lane in registers), both rows are normalised in registers, and one fp32 row is written:
+// 1 (bf16 a) + 2 GB.  Backward reads the output gradient and a once, rebuilds both normalised rows, writes the gradient of a and
+// accumulates the six parameter gradients (LN affines, box weight and bias) in registers across a grid-stride loop.
+struct TailStats { float mean_a, rstd_a, mean_b, rstd_b; };
+
+template <typename TA>
+__global__ __launch_bounds__(256) void ocr_tail_fwd_kernel(const TA* __restrict__ a, const float* __restrict__ bbox, const float* __restrict__ wb,
+                                                           const float* __restrict__ bb, const float* __restrict__ ga, const float* __restrict__ ba,
+                                                           const float* __restrict__ gb, const float* __restrict__ bb2, float* __restrict__ out,
+                                                           float* __restrict__ stats, int64_t rows, float eps, DropCfg drop) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // this lane's 12 columns: c = (i * 64 + lane) * 4 + j.  W_b is [768, 4] row-major: the 4 weights of a column are one float4
+  f32x4 w[3][4], bias[3], gA[3], bA[3], gB[3], bB[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[i][j] = *reinterpret_cast<const f32x4*>(wb + (e + j) * 4);
+    bias[i] = *reinterpret_cast<const f32x4*>(bb + e);
+    gA[i] = *reinterpret_cast<const f32x4*>(ga + e);
+    bA[i] = *reinterpret_cast<const f32x4*>(ba + e);
+    gB[i] = *reinterpret_cast<const f32x4*>(gb + e);
+    bB[i] = *reinterpret_cast<const f32x4*>(bb2 + e);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+    const f32x4 x4 = *reinterpret_cast<const f32x4*>(bbox + row * 4);
+    f32x4 va[3], vb[3];
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      va[i] = Vec4<TA>::load(a + row * H + (i * 64 + lane) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // nn.Linear: sum_k x[k] W[c, k] + b[c], accumulated in k order like the library's K = 4 dot product
+        vb[i][j] = fmaf(x4[3], w[i][j][3], fmaf(x4[2], w[i][j][2], fmaf(x4[1], w[i][j][1], x4[0] * w[i][j][0]))) + bias[i][j];
+        sa += va[i][j];
+        sb += vb[i][j];
+      }
+    }
+    const float ma = wave_sum(sa) * (1.f / H), mb = wave_sum(sb) * (1.f / H);
+    float qa = 0.f, qb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float da = va[i][j] - ma, db = vb[i][j] - mb;
+        qa += da * da;
+        qb += db * db;
+      }
+    const float ra = 1.f / sqrtf(wave_sum(qa) * (1.f / H) + eps), rb = 1.f / sqrtf(wave_sum(qb) * (1.f / H) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = ((va[i][j] - ma) * ra * gA[i][j] + bA[i][j]) + ((vb[i][j] - mb) * rb * gB[i][j] + bB[i][j]);
+        if (drop.thresh) o[j] *= drop_keep_scale(drop, (uint32_t)(row * H + e + j));
+      }
+      *reinterpret_cast<f32x4*>(out + row * H + e) = o;
+    }
+    if (lane == 0) *reinterpret_cast<f32x4*>(stats + row * 4) = f32x4{ma, ra, mb, rb};
+  }
+}
+
+// partial sums per workgroup, [n_part, 9 * 768] fp32: dgamma_a | dbeta_a | dgamma_b | dbeta_b | dbias_box | dW_box (4 x 768, k-major)
+constexpr int TAIL_PARTS = 9;
+template <typename TA>
+__global__ __launch_bounds__(256) void ocr_tail_bwd_kernel(const float* __restrict__ gout, const TA* __restrict__ a, const float* __restrict__ bbox,
+                                                           const float* __restrict__ wb, const float* __restrict__ bb, const float* __restrict__ ga,
+                                                           const float* __restrict__ gb, const float* __restrict__ stats, TA* __restrict__ da_out,
+                                                           float* __restrict__ part, int64_t rows, DropCfg drop) {
+  __shared__ float red[4][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 w[3][4], bias[3], gA[3], gB[3];
+  f32x4 acc[TAIL_PARTS][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[i][j] = *reinterpret_cast<const f32x4*>(wb + (e + j) * 4);
+    bias[i] = *reinterpret_cast<const f32x4*>(bb + e);
+    gA[i] = *reinterpret_cast<const f32x4*>(ga + e);
+    gB[i] = *reinterpret_cast<const f32x4*>(gb + e);
+#pragma unroll
+    for (int q = 0; q < TAIL_PARTS; ++q) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+    const f32x4 x4 = *reinterpret_cast<const f32x4*>(bbox + row * 4);
+    const f32x4 st = *reinterpret_cast<const f32x4*>(stats + row * 4);
+    f32x4 ta[3], tb[3], xa[3], xb[3];
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      f32x4 g = *reinterpret_cast<const f32x4*>(gout + row * H + e);
+      const f32x4 av = Vec4<TA>::load(a + row * H + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (drop.thresh) g[j] *= drop_keep_scale(drop, (uint32_t)(row * H + e + j));
+        const float bv = fmaf(x4[3], w[i][j][3], fmaf(x4[2], w[i][j][2], fmaf(x4[1], w[i][j][1], x4[0] * w[i][j][0]))) + bias[i][j];
+        xa[i][j] = (av[j] - st[0]) * st[1];
+        xb[i][j] = (bv - st[2]) * st[3];
+        acc[0][i][j] += g[j] * xa[i][j];
+        acc[1][i][j] += g[j];
+        acc[2][i][j] += g[j] * xb[i][j];
+        acc[3][i][j] += g[j];
+        ta[i][j] = g[j] * gA[i][j];
+        tb[i][j] = g[j] * gB[i][j];
+        s1a += ta[i][j];
+        s2a += ta[i][j] * xa[i][j];
+        s1b += tb[i][j];
+        s2b += tb[i][j] * xb[i][j];
+      }
+    }
+    s1a = wave_sum(s1a) * (1.f / H);
+    s2a = wave_sum(s2a) * (1.f / H);
+    s1b = wave_sum(s1b) * (1.f / H);
+    s2b = wave_sum(s2b) * (1.f / H);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      f32x4 oa;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        oa[j] = st[1] * (ta[i][j] - s1a - xa[i][j] * s2a);
+        const float ob = st[3] * (tb[i][j] - s1b - xb[i][j] * s2b);       // gradient of the box projection's output
+        acc[4][i][j] += ob;
+        acc[5][i][j] += ob * x4[0];
+        acc[6][i][j] += ob * x4[1];
+        acc[7][i][j] += ob * x4[2];
+        acc[8][i][j] += ob * x4[3];
+      }
+      Vec4<TA>::store(da_out + row * H + (i * 64 + lane) * 4, oa);
+    }
+  }
+  // 4 waves -> one partial row per workgroup and quantity (through LDS, one quantity at a time)
+#pragma unroll
+  for (int q = 0; q < TAIL_PARTS; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave][(i * 64 + lane) * 4 + j] = acc[q][i][j];
+    __syncthreads();
+    for (int cix = threadIdx.x; cix < H; cix += 256)
+      part[((int64_t)blockIdx.x * TAIL_PARTS + q) * H + cix] = red[0][cix] + red[1][cix] + red[2][cix] + red[3][cix];
+  }
+}
+
 int bwd_parts(int64_t rows) {
   int64_t n = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   return (int)(n < BWD_MAX_PARTS ? (n < 1 ? 1 : n) : BWD_MAX_PARTS);
@@ -290,5 +444,48 @@ extern "C" int t2s_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t 
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, make_drop(drop_p, drop_seed));
   T2S_CHECK_LAUNCH("dropout_mask");
+  return 0;
+}
+
+
+extern "C" int t2s_ocr_tail_parts(int64_t rows) { return bwd_parts(rows); }
+
+extern "C" int t2s_ocr_tail_fwd(const void* a, int a_dtype, const float* bbox, const float* w_box, const float* b_box, const float* gamma_a,
+                                const float* beta_a, const float* gamma_b, const float* beta_b, float* out, float* stats, int64_t rows, float eps,
+                                float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
+  T2S_CHECK_ARG(a && bbox && w_box && b_box && gamma_a && beta_a && gamma_b && beta_b && out && stats, "ocr_tail_fwd: null pointer");
+  T2S_CHECK_ARG(rows > 0 && is_dt(a_dtype), "ocr_tail_fwd: bad shape / dtype");
+  T2S_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rows * H < ((int64_t)1 << 32)), "ocr_tail_fwd: bad dropout");
+  const DropCfg drop = make_drop(drop_p, drop_seed);
+  int64_t nb = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (nb > 8192) nb = 8192;
+  dim3 grid((unsigned)nb), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (a_dtype == T2S_BF16)
+    hipLaunchKernelGGL(ocr_tail_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, bbox, w_box, b_box, gamma_a, beta_a, gamma_b, beta_b, out, stats,
+                       rows, eps, drop);
+  else
+    hipLaunchKernelGGL(ocr_tail_fwd_kernel<float>, grid, block, 0, st, (const float*)a, bbox, w_box, b_box, gamma_a, beta_a, gamma_b, beta_b, out, stats,
+                       rows, eps, drop);
+  T2S_CHECK_LAUNCH("ocr_tail_fwd");
+  return 0;
+}
+
+extern "C" int t2s_ocr_tail_bwd(const float* g_out, const void* a, int a_dtype, const float* bbox, const float* w_box, const float* b_box,
+                                const float* gamma_a, const float* gamma_b, const float* stats, void* d_a, float* part, int64_t rows, float drop_p,
+                                uint64_t drop_seed, t2s_stream_t stream) {
+  T2S_CHECK_ARG(g_out && a && bbox && w_box && b_box && gamma_a && gamma_b && stats && d_a && part, "ocr_tail_bwd: null pointer");
+  T2S_CHECK_ARG(rows > 0 && is_dt(a_dtype), "ocr_tail_bwd: bad shape / dtype");
+  T2S_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "ocr_tail_bwd: bad dropout");
+  const DropCfg drop = make_drop(drop_p, drop_seed);
+  dim3 grid(bwd_parts(rows)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (a_dtype == T2S_BF16)
+    hipLaunchKernelGGL(ocr_tail_bwd_kernel<bf16_t>, grid, block, 0, st, g_out, (const bf16_t*)a, bbox, w_box, b_box, gamma_a, gamma_b, stats, (bf16_t*)d_a,
+                       part, rows, drop);
+  else
+    hipLaunchKernelGGL(ocr_tail_bwd_kernel<float>, grid, block, 0, st, g_out, (const float*)a, bbox, w_box, b_box, gamma_a, gamma_b, stats, (float*)d_a,
+                       part, rows, drop);
+  T2S_CHECK_LAUNCH("ocr_tail_bwd");
   return 0;
 }

@@ -346,6 +346,9 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
                 los.append(cl.view(B, L, HID))
         ctx.keys_list, ctx.drop, ctx.counts, ctx.n_layers = keys_list, (drop_p, seeds_list, attn_drop_p), counts, n_layers
         ctx.save_for_backward(xl, qkv0, *keep)
+        # an output nobody sent a gradient to arrives as None in backward, not as a zero tensor (each pass's gradient comes through ONE
+        # of its two outputs: materialised zeros would cost a 2 GB fill, a cast and an add per pass)
+        ctx.set_materialize_grads(False)
         # operand-dtype mode: the bf16 copies of the outputs follow the fp32 outputs; a consumer may send its gradient through either
         return tuple(outs) + tuple(los)
 
@@ -463,6 +466,37 @@ class PtrLogitsFn(torch.autograd.Function):
         dq = torch.bmm(dsl, k).float()                                    # [B, D, 768]
         dk = torch.bmm(dsl.transpose(1, 2), q.to(k.dtype))                # [B, N, 768]
         return dlogits[:, :, :V], dq, dk, None
+
+
+class OcrTailFn(torch.autograd.Function):
+    """dropout(LN_feat(a) + LN_bbox(Linear_bbox(bbox))): the tail of T2S._forward_ocr_encoding (t2s.py:221-258) as one kernel each
+    way (ops.ocr_tail_fwd / _bwd): the K = 4 box projection is recomputed per row, neither LayerNorm input is copied for
+    backward, the add and the dropout are in the same pass."""
+
+    @staticmethod
+    def forward(ctx, a, bbox, w_box, b_box, ga, ba, gb, bb, drop_p, seed):
+        shape = a.shape
+        a2 = a.contiguous().view(-1, HID)
+        bbox2 = bbox.float().contiguous().view(-1, 4)
+        args = [t.detach().float().contiguous() for t in (w_box, b_box, ga, ba, gb, bb)]
+        out, stats = ops.ocr_tail_fwd(a2, bbox2, *args, drop_p=drop_p, drop_seed=seed)
+        ctx.save_for_backward(a2, bbox2, stats, args[0], args[1], args[2], args[4])
+        ctx.drop = (drop_p, seed)
+        return out.view(*shape[:-1], HID)
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, bbox2, stats, w_box, b_box, ga, gb = ctx.saved_tensors
+        g2 = g.contiguous().view(-1, HID)
+        if g2.dtype != F32:
+            g2 = g2.float()
+        d_a, dga, dba, dgb, dbb, db_box, dw_box = ops.ocr_tail_bwd(g2, a2, bbox2, w_box, b_box, ga, gb, stats, drop_p=ctx.drop[0], drop_seed=ctx.drop[1])
+        return d_a.view(g.shape), None, dw_box, db_box, dga, dba, dgb, dbb, None, None
+
+
+def ocr_tail(a, bbox, box_linear, ln_feat, ln_box, drop_p=0.0):
+    seed = _fresh_seed() if drop_p > 0 else 0
+    return OcrTailFn.apply(a, bbox, box_linear.weight, box_linear.bias, ln_feat.weight, ln_feat.bias, ln_box.weight, ln_box.bias, float(drop_p), seed)
 
 
 class PassHeadFn(torch.autograd.Function):

@@ -40,6 +40,9 @@ _SIGS = {
     "t2s_ground_select": (c_int, [c_void_p] * 6 + [c_int64, c_int] + [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
     "t2s_tanh_residual_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "t2s_tanh_residual_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    "t2s_ocr_tail_parts": (c_int, [c_int64]),
+    "t2s_ocr_tail_fwd": (c_int, [c_void_p, c_int] + [c_void_p] * 9 + [c_int64, c_float, c_float, c_uint64, c_void_p]),
+    "t2s_ocr_tail_bwd": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_int64, c_float, c_uint64, c_void_p]),
     "t2s_add_cast": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p]),
     "t2s_embed_rows": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "t2s_bce_masked": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_void_p]),

@@ -341,6 +341,34 @@ def attention_score(q, k, mask):
     return score
 
 
+def ocr_tail_fwd(a, bbox, w_box, b_box, ga, ba, gb, bb, drop_p=0.0, drop_seed=0, eps=1e-12):
+    """dropout(LN(a; ga, ba) + LN(bbox @ w_box^T + b_box; gb, bb)): a [rows, 768] (fp32 / bf16), bbox [rows, 4] fp32 ->
+    (out [rows, 768] fp32, stats [rows, 4])  (T2S._forward_ocr_encoding t2s.py:221-258)."""
+    rows = _rows768(a)
+    assert bbox.shape == (rows, 4) and bbox.dtype == torch.float32 and bbox.is_contiguous()
+    assert w_box.shape == (HID, 4) and w_box.is_contiguous() and b_box.shape == (HID,)
+    for t in (w_box, b_box, ga, ba, gb, bb):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    out = torch.empty(rows, HID, dtype=torch.float32, device=a.device)
+    stats = torch.empty(rows, 4, dtype=torch.float32, device=a.device)
+    X.check(X.lib().t2s_ocr_tail_fwd(X.ptr(a), X.dtype_code(a), X.ptr(bbox), X.ptr(w_box), X.ptr(b_box), X.ptr(ga), X.ptr(ba), X.ptr(gb), X.ptr(bb),
+                                     X.ptr(out), X.ptr(stats), rows, float(eps), float(drop_p), int(drop_seed), X.stream()), "t2s_ocr_tail_fwd")
+    return out, stats
+
+
+def ocr_tail_bwd(g_out, a, bbox, w_box, b_box, ga, gb, stats, drop_p=0.0, drop_seed=0):
+    """-> (d_a in a's dtype, dga, dba, dgb, dbb, db_box [768], dw_box [768, 4]) (all parameter gradients fp32)."""
+    rows = _rows768(a)
+    assert g_out.shape == (rows, HID) and g_out.dtype == torch.float32 and g_out.is_contiguous() and stats.shape == (rows, 4)
+    d_a = torch.empty_like(a)
+    n_part = X.lib().t2s_ocr_tail_parts(rows)
+    part = torch.empty(n_part, 9, HID, dtype=torch.float32, device=a.device)
+    X.check(X.lib().t2s_ocr_tail_bwd(X.ptr(g_out), X.ptr(a), X.dtype_code(a), X.ptr(bbox), X.ptr(w_box), X.ptr(b_box), X.ptr(ga), X.ptr(gb),
+                                     X.ptr(stats), X.ptr(d_a), X.ptr(part), rows, float(drop_p), int(drop_seed), X.stream()), "t2s_ocr_tail_bwd")
+    p = part.sum(0)
+    return d_a, p[0], p[1], p[2], p[3], p[4], p[5:9].t().contiguous()
+
+
 def tanh_residual_fwd(x, enc_out):
     """x + tanh(enc_out): [B, L, 768] fp32 contiguous (QTV's residual, t2s.py:428-432)."""
     B, L, _ = x.shape

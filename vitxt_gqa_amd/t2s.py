@@ -534,11 +534,9 @@ class T2S(BaseModel):
         x = FN.embed_rows(s.context_feature_0, s.context_feature_1, s.temporal_id, self.temporal_position_embeddings.weight,
                           s.track_id, self.track_position_embeddings.weight, dt)
         a = F.linear(x, self.linear_ocr_feat_to_mmt_in.weight.to(dt), self.linear_ocr_feat_to_mmt_in.bias.to(dt))
-        a = FN.layer_norm(a, self.ocr_feat_layer_norm.weight, self.ocr_feat_layer_norm.bias)
-        b = F.linear(s.ocr_bbox_coordinates.float(), self.linear_ocr_bbox_to_mmt_in.weight,
-                     self.linear_ocr_bbox_to_mmt_in.bias)                      # K = 4: fp32
-        b = FN.layer_norm(b, self.ocr_bbox_layer_norm.weight, self.ocr_bbox_layer_norm.bias)
-        fwd["ocr_mmt_in"] = self._drop(a + b, self.ocr_drop_p)
+        # LN_feat(a) + LN_bbox(Linear_bbox(bbox)) and the dropout in one kernel (the K = 4 box projection is computed per row, fp32)
+        fwd["ocr_mmt_in"] = FN.ocr_tail(a, s.ocr_bbox_coordinates, self.linear_ocr_bbox_to_mmt_in, self.ocr_feat_layer_norm,
+                                        self.ocr_bbox_layer_norm, self.ocr_drop_p if self.training else 0.0)
         fwd["ocr_mask"] = s.ocr_mask
 
     def _forward_output(self, ocr_out, dec_out, mask, dt):
