@@ -443,11 +443,23 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("B%d_F%d_P%d_drop%g" % (B, F, P, args.dropout), {})
+    # MFMA-busy of the attention kernels (SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle, tools/pmc_attn.sh on the kernels alone) - a
+    # property of the kernel build, read from profiles/mfma_busy.json when the dropout setting matches
+    busy = {}
+    bpath = os.path.join(ROOT, "profiles", "mfma_busy.json")
+    if os.path.exists(bpath):
+        busy = json.load(open(bpath)).get("drop%g" % args.dropout, {})
+    L_seq = T_Q + F + F * P + (3 * DEC if not args.forward_only else DEC)
+    alg_fwd = 4.0 * B * L_seq * HID * 2            # Q, K, V read + O written once, bf16 (dense upper bound: every key visible)
+    alg_bwd = 8.0 * B * L_seq * HID * 2            # Q, K, V, O, dO read + dQ, dK, dV written once
     fwd_block = bwd_block = None
     if att_f:
         fwd_block = {"kernel": "attn_fwd_bf16_kernel (all launches with >= 1 GFLOP in the timed region)",
                      "bound": "mfma", "achieved": att_f["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": att_f["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic.get("attn_fwd"),
+                     "mfma_busy": (busy.get("attn_fwd_bf16_kernel") or {}).get("mfma_busy"),
+                     "algorithmic_bytes_per_launch": alg_fwd,
+                     "traffic_over_algorithmic": (traffic.get("attn_fwd") / alg_fwd) if traffic.get("attn_fwd") else None,
                      "launches": att_f["launches"], "avg_launch_ms": att_f["avg_ms"], "ms_per_step": att_f["total_ms"] / args.steps,
                      "achieved_dense_mask_equivalent": att_f["tflops_dense"],
                      "note": "achieved = algorithmic attention-GEMM FLOPs over the VISIBLE keys (2 products: 4*12*64*L*sum_b(visible keys) "
@@ -460,6 +472,9 @@ def main():
                                "with >= 1 GFLOP in the timed region)",
                      "bound": "mfma", "achieved": att_b["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": att_b["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic.get("attn_bwd"),
+                     "mfma_busy": (busy.get("attn_bwd_fused_bf16_kernel") or {}).get("mfma_busy"),
+                     "algorithmic_bytes_per_launch": alg_bwd,
+                     "traffic_over_algorithmic": (traffic.get("attn_bwd") / alg_bwd) if traffic.get("attn_bwd") else None,
                      "launches": att_b["launches"], "fused_5_product_launches": att_b["fused_launches"], "avg_launch_ms": att_b["avg_ms"],
                      "fused_avg_launch_ms": att_b["fused_avg_ms"], "fused_achieved": att_b["fused_tflops"],
                      "ms_per_step": att_b["total_ms"] / args.steps, "achieved_executed": att_b["tflops_executed"],
@@ -467,7 +482,10 @@ def main():
                              "launch) / HIP-event time around ops.attn_bwd; achieved_executed counts the products the kernels really "
                              "run (7 per (query, key) pair in the two-kernel form, which recomputes S and dP; 5 in the fused form); "
                              "fused_avg_launch_ms / fused_achieved: the launches that took the fused form alone (their group in a rocprofv3 "
-                             "kernel trace: attn_delta_prep + attn_bwd_fused<.,0,.> + attn_bwd_fused<.,1,.> + attn_dq_cast)"}
+                             "kernel trace: attn_delta_prep + attn_bwd_fused<.,0,.> + attn_bwd_fused<.,1,.> + attn_dq_cast); "
+                             "mfma_busy: SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle of the fused kernel alone (profiles/mfma_busy.json); "
+                             "traffic_over_algorithmic: PMC bytes per launch / (Q, K, V, O, dO read + dQ, dK, dV written once) - the "
+                             "fp32 dQ atomics of the fused form are the excess (DESIGN section 5)"}
     # `roofline` = the dominant kernel group of the step (the attention backward in a train step, the forward otherwise)
     if bwd_block is not None:
         res["roofline"], res["roofline_fwd"] = bwd_block, fwd_block

@@ -38,3 +38,11 @@ python3 $REPO/tools/pmc_summary.py $OUT > $OUT/pmc_fetch_write.txt
 python3 $REPO/tools/traffic_from_pmc.py $OUT > $OUT/traffic.json
 cat $OUT/traffic.json
 fi
+if [ "$PART" == "busy" ]; then
+# 4. SQ counters of the attention kernels alone (three --pmc passes each, with and without dropout) -> MFMA busy
+bash $REPO/tools/pmc_attn.sh ${TAG}_drop 8 10120 0.7 12 2 0.1 > $OUT/attn_probe_b8_sq_pmc_drop.txt 2>&1
+bash $REPO/tools/pmc_attn.sh ${TAG}_nodrop 8 10120 0.7 12 2 0.0 > $OUT/attn_probe_b8_sq_pmc_nodrop.txt 2>&1
+python3 $REPO/tools/mfma_busy_from_pmc.py $REPO/gpurun_out/pmc_${TAG}_drop drop0.1 > $OUT/mfma_busy_drop.json
+python3 $REPO/tools/mfma_busy_from_pmc.py $REPO/gpurun_out/pmc_${TAG}_nodrop drop0 > $OUT/mfma_busy_nodrop.json
+cat $OUT/mfma_busy_drop.json $OUT/mfma_busy_nodrop.json
+fi
