@@ -486,7 +486,7 @@ def test_pruned_kv_projection_equals_the_full_projection(share_prefix, monkeypat
         out = model(s)
         monkeypatch.setattr(FNmod.ops, "attn_fwd", orig)
         # shared prefix: layers 1, 2 of the pos and neg passes; separate calls: all three layers of both
-        assert sum(seen) == (0 if prune == 0 else (4 if share_prefix else 6)), seen
+        assert sum(seen) == (0 if prune == 0 else 6), seen          # 3 layers x (pos, neg): layer 0 reads its K | V rows gathered from the shared projection
         sum(v.mean() for v in out["losses"].values()).backward()
         res[prune] = ({k: out[k].detach().float().cpu() for k in ("ref_scores", "pos_scores", "neg_scores")},
                       {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None})

@@ -49,7 +49,7 @@ def _wgrad(dy2, x2, B):
     return part.sum(0, dtype=F32)           # fp32: it goes straight into the fp32 gradient of the master weight
 
 
-def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute, materialise=True, qkv=None):
+def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute, materialise=True, qkv=None, kv_given=None):
     """One BERT layer on rows: x2 the fp32 residual stream entering the layer ([B*L, 768] tensor, or an ``ops.NormRes`` left
     by the previous layer), xl its operand-dtype copy.  W = (w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2,
     be2).  Returns (y2, y2_lo or None, tensors to keep for backward).  In the bf16 operand mode the fp32 stream value
@@ -59,7 +59,12 @@ def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute,
     w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2 = W
     lo = w_qkv.dtype != F32
     kvc = None
-    if qkv is None and _prunable(keys, lo):
+    if kv_given is not None:
+        # layer 0 of a pruned pass of SharedPrefixEncoderFn: ``qkv`` is the contiguous Q third of the shared projection and
+        # ``kv_given`` the K | V rows of this pass's keys gathered from it
+        kvc = kv_given
+        att, lse = ops.attn_fwd(qkv, keys.compact(L)[0], drop_p=attn_drop_p, drop_seed=seeds[2], kv=kvc)
+    elif qkv is None and _prunable(keys, lo):
         # Q for every row, K | V for the key rows only (KeyList.compact): [B, capK, 1536] instead of [B, L, 1536]
         keys_c, flat_rows, capK = keys.compact(L)
         qkv = _mm_bias(xl, w_qkv[:HID], b_qkv[:HID]).view(B, L, HID)
@@ -122,11 +127,12 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p, stop_at_qkv=Fal
     del dz1x
     # ---- attention
     if kvc is not None:          # pruned K / V (see _layer_forward): gradients of Q for every row, of K | V for the key rows
-        assert not stop_at_qkv
         keys_c, flat_rows, capK = keys.compact(L)
         dq, dkv = ops.attn_bwd(qkv, att, datt, lse, keys_c, drop_p=attn_drop_p, drop_seed=seeds[2], kv=kvc)
         del datt
         dq, dkv = dq.view(B * L, HID), dkv.view(B * capK, 2 * HID)
+        if stop_at_qkv:          # SharedPrefixEncoderFn adds them into the summed gradient of the shared projection
+            return (dz1, (dq, dkv, flat_rows)), (None, None, dw_ao, db_ao, dg1, dbe1, dw_i, db_i, dw_o, db_o, dg2, dbe2)
         xc = xl.index_select(0, flat_rows)
         dw_qkv = torch.cat([_wgrad(dq, xl, B), (dkv.t() @ xc).float()], 0)
         db_qkv = torch.cat([dq.sum(0, dtype=F32), dkv.sum(0, dtype=F32)], 0)
@@ -330,15 +336,28 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
         xl = x2.to(dt) if dt != F32 else x2
         qkv0 = _mm_bias(xl, flat_w[0], flat_w[1]).view(B, L, 3 * HID)
         keep, counts, outs, los = [], [], [], []
+        q0c = None                  # contiguous Q third of the shared projection, for the passes that prune their keys
         for keys, seeds in zip(keys_list, seeds_list):
             c2, cl = x2, xl
             for l in range(n_layers):
+                q_in, kv_in = (qkv0 if l == 0 else None), None
+                if l == 0 and _prunable(keys, dt != F32):
+                    # this pass sees a handful of keys: its attention reads Q from a contiguous copy (made once) and K | V from the
+                    # gathered rows of its keys, so that its backward produces [B, L, 768] + [B, capK, 1536] instead of a full
+                    # [B, L, 2304] buffer (zero-filled K / V thirds) that then has to be added to the other passes'
+                    if q0c is None:
+                        q0c = qkv0[..., :HID].contiguous()
+                    _, flat_rows, capK = keys.compact(L)
+                    q_in = q0c
+                    kv_in = qkv0.view(B * L, 3 * HID).index_select(0, flat_rows)[:, HID:].contiguous().view(B, capK, 2 * HID)
                 c2, c_lo, saved = _layer_forward(c2, cl, keys, B, L, flat_w[12 * l:12 * l + 12], drop_p, seeds[l], attn_drop_p,
-                                                 RECOMPUTE_ACTIVATIONS, materialise=(l == n_layers - 1), qkv=(qkv0 if l == 0 else None))
+                                                 RECOMPUTE_ACTIVATIONS, materialise=(l == n_layers - 1), qkv=q_in, kv_given=kv_in)
                 cl = c_lo if c_lo is not None else c2
                 saved = list(saved)
-                if l == 0:          # xl and qkv0 are kept once (below), not per pass
-                    saved[0] = saved[1] = None
+                if l == 0:          # xl and qkv0 are kept once (below), not per pass (a pruned pass keeps its Q copy and K | V rows)
+                    saved[0] = None
+                    if kv_in is None:
+                        saved[1] = None
                 counts.append([t is not None for t in saved])
                 keep.extend(t for t in saved if t is not None)
             outs.append(c2.view(B, L, HID))
@@ -384,7 +403,9 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
             for l in reversed(range(n_layers)):
                 saved = per[pi * n_layers + l]
                 if l == 0:
-                    saved[0], saved[1] = xl, qkv0
+                    saved[0] = xl
+                    if saved[1] is None:
+                        saved[1] = qkv0
                 d, g = _layer_backward(saved, keys, d, drop_p, seeds[l], attn_drop_p, stop_at_qkv=(l == 0))
                 per[pi * n_layers + l] = None
                 if grads[l] is None:
@@ -395,7 +416,15 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
             dz1, dqkv = d
             # sums over the passes in the operand dtype, in place in the first pass's buffers
             dz1_sum = dz1 if dz1_sum is None else dz1_sum.add_(dz1)
-            dqkv_sum = dqkv if dqkv_sum is None else dqkv_sum.add_(dqkv)
+            if isinstance(dqkv, tuple):          # a pruned pass: Q gradient for every row + K | V gradient of its key rows
+                dq_p, dkv_p, rows_p = dqkv
+                if dqkv_sum is None:
+                    dqkv_sum = torch.zeros(B * L, 3 * HID, dtype=dq_p.dtype, device=dq_p.device)
+                dqkv_sum[:, :HID].add_(dq_p)
+                dqkv_sum[:, HID:].index_add_(0, rows_p, dkv_p)
+                del dq_p, dkv_p
+            else:
+                dqkv_sum = dqkv if dqkv_sum is None else dqkv_sum.add_(dqkv)
             del d, dz1, dqkv
         if dqkv_sum is None:
             return (None,) * (7 + MASTERS_PER_LAYER * n_layers)
