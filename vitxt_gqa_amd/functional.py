@@ -51,12 +51,12 @@ def _wgrad(dy2, x2, B):
 
 def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute, materialise=True, qkv=None, kv_given=None):
     """One BERT layer on rows: x2 the fp32 residual stream entering the layer ([B*L, 768] tensor, or an ``ops.NormRes`` left
-    by the previous layer), xl its operand-dtype copy.  W = (w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2,
+    by the previous layer), xl its operand-dtype copy.  W = operand_weights(...) = (w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2,
     be2).  Returns (y2, y2_lo or None, tensors to keep for backward).  In the bf16 operand mode the fp32 stream value
     between two residual+LayerNorm blocks exists only in normalised form (pre-LN sum + statistics, both kept for backward
     anyway): the next block's kernel re-normalises it on the fly, so it is never written to HBM; y2 is then an
     ``ops.NormRes`` unless ``materialise`` (last layer of a stack)."""
-    w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2 = W
+    w_qkv, b_qkv, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2, w_qkv_t, w_ao_t, w_i_t, w_o_t = W
     lo = w_qkv.dtype != F32
     kvc = None
     if kv_given is not None:
@@ -88,7 +88,7 @@ def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute,
         y2 = ops.NormRes(z2, st2, g2, be2)
     if recompute:      # store less: GELU output and the LN1 operand copy are rebuilt in backward
         gact = y1_op = None
-    return y2, (y2_lo if lo else None), (xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op, kvc)
+    return y2, (y2_lo if lo else None), (xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv_t, w_ao_t, g1, be1, w_i_t, w_o_t, g2, gact, y1_op, kvc)
 
 
 def _prunable(keys, lo):
@@ -99,16 +99,16 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p, stop_at_qkv=Fal
     """dy: [B*L, 768] gradient of the layer output (fp32 or the operand dtype).  Returns (dx [B*L, 768] in the operand
     dtype, the 12 parameter gradients in the order of W, all fp32: they are gradients of the fp32 master parameters).  The bias gradients of the two projections that feed a
     residual+LayerNorm block come out of that block's backward kernel (column sums in the same pass)."""
-    xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv, w_ao, g1, be1, w_i, w_o, g2, gact, y1_op, kvc = saved
+    xl, qkv, att, lse, z1, st1, u, z2, st2, w_qkv_t, w_ao_t, g1, be1, w_i_t, w_o_t, g2, gact, y1_op, kvc = saved      # weights: [in, out] copies
     B, L, _ = qkv.shape
-    dt = w_qkv.dtype
+    dt = w_qkv_t.dtype
     lo = dt != F32
     # ---- output LayerNorm + FFN
     dz2, dz2x, dg2, dbe2, db_o = ops.add_layernorm_bwd(dy, z2, st2, g2, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[1], want_bias=True)
     if gact is None:
         gact = ops.gelu_fwd(u)
     dw_o = _wgrad(dz2x, gact, B)
-    dgact = dz2x @ w_o
+    dgact = dz2x @ w_o_t.t()
     del gact, dz2x
     du, db_i = ops.gelu_bwd(dgact, u)
     del dgact
@@ -117,13 +117,13 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p, stop_at_qkv=Fal
         y1_op = y1_lo if lo else y1
         del y1, y1_lo
     dw_i = _wgrad(du, y1_op, B)
-    dy1 = dz2.addmm_(du, w_i)          # + residual branch of LN2, accumulated IN PLACE (out-of-place addmm first copies C)
+    dy1 = dz2.addmm_(du, w_i_t.t())    # + residual branch of LN2, accumulated IN PLACE (out-of-place addmm first copies C)
     del du, y1_op, dz2
     # ---- attention output LayerNorm + projection
     dz1, dz1x, dg1, dbe1, db_ao = ops.add_layernorm_bwd(dy1, z1, st1, g1, out_dtype=dt, drop_p=drop_p, drop_seed=seeds[0], want_bias=True)
     del dy1
     dw_ao = _wgrad(dz1x, att.view(B * L, HID), B)
-    datt = (dz1x @ w_ao).view(B, L, HID)
+    datt = (dz1x @ w_ao_t.t()).view(B, L, HID)
     del dz1x
     # ---- attention
     if kvc is not None:          # pruned K / V (see _layer_forward): gradients of Q for every row, of K | V for the key rows
@@ -136,8 +136,8 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p, stop_at_qkv=Fal
         xc = xl.index_select(0, flat_rows)
         dw_qkv = torch.cat([_wgrad(dq, xl, B), (dkv.t() @ xc).float()], 0)
         db_qkv = torch.cat([dq.sum(0, dtype=F32), dkv.sum(0, dtype=F32)], 0)
-        dx = dz1.addmm_(dq, w_qkv[:HID])                                 # + residual branch of LN1 (in place)
-        dx.index_add_(0, flat_rows, dkv @ w_qkv[HID:])                   # the key rows' share (positions behind a list: zeros onto row 0)
+        dx = dz1.addmm_(dq, w_qkv_t[:, :HID].t())                        # + residual branch of LN1 (in place)
+        dx.index_add_(0, flat_rows, dkv @ w_qkv_t[:, HID:].t())          # the key rows' share (positions behind a list: zeros onto row 0)
         return dx, (dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1, dw_i, db_i, dw_o, db_o, dg2, dbe2)
     dqkv = ops.attn_bwd(qkv, att, datt, lse, keys, drop_p=attn_drop_p, drop_seed=seeds[2]).view(B * L, 3 * HID)
     del datt
@@ -145,7 +145,7 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p, stop_at_qkv=Fal
         return (dz1, dqkv), (None, None, dw_ao, db_ao, dg1, dbe1, dw_i, db_i, dw_o, db_o, dg2, dbe2)
     dw_qkv = _wgrad(dqkv, xl, B)
     db_qkv = dqkv.sum(0, dtype=F32)
-    dx = dz1.addmm_(dqkv, w_qkv)                                         # + residual branch of LN1 (in place, as above)
+    dx = dz1.addmm_(dqkv, w_qkv_t.t())                                   # + residual branch of LN1 (in place, as above)
     return dx, (dw_qkv, db_qkv, dw_ao, db_ao, dg1, dbe1, dw_i, db_i, dw_o, db_o, dg2, dbe2)
 
 
@@ -157,6 +157,8 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p, stop_at_qkv=Fal
 # between two calls (optimizer step, ``.data`` surgery, load_state_dict) can never meet a stale copy.
 _SCOPE = threading.local()
 MASTERS_PER_LAYER = 16
+_DGRAD_NT = os.environ.get("T2S_DGRAD_NT", "1") != "0"
+W_PER_LAYER = 16          # operand_weights(): the 12 forward operands + 4 transposed weight copies for the input-gradient GEMMs
 
 
 @contextlib.contextmanager
@@ -189,6 +191,11 @@ def operand_weights(m, dtype):
     c = (lambda t: t.detach().to(dtype))
     W = (torch.cat([wq, wk, wv], 0).to(dtype), torch.cat([bq, bk, bv], 0).to(dtype), c(w_ao), c(b_ao), g1.detach(), be1.detach(),
          c(w_i), c(b_i), c(w_o), c(b_o), g2.detach(), be2.detach())
+    # Transposed copies [in, out] for the input-gradient GEMMs dx = dy W: handed to the library as dy @ Wt.t() ("NT", the layout of
+    # the forward) they run 8-12 % faster than dy @ W ("NN") on every shape of the layer (tools/gemm_layout_probe.py: e.g.
+    # [650k, 768] x [768, 3072]: 2.63 vs 3.00 ms) - the NN path gets a 256x256x32 tile, the NT path 256x256x64.
+    # (T2S_DGRAD_NT=0: views instead of copies, i.e. the NN layout - for same-box A/B runs)
+    W = W + tuple((W[i].t().contiguous() if _DGRAD_NT else W[i].t()) for i in (0, 2, 6, 8))
     if cache is not None:
         cache[key] = (m[0], W)                            # holding m[0] keeps its id() from being reused inside the scope
     return W
@@ -238,7 +245,7 @@ def _encoder_forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, mas
     xl = x2.to(dt) if dt != F32 else x2
     keep, counts = [], []
     for l in range(n_layers):
-        x2, x_lo, saved = _layer_forward(x2, xl, keys, B, L, flat_w[12 * l:12 * l + 12], drop_p, seeds[l], attn_drop_p,
+        x2, x_lo, saved = _layer_forward(x2, xl, keys, B, L, flat_w[W_PER_LAYER * l:W_PER_LAYER * (l + 1)], drop_p, seeds[l], attn_drop_p,
                                          RECOMPUTE_ACTIVATIONS, materialise=(l == n_layers - 1))
         xl = x_lo if x_lo is not None else x2
         counts.append([t is not None for t in saved])
@@ -350,7 +357,7 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
                     _, flat_rows, capK = keys.compact(L)
                     q_in = q0c
                     kv_in = qkv0.view(B * L, 3 * HID).index_select(0, flat_rows)[:, HID:].contiguous().view(B, capK, 2 * HID)
-                c2, c_lo, saved = _layer_forward(c2, cl, keys, B, L, flat_w[12 * l:12 * l + 12], drop_p, seeds[l], attn_drop_p,
+                c2, c_lo, saved = _layer_forward(c2, cl, keys, B, L, flat_w[W_PER_LAYER * l:W_PER_LAYER * (l + 1)], drop_p, seeds[l], attn_drop_p,
                                                  RECOMPUTE_ACTIVATIONS, materialise=(l == n_layers - 1), qkv=q_in, kv_given=kv_in)
                 cl = c_lo if c_lo is not None else c2
                 saved = list(saved)
@@ -386,7 +393,7 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
                 cur.append(flat[pos] if present else None)
                 pos += present
             per.append(cur)
-        w_qkv0 = per[0][9]                 # the fused QKV operand weight of layer 0 (same tensor in every pass's list)
+        w_qkv0_t = per[0][9]               # the fused QKV operand weight of layer 0, [in, out] copy (same tensor in every pass's list)
         grads = [None] * n_layers          # parameter gradients summed over the passes, per layer (12-tuples, fp32)
         dz1_sum = dqkv_sum = None
         n_pass = len(ctx.keys_list)
@@ -431,7 +438,7 @@ class SharedPrefixEncoderFn(torch.autograd.Function):
         dqkv2 = dqkv_sum.view(B * L, 3 * HID)
         grads[0][0] = _wgrad(dqkv2, xl, B)
         grads[0][1] = dqkv2.sum(0, dtype=F32)
-        dx = dz1_sum.addmm_(dqkv2, w_qkv0)                  # + residual branch of LN1 (in place)
+        dx = dz1_sum.addmm_(dqkv2, w_qkv0_t.t())            # + residual branch of LN1 (in place)
         out = (dx.view(B, L, HID).float(), None, None, None, None, None, None)
         for g in grads:
             out += _master_grads(tuple(g))
@@ -703,7 +710,7 @@ def _layer_weights(lp, dtype):
 
 def _layer_tail(att2, res32, w, dtype):
     """attention output [rows, 768] -> layer output (fp32 stream, operand copy)."""
-    _, _, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2 = w
+    _, _, w_ao, b_ao, g1, be1, w_i, b_i, w_o, b_o, g2, be2 = w[:12]
     lo = dtype != F32
     a = _mm_bias(att2, w_ao, b_ao)
     y1, y1_lo, _, _ = ops.add_layernorm_fwd(a, res32, g1, be1, save=False, stream_dtype=F32, want_lo=lo)
