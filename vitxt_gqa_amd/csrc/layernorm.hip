@@ -246,71 +246,88 @@ __global__ __launch_bounds__(256) void ocr_tail_fwd_kernel(const TA* __restrict_
 // partial sums per workgroup, [n_part, 9 * 768] fp32: dgamma_a | dbeta_a | dgamma_b | dbeta_b | dbias_box | dW_box (4 x 768, k-major)
 constexpr int TAIL_PARTS = 9;
 template <typename TA>
-__global__ __launch_bounds__(256) void ocr_tail_bwd_kernel(const float* __restrict__ gout, const TA* __restrict__ a, const float* __restrict__ bbox,
-                                                           const float* __restrict__ wb, const float* __restrict__ bb, const float* __restrict__ ga,
-                                                           const float* __restrict__ gb, const float* __restrict__ stats, TA* __restrict__ da_out,
-                                                           float* __restrict__ part, int64_t rows, DropCfg drop) {
+__global__ __launch_bounds__(256, 2) void ocr_tail_bwd_kernel(const float* __restrict__ gout, const TA* __restrict__ a, const float* __restrict__ bbox,
+                                                              const float* __restrict__ wb, const float* __restrict__ bb, const float* __restrict__ ga,
+                                                              const float* __restrict__ gb, const float* __restrict__ stats, TA* __restrict__ da_out,
+                                                              float* __restrict__ part, int64_t rows, DropCfg drop) {
+  // the per-column constants (box weight 4 + bias + two LayerNorm gains = 7 floats per column) live in LDS and are re-read per row:
+  // with them in registers beside the 108 partial sums the kernel needs 256 VGPRs (one wave per SIMD, 3.7 TB/s); from LDS it keeps
+  // two waves per SIMD in flight
+  __shared__ float cst[7][H];
   __shared__ float red[4][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 w[3][4], bias[3], gA[3], gB[3];
+  for (int c = threadIdx.x; c < H; c += 256) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cst[k][c] = wb[c * 4 + k];          // k-major: the lane's 4 consecutive columns are one float4 per k
+    cst[4][c] = bb[c];
+    cst[5][c] = ga[c];
+    cst[6][c] = gb[c];
+  }
+  __syncthreads();
   f32x4 acc[TAIL_PARTS][3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int e = (i * 64 + lane) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[i][j] = *reinterpret_cast<const f32x4*>(wb + (e + j) * 4);
-    bias[i] = *reinterpret_cast<const f32x4*>(bb + e);
-    gA[i] = *reinterpret_cast<const f32x4*>(ga + e);
-    gB[i] = *reinterpret_cast<const f32x4*>(gb + e);
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int q = 0; q < TAIL_PARTS; ++q) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
   for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
     const f32x4 x4 = *reinterpret_cast<const f32x4*>(bbox + row * 4);
     const f32x4 st = *reinterpret_cast<const f32x4*>(stats + row * 4);
-    f32x4 ta[3], tb[3], xa[3], xb[3];
+    // two sweeps over the lane's 12 columns: the first forms the row sums, the second rebuilds the normalised values from the
+    // registers that hold g and a (the constants come from LDS again) - keeping xa / xb / ta / tb of the whole row alive costs 48 VGPRs
+    f32x4 g[3], av[3];
     float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+    asm volatile("" ::: "memory");        // the constants are row-invariant: without this the compiler hoists their 84 LDS loads into registers
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int e = (i * 64 + lane) * 4;
-      f32x4 g = *reinterpret_cast<const f32x4*>(gout + row * H + e);
-      const f32x4 av = Vec4<TA>::load(a + row * H + e);
+      g[i] = *reinterpret_cast<const f32x4*>(gout + row * H + e);
+      av[i] = Vec4<TA>::load(a + row * H + e);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&cst[0][e]), w1 = *reinterpret_cast<const f32x4*>(&cst[1][e]);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(&cst[2][e]), w3 = *reinterpret_cast<const f32x4*>(&cst[3][e]);
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(&cst[4][e]);
+      const f32x4 gA = *reinterpret_cast<const f32x4*>(&cst[5][e]), gB = *reinterpret_cast<const f32x4*>(&cst[6][e]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (drop.thresh) g[j] *= drop_keep_scale(drop, (uint32_t)(row * H + e + j));
-        const float bv = fmaf(x4[3], w[i][j][3], fmaf(x4[2], w[i][j][2], fmaf(x4[1], w[i][j][1], x4[0] * w[i][j][0]))) + bias[i][j];
-        xa[i][j] = (av[j] - st[0]) * st[1];
-        xb[i][j] = (bv - st[2]) * st[3];
-        acc[0][i][j] += g[j] * xa[i][j];
-        acc[1][i][j] += g[j];
-        acc[2][i][j] += g[j] * xb[i][j];
-        acc[3][i][j] += g[j];
-        ta[i][j] = g[j] * gA[i][j];
-        tb[i][j] = g[j] * gB[i][j];
-        s1a += ta[i][j];
-        s2a += ta[i][j] * xa[i][j];
-        s1b += tb[i][j];
-        s2b += tb[i][j] * xb[i][j];
+        if (drop.thresh) g[i][j] *= drop_keep_scale(drop, (uint32_t)(row * H + e + j));
+        const float bv = fmaf(x4[3], w3[j], fmaf(x4[2], w2[j], fmaf(x4[1], w1[j], x4[0] * w0[j]))) + bi[j];
+        const float xa = (av[i][j] - st[0]) * st[1], xb = (bv - st[2]) * st[3];
+        acc[0][i][j] += g[i][j] * xa;
+        acc[1][i][j] += g[i][j];
+        acc[2][i][j] += g[i][j] * xb;
+        acc[3][i][j] += g[i][j];
+        const float ta = g[i][j] * gA[j], tb = g[i][j] * gB[j];
+        s1a += ta;
+        s2a += ta * xa;
+        s1b += tb;
+        s2b += tb * xb;
       }
     }
     s1a = wave_sum(s1a) * (1.f / H);
     s2a = wave_sum(s2a) * (1.f / H);
     s1b = wave_sum(s1b) * (1.f / H);
     s2b = wave_sum(s2b) * (1.f / H);
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&cst[0][e]), w1 = *reinterpret_cast<const f32x4*>(&cst[1][e]);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(&cst[2][e]), w3 = *reinterpret_cast<const f32x4*>(&cst[3][e]);
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(&cst[4][e]);
+      const f32x4 gA = *reinterpret_cast<const f32x4*>(&cst[5][e]), gB = *reinterpret_cast<const f32x4*>(&cst[6][e]);
       f32x4 oa;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        oa[j] = st[1] * (ta[i][j] - s1a - xa[i][j] * s2a);
-        const float ob = st[3] * (tb[i][j] - s1b - xb[i][j] * s2b);       // gradient of the box projection's output
+        const float bv = fmaf(x4[3], w3[j], fmaf(x4[2], w2[j], fmaf(x4[1], w1[j], x4[0] * w0[j]))) + bi[j];
+        const float xa = (av[i][j] - st[0]) * st[1], xb = (bv - st[2]) * st[3];
+        oa[j] = st[1] * (g[i][j] * gA[j] - s1a - xa * s2a);
+        const float ob = st[3] * (g[i][j] * gB[j] - s1b - xb * s2b);      // gradient of the box projection's output
         acc[4][i][j] += ob;
         acc[5][i][j] += ob * x4[0];
         acc[6][i][j] += ob * x4[1];
         acc[7][i][j] += ob * x4[2];
         acc[8][i][j] += ob * x4[3];
       }
-      Vec4<TA>::store(da_out + row * H + (i * 64 + lane) * 4, oa);
+      Vec4<TA>::store(da_out + row * H + e, oa);
     }
   }
   // 4 waves -> one partial row per workgroup and quantity (through LDS, one quantity at a time)
