@@ -29,7 +29,7 @@ RECOMPUTE_ACTIVATIONS = False
 # guaranteed by the top-k masks) projects K and V only for the rows that are keys: masked keys contribute exactly nothing
 # (deviation 1), so their K / V rows - two thirds of the QKV GEMM, of its input-gradient and of its
 # weight-gradient GEMM - are never read.  Lists with a bound above this many keys keep the fused [B, L, 2304] projection.
-PRUNE_KV_MAX_KEYS = int(os.environ.get("T2S_PRUNE_KV_MAX_KEYS", "1024"))
+PRUNE_KV_MAX_KEYS = int(os.environ.get("T2S_PRUNE_KV_MAX_KEYS", "2047"))      # (below ops.ATTN_BWD_FUSED_MIN_KEYS: pruned launches take the two-kernel backward)
 
 
 def _mm_bias(x2, w, b):
