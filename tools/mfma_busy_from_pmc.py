@@ -27,5 +27,13 @@ for k, cs in acc.items():
         e["valu_per_mfma"] = mean(cs["SQ_INSTS_VALU"]) / mean(cs["SQ_INSTS_MFMA"])
     if "SQ_LDS_BANK_CONFLICT" in cs and "SQ_LDS_IDX_ACTIVE" in cs and mean(cs["SQ_LDS_IDX_ACTIVE"]) > 0:
         e["lds_bank_conflict_frac"] = mean(cs["SQ_LDS_BANK_CONFLICT"]) / mean(cs["SQ_LDS_IDX_ACTIVE"])
-    out[k.split("(")[0].replace("void (anonymous namespace)::", "").strip()[:60]] = e
+    name = k.replace("void ", "").replace("(anonymous namespace)::", "").strip()
+    base = name.split("<")[0].split("(")[0]
+    # one entry per kernel FAMILY; of a family's instantiations keep the one with the most MFMA-busy cycles (the steady-state form)
+    if base not in out or busy > out[base]["_busy_cycles"]:
+        e["_busy_cycles"] = busy
+        e["instantiation"] = name[:90]
+        out[base] = e
+for e in out.values():
+    e.pop("_busy_cycles", None)
 print(json.dumps({sys.argv[2] if len(sys.argv) > 2 else "attn_probe": out}, indent=1))

@@ -10,12 +10,12 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 set -e               # a failed GPU step ends the run: no further GPU work behind it
 cd /tmp && export TMPDIR=/tmp
-if [ "$PART" != "extra" ]; then
+if [ "$PART" != "extra" ] && [ "$PART" != "busy" ]; then
 # 1. the bench line (defaults: B=64 train step, with the bounded CPU baseline)
 timeout -k 10 900 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
 fi
-if [ "$PART" != "core" ]; then
+if [ "$PART" != "core" ] && [ "$PART" != "busy" ]; then
 # 1b. the other BASELINE configurations: forward-only (configs[1]) and the 300 x 200 long-sequence stress (configs[4])
 timeout -k 10 900 python3 $REPO/bench.py --forward-only --no-cpu-baseline > $OUT/forward_only.json 2>> $OUT/bench.err
 timeout -k 10 900 python3 $REPO/bench.py --batch 2 --frames 300 --ocr 200 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stress_b2_300x200.json 2>> $OUT/bench.err
@@ -26,7 +26,7 @@ timeout -k 10 300 python3 $REPO/tools/attn_probe.py 32 10120 0.7 12 5 0.1 > $OUT
 timeout -k 10 300 python3 $REPO/tools/attn_probe.py 32 10120 0.7 12 5 0.0 >> $OUT/attn_probe_b32.txt 2>> $OUT/bench.err
 T2S_BENCH_FORCE_DIST=1 timeout -k 10 600 python3 $REPO/bench.py --no-cpu-baseline --no-dropout0 > $OUT/single_rank_rccl.json 2>> $OUT/bench.err
 fi
-if [ "$PART" != "extra" ]; then
+if [ "$PART" != "extra" ] && [ "$PART" != "busy" ]; then
 # 2. kernel trace + stats of the same command (fewer steps, no CPU baseline: identical GPU work per step)
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dropout0 > $OUT/stats.log 2>&1
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
