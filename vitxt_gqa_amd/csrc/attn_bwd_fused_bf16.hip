@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   // per-lane LDS byte offsets, computed once: row fragment of row lr of a 32-row block (chunk 2s + lh), transposed fragment
   // (rows 4lh + qq and + 8, chunk 4db + 2g1 + (pp >> 1)), dS^T store (row lr, chunk cc); block / tile / image offsets are
   // immediates or uniform adds on top of these
-  int ka[4], va[2][2];
+  int ka[4], va[2][2], vads[2][2];
 #pragma unroll
   for (int s = 0; s < 4; ++s) ka[s] = tile_off(lr, 2 * s + lh);
   {
@@ -200,6 +200,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       const int chunk = 4 * db + 2 * g1 + (pp >> 1);
       va[db][0] = tile_off(4 * lh + qq, chunk) + ((pp & 1) << 3);
       va[db][1] = tile_off(4 * lh + qq + 8, chunk) + ((pp & 1) << 3);
+      // the dS^T image swaps the two 8-byte halves of every 16-byte chunk on ODD rows (see the stores below): the same involution here
+      vads[db][0] = tile_off(4 * lh + qq, chunk) + (((pp ^ qq) & 1) << 3);
+      vads[db][1] = tile_off(4 * lh + qq + 8, chunk) + (((pp ^ qq) & 1) << 3);
     }
   }
   const int wrow = lr * 128, wxor = tile_f(lr) << 4;          // dS^T store of chunk cc: wrow + ((cc << 4) ^ wxor)
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int dq_qb = wave_u >> 1, dq_db = wave_u & 1;          // this wave's 32 x 32 tile of dQ (provably wave-uniform)
-    const int vaq[2] = {dq_qb ? va[1][0] : va[0][0], dq_qb ? va[1][1] : va[0][1]};
+    const int vaq[2] = {dq_qb ? vads[1][0] : vads[0][0], dq_qb ? vads[1][1] : vads[0][1]};
     const int vad[2] = {dq_db ? va[1][0] : va[0][0], dq_db ? va[1][1] : va[0][1]};
     // EDGE: first tile row that sees this lane's key of block kb (prefix keys: every row; keys past the list: none)
     int qmin[FB_KB];
@@ -400,7 +403,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         const int rowb = qt * FB_QROWS + 4 * lh;
 #define FB_THR(i_) if (EDGE) thr[(i_) & 1] = qmin[(i_) % 3] - rowb - ((i_) / 3) * 32;
         uint32_t pfw[8], dsw[8];
-        char* dsw_ = dsimg + wave * (FB_WKEYS * 128) + 8 * lh;
+        // 8-byte stores of rows lr and lr + 1 would hit the same LDS banks (the chunk swizzle ignores bit 0 of the row, and an
+        // 8-byte store spans half a chunk): odd rows take the other half of the chunk - 10 % of this kernel's LDS cycles were
+        // bank conflicts of these stores (profiles/mfma_busy.json, round 2 / 3)
+        char* dsw_ = dsimg + wave * (FB_WKEYS * 128) + 8 * (lh ^ (lr & 1));
 #define FB_LD_QT(sb_)                                                                               \
   _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                     \
   _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                \
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             for (int s = 0; s < 2; ++s) { pf[s] = acc_to_frag(pdrop, s); dsf[s] = acc_to_frag(dpacc, s); }
             fb_mfma_dvdk(dvacc[kb][0], dvacc[kb][1], dkacc[kb][0], dkacc[kb][1], doT, qT, pf, dsf);
             // dS^T image: this lane's key row, queries sb*32 + 16s + {0..3, 8..11} + 4lh: two 8-byte stores per s
-            char* dsrow = dsimg + 8 * lh;
+            char* dsrow = dsimg + 8 * (lh ^ (lr & 1));        // (keyrow0 is a multiple of 32: the row's parity is lr's)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
               const uint4 w = __builtin_bit_cast(uint4, dsf[s]);
