@@ -178,6 +178,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 
 // bf16 forward kernel lives in attn_fwd_bf16.hip
 void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st);
+// one-wave-per-SIMD, hand-placed main pass for long sequences (attn_fwd_pw_bf16.hip); 0 or an error code
+int launch_attn_fwd_pw_bf16(const AttnParams& p, hipStream_t st);
 // bf16 dK/dV kernel lives in attn_dkdv_bf16.hip
 void launch_attn_dkdv_bf16(const AttnParams& p, int max_keys, hipStream_t st);
 // fused 5-product bf16 backward (delta + housekeeping, main kernel, dQ cast) lives in attn_bwd_fused_bf16.hip

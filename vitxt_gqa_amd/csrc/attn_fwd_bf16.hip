@@ -24,6 +24,8 @@
 //  * The tile body is written as a wavefront - S(key block 0) | S(key block 1) + exp(block 0) | PV(block 0) +
 //    exp(block 1) | PV(block 1) - with scheduling fences between the stages and an MFMA:VALU interleave pattern
 //    inside them.
+#include <stdlib.h>
+
 #include "attn_common.h"
 
 namespace {
@@ -414,7 +416,14 @@ void launch_fwd(const AttnParams& p, hipStream_t st) {
 }  // namespace
 
 void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st) {
-  if (p.drop_thresh) launch_fwd<true, false>(p, st);
+  // main pass: this file's two-waves-per-SIMD kernel.  T2S_ATTN_FWD_PW=1 (read per launch, so that one process can run both) sends
+  // sequences longer than one 256-row workgroup to the one-wave-per-SIMD kernel of attn_fwd_pw_bf16.hip instead: an experiment that
+  // is correct (the kernel tests run both) and 5-12 % SLOWER on the benchmark shape - opt-in, for A/B runs.
+  // The repair launch below is this file's either way.
+  const char* pw_env = getenv("T2S_ATTN_FWD_PW");
+  const bool use_pw = pw_env && pw_env[0] == '1';
+  if (use_pw && p.Lq > 256 && launch_attn_fwd_pw_bf16(p, st) == 0) {
+  } else if (p.drop_thresh) launch_fwd<true, false>(p, st);
   else launch_fwd<false, false>(p, st);
   // The steady-state loop exists only when some sample can have more than one whole tile of prefix keys; only then can
   // a wave have poisoned its rows.  The repair launch reads the LSE of its rows and returns unless one is NaN.
