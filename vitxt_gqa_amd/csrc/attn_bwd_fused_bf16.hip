@@ -282,9 +282,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     q1r = *reinterpret_cast<const uint4*>(Qb + a1_);                                            \
     d1r = *reinterpret_cast<const uint4*>(DOb + b1_);                                           \
     const int r2c_ = ld_row < p.Lq ? ld_row : p.Lq - 1;                                         \
-    const float l_ = LSE[r2c_] * LOG2E, dl_ = DELTA[r2c_];                                      \
-    lreg = ld_row < p.Lq ? -l_ : -INFINITY;                                                     \
-    dreg = ld_row < p.Lq ? -dl_ : 0.f;                                                          \
+    lreg = LSE[r2c_]; dreg = DELTA[r2c_];       /* raw: arithmetic on them HERE would make the wave wait for the loads here */  \
     if (DROP && tid < FB_QROWS / 2) {                                                           \
       const int qa_ = ld_row0 + 2 * tid, qb2_ = qa_ + 1;                                        \
       rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1) << 16); \
@@ -299,9 +297,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     *reinterpret_cast<uint4*>(base_ + FB_TILE + tile_off(sr, sc)) = d0r;                        \
     *reinterpret_cast<uint4*>(base_ + tile_off(sr + 32, sc)) = q1r;                             \
     *reinterpret_cast<uint4*>(base_ + FB_TILE + tile_off(sr + 32, sc)) = d1r;                   \
-    if (tid < FB_QROWS) {                                                                       \
-      reinterpret_cast<float*>(base_ + 2 * FB_TILE)[tid] = lreg;                                \
-      reinterpret_cast<float*>(base_ + 2 * FB_TILE + FB_QROWS * 4)[tid] = dreg;                 \
+    if (tid < FB_QROWS) {        /* (ld_row was advanced past the staged tile by the load) */  \
+      const bool in_ = ld_row - FB_QROWS < p.Lq;                                                \
+      reinterpret_cast<float*>(base_ + 2 * FB_TILE)[tid] = in_ ? -(lreg * LOG2E) : -INFINITY;   \
+      reinterpret_cast<float*>(base_ + 2 * FB_TILE + FB_QROWS * 4)[tid] = in_ ? -dreg : 0.f;    \
     }                                                                                           \
     if (DROP && tid < FB_QROWS / 2) reinterpret_cast<uint32_t*>(base_ + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
   }

@@ -115,9 +115,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_dkdv_bf16_kernel(AttnParams p
       d1r = *reinterpret_cast<const uint4*>(DOb + b1_);                                         \
     }                                                                                           \
     const int r2c_ = ld_row < p.Lq ? ld_row : p.Lq - 1;                                         \
-    const float l_ = LSE[r2c_] * LOG2E, dl_ = DELTA[r2c_];                                      \
-    lreg = ld_row < p.Lq ? -l_ : -INFINITY; /* -inf => P = exp2(-inf) = 0 for rows past Lq */    \
-    dreg = ld_row < p.Lq ? -dl_ : 0.f;                                                          \
+    lreg = LSE[r2c_]; dreg = DELTA[r2c_];       /* raw: arithmetic on them HERE would make the wave wait for the loads here */  \
     if (DROP && tid < QROWS / 2) {                                                              \
       const int qa_ = ld_row0 + 2 * tid, qb_ = qa_ + 1;                                         \
       rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1) | (attn_drop_rowkey16(salt, qb_ < p.Lq ? qb_ : p.Lq - 1) << 16); \
@@ -134,9 +132,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_dkdv_bf16_kernel(AttnParams p
       *reinterpret_cast<uint4*>(base_ + tile_off(sr + 32, sc)) = q1r;                           \
       *reinterpret_cast<uint4*>(base_ + TILE + tile_off(sr + 32, sc)) = d1r;                    \
     }                                                                                           \
-    if (tid < QROWS) {                                                                          \
-      reinterpret_cast<float*>(base_ + 2 * TILE)[tid] = lreg;                                   \
-      reinterpret_cast<float*>(base_ + 2 * TILE + QROWS * 4)[tid] = dreg;                       \
+    if (tid < QROWS) {           /* (ld_row was advanced past the staged tile by the load); -inf => P = exp2(-inf) = 0 for rows past Lq */ \
+      const bool in_ = ld_row - QROWS < p.Lq;                                                   \
+      reinterpret_cast<float*>(base_ + 2 * TILE)[tid] = in_ ? -(lreg * LOG2E) : -INFINITY;      \
+      reinterpret_cast<float*>(base_ + 2 * TILE + QROWS * 4)[tid] = in_ ? -dreg : 0.f;          \
     }                                                                                           \
     if (DROP && tid < QROWS / 2) reinterpret_cast<uint32_t*>(base_ + 2 * TILE + 2 * QROWS * 4)[tid] = rkreg; \
   }
