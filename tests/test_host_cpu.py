@@ -125,3 +125,20 @@ def test_bench_gpus_n_spawns_its_own_ranks():
     if __import__("torch").cuda.device_count() < 4:
         out = subprocess.run([sys.executable, bench, "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 2 and "only" in out.stderr
+
+
+def test_tuned_gemm_file_is_well_formed_and_inert_without_a_gpu():
+    """vitxt_gqa_amd/tuned/*.csv: torch TunableOp's format (validator lines, then op, shape, solution, time); without a GPU the
+    loader does nothing."""
+    import os
+    import vitxt_gqa_amd.gemm_tuning as G
+    assert os.path.exists(G._FILE)
+    rows = [l.strip().split(",") for l in open(G._FILE) if l.strip()]
+    val = [r for r in rows if r[0] == "Validator"]
+    ops_ = [r for r in rows if r[0] != "Validator"]
+    assert {r[1] for r in val} >= {"PT_VERSION", "HIPBLASLT_VERSION", "GCN_ARCH_NAME"}
+    assert any(r[2].startswith("gfx950") for r in val if r[1] == "GCN_ARCH_NAME")
+    assert len(ops_) > 20 and all(len(r) == 4 and float(r[3]) > 0 for r in ops_)
+    import torch
+    if not torch.cuda.is_available():
+        assert G.enable_tuned_gemms() is False
