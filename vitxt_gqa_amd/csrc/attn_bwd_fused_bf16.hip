@@ -151,7 +151,7 @@ __device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dp
                                       const float nd1, const float inv) {
   constexpr int par = I & 1;
   if (DROP) {
-    const float d0 = attn_drop_zero(dpacc[par][2 * M], attn_drop_lo32(mw[M])), d1 = attn_drop_zero(dpacc[par][2 * M + 1], attn_drop_hi32(mw[M]));
+    const float d0 = attn_drop_zero_lo(dpacc[par][2 * M], mw[M]), d1 = attn_drop_zero_hi(dpacc[par][2 * M + 1], mw[M]);
     dsw[M] = fb_pack2(sacc[par][2 * M] * __builtin_fmaf(d0, inv, nd0), sacc[par][2 * M + 1] * __builtin_fmaf(d1, inv, nd1));
   } else {
     dsw[M] = fb_pack2(sacc[par][2 * M] * dpacc[par][2 * M], sacc[par][2 * M + 1] * dpacc[par][2 * M + 1]);

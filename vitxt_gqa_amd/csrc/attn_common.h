@@ -99,6 +99,24 @@ __device__ __forceinline__ float attn_drop_zero(float x, uint32_t m32) {
   return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & ~m32);
 }
 
+// The same two selects as single instructions each (v_bfe_i32 / v_ashrrev_i32 for the 32-bit mask, v_bfi_b32 to clear): written
+// in C the compiler turns "x & ~sign_mask" into a compare + v_cndmask per score and an extra v_and per pair (5 instructions per
+// score pair instead of 4 in the issue-bound phase of the fused backward)
+__device__ __forceinline__ float attn_drop_zero_lo(float x, uint32_t mword) {
+  uint32_t m32;
+  float r;
+  asm("v_bfe_i32 %0, %1, 0, 16" : "=v"(m32) : "v"(mword));
+  asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(r) : "v"(m32), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float attn_drop_zero_hi(float x, uint32_t mword) {
+  uint32_t m32;
+  float r;
+  asm("v_ashrrev_i32 %0, 16, %1" : "=v"(m32) : "v"(mword));
+  asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(r) : "v"(m32), "v"(x));
+  return r;
+}
+
 int attn_setup_dropout(AttnParams& p, float drop_p, uint64_t drop_seed, hipStream_t st, const char* who);
 
 // ---- XCD-aware workgroup -> tile mapping.  MI355X hands consecutive workgroup ids round-robin to its 8 XCDs, each with
