@@ -551,3 +551,27 @@ def test_attention_fwd_one_wave_per_simd_variant(B, L1, n_dec, keep, drop_p, mon
     # two bf16 ulps of the larger of (|out|, 1): the two kernels sum the same products in different orders
     assert ((out1.float() - out0.float()).abs() <= 2.0 ** -6 * out0.float().abs().clamp(min=1.0)).all()
     assert (lse1 - lse0).abs().max().item() < 2e-2
+
+
+@pytest.mark.gpu
+def test_recorded_gemm_selections_load_and_change_no_result_beyond_rounding():
+    """vitxt_gqa_amd/gemm_tuning.py: the recorded hipBLASLt selections load on this card (torch's validators accept the file) and a
+    GEMM of a recorded shape gives the library default's result up to the rounding of a different summation order."""
+    _need_gpu()
+    import torch.cuda.tunable as tunable
+    from vitxt_gqa_amd import gemm_tuning
+    if not gemm_tuning.enable_tuned_gemms():
+        pytest.skip("recorded selections not active (T2S_TUNED_GEMMS=0, TunableOp driven from outside, or other library versions)")
+    assert tunable.is_enabled() and not tunable.tuning_is_enabled() and len(tunable.get_results()) > 20
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M = 647680 // 8                     # (a recorded shape has M = 647 680; any M exercises the lookup, the small one keeps the test light)
+    a = torch.randn(M, 768, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(2304, 768, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    b = torch.randn(2304, generator=g).to(DEV).to(torch.bfloat16)
+    y1 = torch.addmm(b, a, w.t())
+    tunable.enable(False)
+    try:
+        y0 = torch.addmm(b, a, w.t())
+    finally:
+        tunable.enable(True)
+    assert (y1.float() - y0.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, y0.float().abs().max().item())
