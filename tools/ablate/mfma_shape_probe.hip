@@ -9,7 +9,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ inline unsigned mix(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
-template <int SHAPE, bool RANDOM>
+template <int SHAPE, bool RANDOM, int FILL>
 __global__ __launch_bounds__(256, 2) void probe(float* out, unsigned long long* t, int n) {
   bf16x8 a[2], b[2];
   for (int k = 0; k < 2; ++k)
@@ -20,6 +20,8 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, unsigned long long* 
     }
   f32x16 c[4] = {};
   f32x4 d[8] = {};
+  float e[8];
+  for (int j = 0; j < 8; ++j) e[j] = (threadIdx.x & 63) * 1e-3f + j * 0.1f;
   unsigned long long m0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < n; ++i) {
     if (SHAPE == 0) {
@@ -29,28 +31,35 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, unsigned long long* 
 #pragma unroll
       for (int u = 0; u < 8; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u & 1], b[(u >> 1) & 1], d[u], 0, 0, 0);
     }
+    // FILL: softmax-like VALU work beside the MFMAs (per group: FILL x (v_exp + v_fma + v_cvt-like mul)), values stay bounded
+#pragma unroll
+    for (int j = 0; j < FILL; ++j) {
+      e[j & 7] = __builtin_amdgcn_exp2f(e[j & 7] * -0.5f);
+      e[(j + 3) & 7] = __builtin_fmaf(e[j & 7], 0.25f, e[(j + 3) & 7] * 0.5f);
+    }
   }
   unsigned long long m1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
   float s = 0;
   for (int u = 0; u < 4; ++u) for (int j = 0; j < 16; ++j) s += c[u][j];
   for (int u = 0; u < 8; ++u) for (int j = 0; j < 4; ++j) s += d[u][j];
+  for (int j = 0; j < 8; ++j) s += e[j];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0) { t[2 * blockIdx.x] = m1 - m0; t[2 * blockIdx.x + 1] = r1 - r0; }
 }
-template <int SHAPE, bool RANDOM>
+template <int SHAPE, bool RANDOM, int FILL = 0>
 void run(int blocks, int n) {
   float* out; unsigned long long* t;
   hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&t, blocks * 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<SHAPE, RANDOM>), dim3(blocks), dim3(256), 0, 0, out, t, n);
+  hipLaunchKernelGGL((probe<SHAPE, RANDOM, FILL>), dim3(blocks), dim3(256), 0, 0, out, t, n);
   hipDeviceSynchronize();
-  hipEventRecord(e0); hipLaunchKernelGGL((probe<SHAPE, RANDOM>), dim3(blocks), dim3(256), 0, 0, out, t, n); hipEventRecord(e1); hipEventSynchronize(e1);
+  hipEventRecord(e0); hipLaunchKernelGGL((probe<SHAPE, RANDOM, FILL>), dim3(blocks), dim3(256), 0, 0, out, t, n); hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   std::vector<unsigned long long> h(2 * blocks); hipMemcpy(h.data(), t, blocks * 16, hipMemcpyDeviceToHost);
   double mc = 0, rc = 0; for (int i = 0; i < blocks; ++i) { mc += h[2 * i]; rc += h[2 * i + 1]; }
   const double waves = (double)blocks * 4, fl = waves * n * 4.0 * 32 * 32 * 16 * 2;
-  printf("%s operands, %s, %d waves/SIMD: %8.3f ms  %7.0f TFLOP/s  %6.1f cycles per group of 131 kFLOP/wave  clock %.2f x the realtime tick\n",
-         RANDOM ? "random " : "constant", SHAPE ? "16x16x32" : "32x32x16", blocks / 256, ms, fl / (ms * 1e-3) / 1e12, mc / blocks / n, mc / rc);
+  printf("fill %2d, %s operands, %s, %d waves/SIMD: %8.3f ms  %7.0f TFLOP/s  %6.1f cycles per group of 131 kFLOP/wave  clock %.2f x the realtime tick\n",
+         FILL, RANDOM ? "random " : "constant", SHAPE ? "16x16x32" : "32x32x16", blocks / 256, ms, fl / (ms * 1e-3) / 1e12, mc / blocks / n, mc / rc);
   hipFree(out); hipFree(t);
 }
 int main() {
@@ -59,6 +68,10 @@ int main() {
     run<0, false>(512, n); run<1, false>(512, n);
     run<0, true>(512, n);  run<1, true>(512, n);
     run<0, true>(256, n);  run<1, true>(256, n);
+    // with VALU work beside the MFMAs (an attention-like duty cycle: 4 x 32 MFMA cycles per group against 16 / 24 x ~16 VALU cycles)
+    run<0, true, 16>(256, n / 2); run<1, true, 16>(256, n / 2);
+    run<0, true, 24>(256, n / 2); run<1, true, 24>(256, n / 2);
+    run<0, true, 16>(512, n / 2); run<1, true, 16>(512, n / 2);
   }
   return 0;
 }
