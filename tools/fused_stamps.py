@@ -49,3 +49,5 @@ tot = per.sum(1).mean().item()
 for i, n in enumerate(names):
     print("  %-12s %8.0f cycles per tile  (%4.1f %%)" % (n, per[:, i].mean().item(), 100 * per[:, i].mean().item() / tot))
 print("  %-12s %8.0f cycles per tile (stamped build; MFMA time of a tile: 120 x 32 = 3840)" % ("sum", tot))
+print("  shader clock over the sweep (s_memtime per 100 MHz s_memrealtime tick): %.2f GHz (min %.2f, max %.2f over the workgroups)"
+      % (d[:, 7].double().mean().item() / 1e4, d[:, 7].min().item() / 1e4, d[:, 7].max().item() / 1e4))

@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
 #define FB_TICK(k_) { FB_FENCE(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1) :: "memory"); st_sum[k_] += st_t1 - st_t0; st_t0 = st_t1; FB_FENCE(); }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0) :: "memory");
+    const unsigned long long st_c0 = st_t0, st_r0 = __builtin_amdgcn_s_memrealtime();      // the clock: shader cycles per 100 MHz tick over the sweep
 #else
 #define FB_TICK(k_)
 #endif
@@ -712,6 +713,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(dq32 + (int64_t)p.B * p.Lq * (p.H * 64)) + (int64_t)(blockIdx.x & 255) * 8;
       for (int k = 0; k < 6; ++k) dbg[k] = st_sum[k];
       dbg[6] = (unsigned long long)nqt;
+      dbg[7] = ((st_t0 - st_c0) * 1000ull) / (__builtin_amdgcn_s_memrealtime() - st_r0 + 1);       // MHz / 100 * 1000
     }
 #endif
     };
