@@ -232,6 +232,9 @@ def main():
     ap.add_argument("--compact-wire", action="store_true",
                     help="with --host-inputs: ship the OCR tokens as 64-byte slots and build the 604-d PHOC rows "
                          "(context_feature_1) on the GPU with t2s_phoc instead of transferring them")
+    ap.add_argument("--seed", type=int, default=1234,
+                    help="torch.manual_seed before the first step: the dropout seeds of every step follow from it, so `loss_step0` "
+                         "(the loss of the first executed step) can be recomputed from the same seed (tests/test_fullsize_gpu.py)")
     ap.add_argument("--dropout", type=float, default=0.1,
                     help="every dropout probability of the model (hidden, attention-probability, embedding, obj/ocr input). "
                          "Default 0.1 = the reference's config default, which BASELINE.md prescribes for throughput runs; "
@@ -310,6 +313,8 @@ def main():
     batch = to_device(make_batch(B, F, P, V=V, seed=100 + block), dev)
     batch.grounding_noise = tuple(t.to(dev) for t in make_noise(B, F, P, seed=100 + block))
     scalar_reduces = [0]
+    first_loss = []
+    torch.manual_seed(args.seed)        # (model and batch above are name- / block-seeded; this governs the dropout seeds of the steps)
 
     def step(batch=batch):
         if args.forward_only:
@@ -320,8 +325,10 @@ def main():
             # the logging exchange of the reference's loop (_update_meter, base_trainer.py:293-301: reduce_dict of the losses and of
             # the metrics every iteration) as ONE stacked reduce to rank 0
             reduce_dict({**out["losses"], **{"metric/" + k: v for k, v in out.get("metrics", {}).items()}})
-            scalar_reduces[0] += 1
+            scalar_reduces[0] += 1 if world > 1 else 0          # reduce_dict issues no collective in a one-rank group
         loss = sum(l.mean() for l in out["losses"].values())
+        if not first_loss:
+            first_loss.append(loss.detach())          # kept on the device; read after the timed region
         buckets.reset()
         loss.backward()
         buckets.finish()
@@ -437,6 +444,10 @@ def main():
     }
     if not args.forward_only:
         res["loss"] = float(last.detach())
+        # the loss of the FIRST executed step (warm-up or timed): a function of --seed, the name-seeded weights and the block-seeded
+        # batch alone - tests/test_fullsize_gpu.py recomputes it at B=64
+        res["loss_step0"] = float(first_loss[0]) if first_loss else None
+        res["seed"] = args.seed
     # HBM traffic per launch from the PMC counters is a property of ONE configuration: profiles/traffic.json is keyed by
     # (B, F, P, dropout) and anything else reports null
     traffic = {}

@@ -290,3 +290,109 @@ def test_attention_bwd_fused_full_length_against_fp64_heads(drop_p):
                     "head %d %s (dropout %g): max err %.3e at scale %.3e, relative L2 %.3e" % (h, name, drop_p, err, rr.abs().max().item(), rel)
             inv = ~valid[0]
             assert gk[:L1][inv].abs().max().item() == 0 and gv[:L1][inv].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The batch the metric is quoted on, under pytest: B = 64, 100 x 100, bf16 operands (BASELINE.json configs[1] /
+# configs[2]).  At B = 64 the fused QKV buffer is 3 GB (byte offsets beyond 2^31), the attention grids have 20 000+ workgroups
+# over all 8 XCDs and the step keeps ~200 GB of activations: none of that is reached by the B <= 3 tests above.  The reference
+# contract checked is T2S.forward's (pythia/models/t2s.py:153-175): no operation on the path mixes samples, so
+#   * every sample's scores at B = 64 equal its scores when run ALONE (B = 1) with the same noise, ground_frame EQUAL,
+#   * the B = 64 gradient is the mean of the gradients of its two B = 32 halves (both losses are batch means over equal mask counts),
+#   * every live gradient is finite and non-zero,
+# and the benchmark's own first-step loss (bench.py `loss_step0`: dropout 0.1, seeded) is recomputed here from the same seed.
+def test_metric_batch_b64_100x100_equals_its_samples_and_its_halves():
+    _need_gpu()
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    from vitxt_gqa_amd.ddp import DistributedSampler
+    from vitxt_gqa_amd.schema import is_dead_param
+    from vitxt_gqa_amd.synth import make_batch, make_noise
+    from vitxt_gqa_amd.testing import make_model, to_device
+    torch.cuda.empty_cache()          # what earlier tests of this process left in the caching allocator
+    free_b, _ = torch.cuda.mem_get_info(0)
+    if free_b < 230e9:
+        pytest.skip("needs ~215 GB of free HBM (B = 64 keeps ~200 GB of activations), %.0f GB free" % (free_b / 1e9))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t_start = time.time()
+    # ---- (a) bench.py's first step, in a child process (the GPU memory is free again when it returns)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-dropout0", "--seed", "4321"]
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-2000:]
+    line = json.loads([l for l in pr.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert line["config"]["global_batch"] == 64 and "configs[2]" in line["config"]["workload"] and line["config"]["dropout"] == 0.1
+    assert line["loss_step0"] == line["loss"] and line["loss"] == line["loss"]                      # one step: first == last, not NaN
+    # ---- the same model / batch, built the way bench.py builds them
+    V, B = 5000, 64
+    sampler = DistributedSampler(1, num_replicas=1, rank=0, shuffle=True)
+    sampler.set_epoch(1)
+    block = int(sampler.indices()[0])
+    model = make_model(F, P, V, seed=0, dtype=torch.bfloat16, dropout=0.1).to(DEV).train()
+    batch = make_batch(B, F, P, V=V, seed=100 + block)
+    noise = make_noise(B, F, P, seed=100 + block)
+
+    def sample_list(idx=None):
+        bt = batch if idx is None else {k: v[idx] for k, v in batch.items()}
+        s = to_device(bt, DEV)
+        s.grounding_noise = tuple((t if idx is None else t[idx]).to(DEV) for t in noise)
+        return s
+
+    s64 = sample_list()
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        out = model(s64)
+        loss_drop = sum(l.mean() for l in out["losses"].values()).item()
+    assert abs(loss_drop - line["loss_step0"]) <= 5e-4 * abs(loss_drop), (loss_drop, line["loss_step0"])
+    del out
+    # ---- (b) parity configuration (dropout 0): B = 64 forward + backward
+    model.set_dropout(0.0)
+
+    def run(s):
+        model.zero_grad(set_to_none=True)
+        out = model(s)
+        loss = sum(l.mean() for l in out["losses"].values())
+        loss.backward()
+        keep = {k: out[k].detach().float() for k in ("ref_scores", "pos_scores", "neg_scores")}
+        keep["ground_frame"] = out["ground_frame"].clone()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        return loss.item(), keep, grads
+
+    loss64, o64, g64 = run(s64)
+    assert loss64 == loss64 and abs(loss64) < float("inf")
+    named = dict(model.named_parameters())
+    assert set(g64) == {n for n in named if not is_dead_param(n)}
+    for n, g in g64.items():
+        assert torch.isfinite(g).all(), n
+        assert g.abs().max().item() > 0, "gradient of %s is identically zero at B = 64" % n
+    scale = {k: max(1.0, o64[k].abs().max().item()) for k in ("ref_scores", "pos_scores", "neg_scores")}
+    # ---- (c) the two halves: scores of all 64 samples, mean of the half gradients
+    gsum = None
+    for half in (torch.arange(0, 32), torch.arange(32, 64)):
+        lh, oh, gh = run(sample_list(half))
+        for k in scale:
+            err = (oh[k] - o64[k][half]).abs().max().item()
+            assert err < 1e-2 * scale[k], (k, err, scale[k])
+        assert torch.equal(oh["ground_frame"], o64["ground_frame"][half])
+        gsum = gh if gsum is None else {n: gsum[n] + gh[n] for n in gsum}
+        del oh, gh
+    tot = sum(g.double().norm().item() ** 2 for g in g64.values()) ** 0.5
+    worst = 0.0
+    for n, g in g64.items():
+        d = (g.double() - 0.5 * gsum[n].double()).norm().item()
+        worst = max(worst, d / (g.double().norm().item() + 1e-4 * tot))
+        assert d <= 3e-2 * g.double().norm().item() + 1e-4 * tot, (n, d, g.double().norm().item())
+    del gsum
+    # ---- (d) samples 0, 31, 63 alone (B = 1): another grid, other GEMM shapes, the same per-sample function
+    for b in (0, 31, 63):
+        _, o1, _ = run(sample_list(torch.tensor([b])))
+        for k in scale:
+            err = (o1[k][0] - o64[k][b]).abs().max().item()
+            assert err < 1e-2 * scale[k], (b, k, err, scale[k])
+        assert torch.equal(o1["ground_frame"][0], o64["ground_frame"][b])
+    print("B=64 100x100: loss_step0 %.6f (bench %.6f), loss %.6f, total gradient norm %.4e, worst relative half-mean deviation %.2e, %.0f s"
+          % (loss_drop, line["loss_step0"], loss64, tot, worst, time.time() - t_start))
+    del model, g64, o64
+    torch.cuda.empty_cache()

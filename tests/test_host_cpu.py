@@ -142,3 +142,39 @@ def test_tuned_gemm_file_is_well_formed_and_inert_without_a_gpu():
     import torch
     if not torch.cuda.is_available():
         assert G.enable_tuned_gemms() is False
+
+
+def test_compact_key_list_is_clamped_to_its_buffer_when_the_bound_is_violated():
+    """KeyList.compact (the pruned K / V projection of the pos / neg passes) trusts a caller-vouched structural bound.  If the bound
+    is wrong all the same, the compact list must stay inside the [B, capK] buffers the kernels index: cnt + n_dec <= capK for every
+    sample, every gathered row a real row of its own sample, the decoder keys still closing the list.  Pure tensor
+    logic: runs on the CPU."""
+    from vitxt_gqa_amd.ops import KeyList
+    B, L1, n_dec = 3, 300, 12
+    L = L1 + n_dec
+    valid = torch.zeros(B, L1, dtype=torch.bool)
+    valid[0, :40] = True            # inside the bound
+    valid[1, ::2] = True            # 150 keys: violates a bound of 100
+    valid[2, :] = True              # 300 keys: violates it grossly
+    idx = torch.zeros(B, L, dtype=torch.int32)
+    cnt = valid.sum(1).to(torch.int32)
+    for b in range(B):
+        rows = torch.nonzero(valid[b]).flatten().to(torch.int32)
+        idx[b, :len(rows)] = rows
+        idx[b, len(rows):len(rows) + n_dec] = torch.arange(L1, L, dtype=torch.int32)
+    keys = KeyList(idx, cnt, n_dec, L1, cap_hint=100 + n_dec)
+    keys.bound_is_structural = True
+    keys_c, flat, capK = keys.compact(L)
+    assert capK == 128 and keys_c.idx.shape == (B, capK) and flat.shape == (B * capK,)
+    assert int((keys_c.cnt + n_dec).max()) <= capK and keys_c.cnt.tolist() == [40, 116, 116]
+    flat = flat.view(B, capK)
+    for b in range(B):
+        n = int(keys_c.cnt[b])
+        assert (flat[b] >= b * L).all() and (flat[b] < (b + 1) * L).all()                     # rows of the sample's own sequence
+        assert flat[b, :n].tolist() == (idx[b, :n].long() + b * L).tolist()                   # the first n prefix keys, list order
+        assert flat[b, n:n + n_dec].tolist() == list(range(b * L + L1, b * L + L))            # the decoder keys close the list
+        assert (flat[b, n + n_dec:] == b * L).all()                                            # positions behind the list: row 0
+    # an honest bound changes nothing
+    k2 = KeyList(idx[:1], cnt[:1], n_dec, L1, cap_hint=40 + n_dec)
+    k2c, f2, cap2 = k2.compact(L)
+    assert cap2 == 64 and k2c.cnt.tolist() == [40] and f2[:52].tolist() == idx[0, :52].long().tolist()

@@ -373,6 +373,44 @@ def test_attention_bwd_survives_a_wrong_static_key_bound(dtype, drop_p):
         assert torch.equal(ops.attn_bwd(x, out, dout, lse, nofill, **kw), want), hint
 
 
+def test_pruned_kv_path_with_a_violated_structural_bound_stays_in_bounds():
+    """The pruned K / V projection (functional._layer_forward, KeyList.compact) trusts a caller-vouched bound on the visible keys.
+    With the bound VIOLATED (sample 1 has ~240 keys against a vouched 100) the compact list is clamped to its [B, capK] buffer:
+    the launch must not fault, every output must be finite, the sample that respects the bound must come out exactly as through
+    the un-pruned path, and the violating sample must equal the attention over its first capK - n_dec listed keys."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    B, L1, n_dec = 2, 300, 12
+    L = L1 + n_dec
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    valid = torch.zeros(B, L1, dtype=torch.bool)
+    valid[0, torch.randperm(L1, generator=g)[:60]] = True
+    valid[1, torch.randperm(L1, generator=g)[:240]] = True
+    valid = valid.to(DEV)
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1, cap_hint=100 + n_dec)
+    keys.bound_is_structural = True
+    keys_c, flat, capK = keys.compact(L)
+    assert capK == 128 and int((keys_c.cnt + n_dec).max()) <= capK
+    q = x[..., :768].contiguous()
+    kv = x.view(B * L, 2304).index_select(0, flat)[:, 768:].contiguous().view(B, capK, 1536)
+    out, lse = ops.attn_fwd(q, keys_c, kv=kv)
+    dq, dkv = ops.attn_bwd(q, out, dout, lse, keys_c, kv=kv)
+    torch.cuda.synchronize()
+    for t in (out, lse, dq, dkv):
+        assert torch.isfinite(t.float()).all()
+    # reference: the un-pruned path over the list each sample effectively has (sample 1: its first capK - n_dec keys)
+    eff = valid.clone()
+    rows1 = torch.nonzero(valid[1]).flatten()
+    eff[1] = False
+    eff[1, rows1[:capK - n_dec]] = True
+    full = ops.compact_keys(eff, n_dec=n_dec, dec_row0=L1)
+    want, wlse = ops.attn_fwd(x, full)
+    assert (out[0].float() - want[0].float()).abs().max().item() < 1e-6 and (lse[0] - wlse[0]).abs().max().item() < 1e-6
+    assert (out[1].float() - want[1].float()).abs().max().item() < 2e-2 and (lse[1] - wlse[1]).abs().max().item() < 2e-2
+
+
 def test_c_abi_from_two_threads():
     """nn.DataParallel (the reference's shipped default, base_trainer.py:121-126) calls forward from one Python thread per
     replica: the C ABI keeps no global mutable state and its error string is thread-local.  Two threads hammer different

@@ -73,8 +73,10 @@ def test_forward_fp32_matches_reference(case):
     assert abs(losses["train/vtextgqa/InfoNCE"].item() / 1000 - fx["loss_nce"].item()) < 2e-4
 
 
-# bf16 logit tolerance: the north star's 1e-2.  Both fixtures have reference-std attention weights; the ptr fixture scales the pointer
-# projections by 2.5 and the vocabulary head by 0.3 so that the two heads compete (|logit| up to 6.9; cfg1: up to 9.6).
+# bf16 logit tolerance.  The north star's 1e-2 holds at reference-std weights: asserted as such on cfg1 (every logit) and on the
+# VOCABULARY logits of the ptr fixture.  The ptr fixture scales both pointer projections by 2.5 (so that the two heads compete:
+# |logit| up to 6.9; cfg1: up to 9.6), which multiplies a reference-std error of its POINTER logits by 6.25: their effective
+# tolerance is 6.25e-2 (stated here and in DESIGN section 2; the measured maxima are printed by the test).
 BF16_TOL = {"cfg1_b2_f20_p30": 1e-2, "ptr_b3_f8_p10": 1e-2}
 
 
@@ -96,33 +98,50 @@ def test_forward_bf16(case):
     model, s = _run(fx, torch.bfloat16)
     out = model(s)
     tolv = _bf16_tol(fx, BF16_TOL[case])
-    tol = tolv.max().item()
     total = 0
     for k in ("ref_scores", "pos_scores", "neg_scores"):
         err = (out[k].float().cpu() - fx[k]).abs()
-        assert (err < tolv).all(), "%s max abs err: vocabulary logits %.3e, pointer logits %.3e" % (k, err[..., :fx.V].max().item(), err[..., fx.V:].max().item())
+        ev, ep = err[..., :fx.V].max().item(), err[..., fx.V:].max().item()
+        print("%s %s: max abs logit error - vocabulary %.3e (tolerance %.3g), pointer %.3e (tolerance %.3g)" % (
+            case, k, ev, tolv[0].item(), ep, tolv[-1].item()))
+        assert (err < tolv).all(), "%s max abs err: vocabulary logits %.3e, pointer logits %.3e" % (k, ev, ep)
         # pointer / copy indices (north star: bit-exact): the argmax of every decoding row equals the reference's wherever the
-        # reference's own top-2 logit gap exceeds what two logits within the bf16 tolerance can close; the NUMBER of rows that
-        # differ is bounded by the number of such near-tie rows of the reference (asserted: a deviation from bit-exact stated as a count)
-        flips = _index_flips(out[k].float().cpu(), fx[k], 2 * tol)
-        t2 = fx[k].topk(2, -1).values
-        near = int(((t2[..., 0] - t2[..., 1]) < 2 * tol).sum())
+        # reference's own gap between the two competing logits exceeds what those two logits' tolerances can close (checked per
+        # flipped ROW, with the tolerance of the head each of the two logits comes from); the NUMBER of rows that differ is
+        # bounded by the number of such near-tie rows of the reference (a deviation from bit-exact stated as a count)
+        flips = _index_flips(out[k].float().cpu(), fx[k], tolv)
+        near = _near_tie_rows(fx[k], tolv)
         assert flips <= near
         total += flips
-        print("%s %s: %d of %d argmax indices differ (reference rows with a top-2 gap < %g: %d)" % (
-            case, k, flips, fx[k].shape[0] * fx[k].shape[1], 2 * tol, near))
+        print("%s %s: %d of %d argmax indices differ (reference rows whose winner is within tolerance of another logit: %d)" % (
+            case, k, flips, fx[k].shape[0] * fx[k].shape[1], near))
     if case == "ptr_b3_f8_p10":      # teacher-forced rows of this fixture: the winners are OCR tokens AND vocabulary tokens
         am = fx["pos_scores"].argmax(-1)
         assert (am >= fx.V).any() and (am < fx.V).any()
 
 
-def _index_flips(got, want, tol):
-    """Number of rows whose argmax differs; asserts that each of them is a near-tie of the reference (top-2 gap < tol)."""
+def _near_tie_rows(want, tolv):
+    """Rows of the reference in which some other logit j lies within tol[winner] + tol[j] of the winner."""
+    top = want.max(-1, keepdim=True)
+    wi = want.argmax(-1, keepdim=True)
+    close = (top.values - want) < (tolv[wi.squeeze(-1)].unsqueeze(-1) + tolv)
+    close.scatter_(-1, wi, False)
+    return int(close.any(-1).sum())
+
+
+def _index_flips(got, want, tolv):
+    """Number of rows whose argmax differs; asserts that EACH of them is itself a near-tie of the reference between exactly the two
+    indices involved: want[winner] - want[picked] < tol[winner] + tol[picked] (per-logit tolerances: 1e-2 for a vocabulary logit,
+    the gain-scaled value for a pointer logit of the ptr fixture)."""
+    if not torch.is_tensor(tolv):
+        tolv = torch.full((want.shape[-1],), float(tolv) / 2)
     gi, wi = got.argmax(-1), want.argmax(-1)
-    top2 = want.topk(2, dim=-1).values
-    gap = top2[..., 0] - top2[..., 1]
     bad = gi != wi
-    assert (gap[bad] < tol).all(), "argmax differs on rows whose reference top-2 gap is %s (tolerance %g)" % (gap[bad].tolist(), tol)
+    if bad.any():
+        gap = want.gather(-1, wi.unsqueeze(-1)).squeeze(-1) - want.gather(-1, gi.unsqueeze(-1)).squeeze(-1)
+        allow = tolv[wi] + tolv[gi]
+        assert (gap[bad] < allow[bad]).all(), "argmax differs on rows whose reference gap between the two indices is %s (allowed %s)" % (
+            gap[bad].tolist(), allow[bad].tolist())
     return int(bad.sum())
 
 
@@ -300,19 +319,20 @@ def test_cached_decode_equals_reference_loop(case, dtype, tol):
         # (top-2 logit gap below what two logits within the 1e-2 bf16 tolerance can close).  Later steps of that sample were
         # fed a different token and are not comparable.
         got, want = a["pos_scores"].argmax(-1).cpu(), fx["eval_argmax"]
-        top2 = fx["eval_pos_scores"].topk(2, dim=-1).values
-        gap = top2[..., 0] - top2[..., 1]
+        ref_sc = fx["eval_pos_scores"]
         flipped = 0
         for b_ in range(got.shape[0]):
             diff = (got[b_] != want[b_]).nonzero().flatten()
             if diff.numel():
                 t = int(diff[0])
-                assert gap[b_, t].item() < 2 * tol, "sample %d step %d: index %d vs %d at reference gap %.3e" % (
-                    b_, t, int(got[b_, t]), int(want[b_, t]), gap[b_, t].item())
+                gi, wi = int(got[b_, t]), int(want[b_, t])
+                gap = (ref_sc[b_, t, wi] - ref_sc[b_, t, gi]).item()
+                assert gap < (tolv[wi] + tolv[gi]).item(), "sample %d step %d: index %d vs %d at reference gap %.3e (allowed %.3e)" % (
+                    b_, t, gi, wi, gap, (tolv[wi] + tolv[gi]).item())
                 flipped += 1
         # the deviation from "bit-exact" as a number: samples that leave the reference's sequence <= samples whose reference
         # sequence contains a near-tie row at all
-        near = int(((gap < 2 * tol).any(-1)).sum())
+        near = sum(1 for b_ in range(got.shape[0]) if _near_tie_rows(ref_sc[b_], tolv) > 0)
         assert flipped <= near
         print("bf16 greedy decode (%s): %d of %d samples leave the reference's index sequence, each at a near-tie (samples with a near-tie row: %d)"
               % (case, flipped, got.shape[0], near))

@@ -70,8 +70,9 @@ class DistributedSampler:
 
 def reduce_dict(dictionary, group=None):
     """The scalar exchange of the logging path (``pythia/utils/distributed_utils.py:91-110``, called on the losses / metrics of
-    a report): ONE reduce of the stacked values to rank 0, which divides by the world size; the other ranks keep their local
-    values (as in the reference, only the main process logs).  Keys are sorted so that every rank stacks in the same order."""
+    a report): ONE reduce of the stacked values to rank 0, which divides by the world size; what the other ranks' returned values
+    hold is whatever the backend's reduce leaves in a non-destination buffer (as in the reference, only the main process logs).
+    Keys are sorted so that every rank stacks in the same order."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world < 2 or len(dictionary) == 0:
         return dictionary

@@ -234,8 +234,9 @@ class BertLayerFn(torch.autograd.Function):
         return (dx.view(B, L, HID).float(), None, None, None, None, None, None) + _master_grads(g)
 
 
-def _encoder_forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, masters, extra=()):
-    """A stack of layers on x [B, L, 768] fp32; what backward needs goes into ctx (``extra``: further tensors to save).
+def _encoder_forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, masters, extra=(), extra_out=None):
+    """A stack of layers on x [B, L, 768] fp32; what backward needs goes into ctx (``extra``: further tensors to save ahead of the
+    layers' own; ``extra_out``: a list - the stack's output rows are saved too, as the first saved tensor).
     Returns the output rows [B * L, 768] fp32."""
     B, L, _ = x.shape
     flat_w = []
@@ -250,6 +251,8 @@ def _encoder_forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, mas
         xl = x_lo if x_lo is not None else x2
         counts.append([t is not None for t in saved])
         keep.extend(t for t in saved if t is not None)
+    if extra_out is not None:
+        extra = (x2,) + tuple(extra)
     ctx.keys, ctx.drop, ctx.counts, ctx.n_extra = keys, (drop_p, seeds, attn_drop_p), counts, len(extra)
     ctx.save_for_backward(*extra, *keep)
     return x2
@@ -306,8 +309,10 @@ class QTVFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, *masters):
         B, L, _ = x.shape
-        enc = _encoder_forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, masters).view(B, L, HID)
-        ctx.enc, ctx.dt = enc, dt             # a plain attribute: the tensor is this node's own intermediate, nobody else sees it
+        # the encoder output is this node's own intermediate: it is kept through save_for_backward (freed with the other saved
+        # tensors when backward has run, version-checked by autograd), written by the last LayerNorm kernel into a buffer allocated here
+        enc = _encoder_forward(ctx, x, keys, n_layers, dt, drop_p, seeds, attn_drop_p, masters, extra_out=[]).view(B, L, HID)
+        ctx.dt = dt
         return ops.tanh_residual_fwd(x.contiguous(), enc)
 
     @staticmethod
@@ -315,7 +320,9 @@ class QTVFn(torch.autograd.Function):
         B, L, _ = gy.shape
         if gy.dtype != F32 or gy.stride(2) != 1 or gy.stride(1) != HID:
             gy = gy.float().contiguous()
-        g_enc = ops.tanh_residual_bwd(gy, ctx.enc, ctx.dt)
+        enc = ctx.saved_tensors[0].view(B, L, HID)
+        g_enc = ops.tanh_residual_bwd(gy, enc, ctx.dt)
+        del enc
         d, g = _encoder_backward(ctx, g_enc.view(B * L, HID))
         del g_enc
         return (ops.add_cast(gy, d), None, None, None, None, None, None) + g

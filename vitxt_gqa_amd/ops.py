@@ -45,10 +45,21 @@ class KeyList:
             B = self.idx.shape[0]
             capK = min(self.idx.shape[1], (self.cap_hint + 63) // 64 * 64)
             pos = torch.arange(capK, device=self.idx.device, dtype=torch.int32)
-            live = pos.unsqueeze(0) < (self.cnt + self.n_dec).unsqueeze(1)
-            rows = torch.where(live, self.idx[:, :capK], torch.zeros((), dtype=torch.int32, device=self.idx.device)).long()
+            # The caller vouches for the bound (bound_is_structural); should it be violated all the same, the list is CLAMPED to the
+            # buffer (no host sync): the prefix keys beyond capK - n_dec are dropped - a wrong result for that sample, but no key-list
+            # position ever points past the [B, capK] buffers the kernels index (an out-of-bounds K / V read can take the node down).
+            cnt_c = torch.clamp(self.cnt, max=capK - self.n_dec)
+            live = pos.unsqueeze(0) < (cnt_c + self.n_dec).unsqueeze(1)
+            src = self.idx[:, :capK]
+            if capK < self.idx.shape[1]:
+                # the decoder keys close the list at positions cnt .. cnt + n_dec - 1 of the ORIGINAL list: re-read them there, so
+                # that a clamped list still ends in its decoder rows
+                dec_pos = (self.cnt.unsqueeze(1) + (pos.unsqueeze(0) - cnt_c.unsqueeze(1))).clamp(0, self.idx.shape[1] - 1).long()
+                is_dec = pos.unsqueeze(0) >= cnt_c.unsqueeze(1)
+                src = torch.where(is_dec, torch.gather(self.idx, 1, dec_pos), src)
+            rows = torch.where(live, src, torch.zeros((), dtype=torch.int32, device=self.idx.device)).long()
             flat = (rows + torch.arange(B, device=rows.device).unsqueeze(1) * L).reshape(-1)
-            keys_c = KeyList(pos.unsqueeze(0).expand(B, capK).contiguous(), self.cnt, self.n_dec, self.dec_q0, min(self.cap_hint, capK), None)
+            keys_c = KeyList(pos.unsqueeze(0).expand(B, capK).contiguous(), cnt_c, self.n_dec, self.dec_q0, min(self.cap_hint, capK), None)
             self._compact[L] = (keys_c, flat, capK)
         return self._compact[L]
 

@@ -97,10 +97,23 @@ class FusedClipAdam(torch.optim.Adam):
         if len(steps) != 1:
             # uneven step counts (a parameter that got no gradient on some iterations, or a resumed reference checkpoint): the
             # kernels carry ONE bias correction, torch's Adam keeps per-parameter steps (the reference) - take its path this step
+            # (torch's multi-tensor "foreach" implementation, not its per-parameter loop; said once, since uneven counts stay uneven)
+            if not getattr(self, "_warned_uneven", False):
+                import warnings
+                warnings.warn("FusedClipAdam: per-parameter step counts differ (%d distinct values, e.g. after loading a checkpoint whose "
+                              "parameters were updated unevenly): taking torch.optim.Adam's foreach path with clip_grad_norm_ instead of "
+                              "the fused clip + Adam kernels on this and every later step" % len(steps))
+                self._warned_uneven = True
             norm = None
             if max_norm is not None:
-                norm = torch.nn.utils.clip_grad_norm_([p for _, p in live], max_norm)
-            super().step()
+                norm = torch.nn.utils.clip_grad_norm_([p for _, p in live], max_norm, foreach=True)
+            for g in self.param_groups:
+                g["foreach"] = True
+            try:
+                super().step()
+            finally:
+                for g in self.param_groups:
+                    g["foreach"] = False
             return norm
         step = steps.pop() + 1
         tb = self._tables
