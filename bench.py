@@ -99,12 +99,17 @@ class _Budget(Exception):
     pass
 
 
-def cpu_baseline(V, seed=0, budget_s=240):
-    """Reference semantics (CPU oracle) timed on the host cores on a bounded sample of the workload: the full train step at
-    B=1, 100 frames x {5, 20} OCR tokens per frame, 1 warm-up + 3 TIMED steps at each point (mean and std reported; BASELINE.md
-    section 3's protocol), about 30 s of CPU work; the 100 x 100 step itself needs ~100 GB of eager autograd state and > 300 s, so
-    ``value`` is the largest measured point EXTRAPOLATED to the 100 x 100 shape by the FLOP model (``kind`` says so; the measured
-    scaling exponent in L is reported beside the model's).  Runs BEFORE the GPU is touched, under a hard wall-clock budget."""
+def cpu_baseline(V, seed=0, budget_s=240, full=(100, 100), guard_s=150):
+    """Reference semantics (CPU oracle) timed on the host cores: ONE REAL full train step (forward, both losses, backward, clip,
+    Adam; fp32; B=1) at the metric's own shape, 100 frames x 100 OCR tokens (L = 10 132), with the oracle's attention evaluated by
+    torch's fused CPU attention on the same additive masks (oracle.ATTENTION_IMPL = "sdpa": BASELINE.md section 3 allows it; the
+    eager form needs ~100 GB of [12, L, L] autograd state there; tests/test_oracle_golden.py pins the two forms to each other).
+    Protocol: a warm-up + timed steps at 100 x 20 (L = 2 132) first - they warm the thread pool and price the full-size step by
+    the FLOP model; the full-size point then runs 1 warm-up + up to 3 timed steps while an estimate of the next step fits the
+    wall guard (``guard_s``), at least ONE timed step (without the warm-up when even two steps would not fit).  ``kind`` is
+    "port, measured" when the full-size step was timed; if not even one step fits the guard (a box with few or slow cores) the
+    largest measured point is EXTRAPOLATED by the FLOP model and ``kind`` says "port, extrapolated".  Runs BEFORE the GPU is
+    touched, under a hard wall-clock budget."""
     import signal
     from oracle import t2s_oracle as O
     from vitxt_gqa_amd.init import make_state_dict
@@ -116,17 +121,13 @@ def cpu_baseline(V, seed=0, budget_s=240):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 64))
     torch.set_num_threads(cores)
-    try:
-        import psutil
-        free_gb = psutil.virtual_memory().available / 2 ** 30
-    except Exception:
-        free_gb = 0.0
-    Fs, Bs = 100, 1
-    f_full, _ = flops_per_sample_fwd(100, 100, V)
+    Fs, Bs = full[0], 1
+    f_full, _ = flops_per_sample_fwd(full[0], full[1], V)
     sd = make_state_dict(state_dict_schema(V), seed=seed)
     for k, v in sd.items():
         v.requires_grad_(not O.is_dead(k))
-    result = {"value": None, "unit": "samples/s", "cores": cores, "kind": "port, extrapolated", "sample": "not measured (budget exceeded)"}
+    result = {"value": None, "unit": "samples/s", "cores": cores, "kind": "port, extrapolated", "sample": "not measured (budget exceeded)",
+              "attention": "torch SDPA (CPU) on the reference's additive masks"}
     points = []
 
     def on_alarm(signum, frame):
@@ -135,56 +136,66 @@ def cpu_baseline(V, seed=0, budget_s=240):
     old = signal.signal(signal.SIGALRM, on_alarm)
     signal.alarm(int(budget_s))
     t_start = time.time()
+    prev_impl = O.ATTENTION_IMPL
+    O.ATTENTION_IMPL = "sdpa"
     try:
-        for Ps, min_steps, max_steps in ((5, 3, 3), (20, 3, 3)):
+        for Ps in sorted({min(20, full[1]), full[1]}):
+            is_full = Ps == full[1]
             L = T_Q + Fs + Fs * Ps + DEC
             f_s, _ = flops_per_sample_fwd(Fs, Ps, V)
+            warm, max_steps = True, 3
             if points:
                 est = points[-1]["s_per_step"] * f_s / points[-1]["flops"]              # FLOP-model estimate of one step here
-                need_gb = 11 * 5 * 12 * L * L * 4 / 2 ** 30                            # ~5 live [12, L, L] fp32 tensors x 11 layers
-                if (time.time() - t_start) + est * (min_steps + 1) > budget_s * 0.9 or need_gb > 0.5 * free_gb:
-                    result["skipped_point"] = "B=1 x 100 x %d (L=%d): est. %.0f s/step, ~%.0f GB of autograd state vs %.0f GB free" % (Ps, L, est, need_gb, free_gb)
+                left = min(guard_s, budget_s * 0.95 - (time.time() - t_start))
+                if est > left:
+                    result["skipped_point"] = "B=1 x %d x %d (L=%d): estimated %.0f s/step against %.0f s left under the wall guard" % (Fs, Ps, L, est, left)
                     break
+                warm = 2 * est <= left
+                max_steps = max(1, min(3, int(left / est) - (1 if warm else 0)))
             batch = make_batch(Bs, Fs, Ps, V=V, seed=seed)
             e1, e2 = make_noise(Bs, Fs, Ps, seed)
             cfg = dict(frame_topk=5, ocr_topk=5, frame_num=Fs, ocr_frame_num=Ps)
             st = {}
-            O.train_step(sd, batch, cfg, st, 1, expo_frame=e1, expo_ocr=e2)      # one untimed warm-up step at each shape
+            t_pt = time.time()
+            if warm:
+                O.train_step(sd, batch, cfg, st, 1, expo_frame=e1, expo_ocr=e2)      # untimed warm-up step at this shape
             times = []
-            n = 0
-            while n < min_steps or n < max_steps:
+            while len(times) < max_steps:
                 t0 = time.time()
-                O.train_step(sd, batch, cfg, st, n + 2, expo_frame=e1, expo_ocr=e2)
+                O.train_step(sd, batch, cfg, st, len(times) + 2, expo_frame=e1, expo_ocr=e2)
                 times.append(time.time() - t0)
-                n += 1
+                if is_full and (time.time() - t_pt) + times[-1] > guard_s:
+                    break
+            n = len(times)
             dt = sum(times) / n
             sd_t = (sum((x - dt) ** 2 for x in times) / max(1, n - 1)) ** 0.5
-            points.append({"frames": Fs, "ocr_per_frame": Ps, "L": L, "s_per_step": dt, "s_per_step_std": sd_t, "steps": n, "flops": f_s,
-                           "samples_per_s": Bs / dt, "samples_per_s_std": Bs * sd_t / (dt * dt)})
+            points.append({"frames": Fs, "ocr_per_frame": Ps, "L": L, "s_per_step": dt, "s_per_step_std": sd_t, "steps": n, "warmup_steps": int(warm),
+                           "flops": f_s, "samples_per_s": Bs / dt, "samples_per_s_std": Bs * sd_t / (dt * dt), "full": is_full})
     except _Budget:
         result["sample"] = "stopped by the %ds wall-clock budget" % budget_s
     finally:
         signal.alarm(0)
         signal.signal(signal.SIGALRM, old)
+        O.ATTENTION_IMPL = prev_impl
     if points:
         big = points[-1]
-        result.update(value=big["samples_per_s"] * big["flops"] / f_full, measured_samples_per_s_at_sample_shape=big["samples_per_s"],
-                      measured_samples_per_s_std=big["samples_per_s_std"],
-                      measured_points=[{k: p[k] for k in ("frames", "ocr_per_frame", "L", "s_per_step", "s_per_step_std", "steps")} for p in points],
-                      sample="oracle (plain-torch CPU restatement of the reference) full train step, fp32, %d threads, "
-                             "B=%d x %d frames x %d OCR/frame (L=%d): 1 warm-up + %d timed steps, %.2f +- %.2f s/step = %.3f samples/s "
-                             "MEASURED; value = that rate EXTRAPOLATED by the FLOP model (x%.4f) to the 100x100 workload, which "
-                             "does not fit the host (eager [12, L, L] scores)"
-                             % (cores, Bs, Fs, big["ocr_per_frame"], big["L"], big["steps"], big["s_per_step"], big["s_per_step_std"],
-                                big["samples_per_s"], big["flops"] / f_full))
+        measured = bool(big["full"])
+        what = ("oracle (plain-torch CPU restatement of the reference, attention through torch SDPA) full train step, fp32, %d threads, "
+                "B=%d x %d frames x %d OCR/frame (L=%d): %d warm-up + %d timed step(s), %.2f +- %.2f s/step = %.4f samples/s MEASURED"
+                % (cores, Bs, Fs, big["ocr_per_frame"], big["L"], big["warmup_steps"], big["steps"], big["s_per_step"], big["s_per_step_std"],
+                   big["samples_per_s"]))
+        result.update(kind="port, measured" if measured else "port, extrapolated",
+                      value=big["samples_per_s"] * (1.0 if measured else big["flops"] / f_full),
+                      measured_samples_per_s_at_sample_shape=big["samples_per_s"], measured_samples_per_s_std=big["samples_per_s_std"],
+                      measured_points=[{k: p[k] for k in ("frames", "ocr_per_frame", "L", "s_per_step", "s_per_step_std", "steps", "warmup_steps")} for p in points],
+                      sample=what + (" at the metric's own shape: value = that rate" if measured else
+                                     "; value = that rate EXTRAPOLATED by the FLOP model (x%.4f) to the %d x %d workload, whose step did not fit "
+                                     "the %d s wall guard on this host" % (big["flops"] / f_full, full[0], full[1], guard_s)))
         if len(points) >= 2:
             import math
             a, b = points[-2], points[-1]
-            expo = math.log(b["s_per_step"] / a["s_per_step"]) / math.log(b["L"] / a["L"])
-            expo_model = math.log(b["flops"] / a["flops"]) / math.log(b["L"] / a["L"])
-            L_full = T_Q + 100 + 100 * 100 + DEC
-            result.update(measured_scaling_exponent_in_L=expo, flop_model_exponent_in_L=expo_model,
-                          value_by_measured_exponent=1.0 / (b["s_per_step"] * (L_full / b["L"]) ** expo))
+            result.update(measured_scaling_exponent_in_L=math.log(b["s_per_step"] / a["s_per_step"]) / math.log(b["L"] / a["L"]),
+                          flop_model_exponent_in_L=math.log(b["flops"] / a["flops"]) / math.log(b["L"] / a["L"]))
     return result
 
 
@@ -253,7 +264,7 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     cpu_res = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_res = cpu_baseline(args.vocab)          # host-only; runs before any GPU call
+        cpu_res = cpu_baseline(args.vocab, full=(args.frames, args.ocr))          # host-only; runs before any GPU call
         print("[bench] cpu_baseline:", json.dumps(cpu_res), file=sys.stderr, flush=True)
     import torch.distributed as dist
     # rehearsal hooks (never set by the driver): T2S_BENCH_BACKEND=gloo and T2S_BENCH_ONE_GPU=1 run the multi-rank path with
@@ -460,6 +471,13 @@ def main():
     bpath = os.path.join(ROOT, "profiles", "mfma_busy.json")
     if os.path.exists(bpath):
         busy = json.load(open(bpath)).get("drop%g" % args.dropout, {})
+    # provenance of the two figures that are NOT measured in this run (they need rocprofv3 --pmc passes): file, configuration
+    # and round they were taken at, carried in the line itself
+    tkey = "B%d_F%d_P%d_drop%g" % (B, F, P, args.dropout)
+    traffic_source = ("profiles/traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench command (%s), NOT measured "
+                      "in this run" % (tkey, traffic.get("_round", "round 3 kernels"))) if traffic else None
+    busy_source = ("profiles/mfma_busy.json[drop%g]: SQ_VALU_MFMA_BUSY_CYCLES of the kernel ALONE in tools/attn_probe.py at B=8, L=10132, "
+                   "70 %% of the keys visible (%s), NOT measured in this run" % (args.dropout, busy.get("_round", "round 3 kernels"))) if busy else None
     L_seq = T_Q + F + F * P + (3 * DEC if not args.forward_only else DEC)
     alg_fwd = 4.0 * B * L_seq * HID * 2            # Q, K, V read + O written once, bf16 (dense upper bound: every key visible)
     alg_bwd = 8.0 * B * L_seq * HID * 2            # Q, K, V, O, dO read + dQ, dK, dV written once
@@ -469,6 +487,7 @@ def main():
                      "bound": "mfma", "achieved": att_f["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": att_f["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic.get("attn_fwd"),
                      "mfma_busy": (busy.get("attn_fwd_bf16_kernel") or {}).get("mfma_busy"),
+                     "traffic_source": traffic_source, "mfma_busy_source": busy_source,
                      "algorithmic_bytes_per_launch": alg_fwd,
                      "traffic_over_algorithmic": (traffic.get("attn_fwd") / alg_fwd) if traffic.get("attn_fwd") else None,
                      "launches": att_f["launches"], "avg_launch_ms": att_f["avg_ms"], "ms_per_step": att_f["total_ms"] / args.steps,
@@ -484,6 +503,7 @@ def main():
                      "bound": "mfma", "achieved": att_b["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": att_b["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic.get("attn_bwd"),
                      "mfma_busy": (busy.get("attn_bwd_fused_bf16_kernel") or {}).get("mfma_busy"),
+                     "traffic_source": traffic_source, "mfma_busy_source": busy_source,
                      "algorithmic_bytes_per_launch": alg_bwd,
                      "traffic_over_algorithmic": (traffic.get("attn_bwd") / alg_bwd) if traffic.get("attn_bwd") else None,
                      "launches": att_b["launches"], "fused_5_product_launches": att_b["fused_launches"], "avg_launch_ms": att_b["avg_ms"],

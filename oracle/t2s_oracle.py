@@ -51,6 +51,14 @@ def linear(x, w, b=None):
     return y if b is None else y + b
 
 
+# How bert_layer evaluates softmax(q k^T / sqrt(d) + mask) v.  "eager" spells the reference's arithmetic out (BertSelfAttention:
+# scores materialised as [B, 12, L, L]); "sdpa" hands the same additive mask to torch's fused CPU attention, which never
+# materialises the scores - BASELINE.md section 3 allows it for the timed CPU baseline ("or use torch SDPA CPU"), where the eager
+# form needs ~100 GB of autograd state at L = 10 132.  Same function (tests/test_oracle_golden.py::test_sdpa_attention_equals_the_
+# eager_form, L = 632, forward and every gradient); parity tests always run "eager".
+ATTENTION_IMPL = "eager"
+
+
 def bert_layer(sd, prefix, x, ext_mask):
     """One BertLayer.  ``ext_mask`` is additive, broadcastable to [B, h, Lq, Lk]."""
     p = prefix
@@ -63,9 +71,16 @@ def bert_layer(sd, prefix, x, ext_mask):
     q = heads(linear(x, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"]))
     k = heads(linear(x, sd[p + "attention.self.key.weight"], sd[p + "attention.self.key.bias"]))
     v = heads(linear(x, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"]))
-    scores = q @ k.transpose(-1, -2) / math.sqrt(dh) + ext_mask
-    probs = torch.softmax(scores, dim=-1)
-    ctx = (probs @ v).permute(0, 2, 1, 3).reshape(B, L, H)
+    if ATTENTION_IMPL == "sdpa":
+        m = ext_mask.to(q.dtype)
+        if m.dim() < 4:
+            m = m.view((1,) * (4 - m.dim()) + tuple(m.shape))
+        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=m.expand(B, -1, L, L), scale=1.0 / math.sqrt(dh))
+        ctx = ctx.permute(0, 2, 1, 3).reshape(B, L, H)
+    else:
+        scores = q @ k.transpose(-1, -2) / math.sqrt(dh) + ext_mask
+        probs = torch.softmax(scores, dim=-1)
+        ctx = (probs @ v).permute(0, 2, 1, 3).reshape(B, L, H)
     a = linear(ctx, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
     a = layer_norm(a + x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"])
     i = gelu_erf(linear(a, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))

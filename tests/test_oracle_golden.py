@@ -195,3 +195,34 @@ def test_ptr_fixture_is_not_degenerate():
     assert (prev >= fx.V).float().mean().item() >= 0.3
     for name in ("tiny_b2_f6_p8", "cfg1_b2_f20_p30"):        # documented: these two ARE constant (the decoder echoes its input)
         assert (Fixture(name)["eval_argmax"] == 1).all()
+
+
+def test_sdpa_attention_equals_the_eager_form():
+    """bench.py's measured CPU baseline times the oracle with ``ATTENTION_IMPL = "sdpa"`` (torch's fused CPU attention fed the same
+    additive 0 / -10000 masks; BASELINE.md section 3 allows it).  It must be the same function as the eager restatement that the
+    golden fixtures pin: one full train step (forward, both losses, backward, clip, Adam) at 100 frames x 5 OCR tokens (L = 632),
+    both ways - loss, both loss terms, gradient norm and every updated parameter."""
+    from oracle import t2s_oracle as O
+    from vitxt_gqa_amd.init import make_state_dict
+    from vitxt_gqa_amd.schema import state_dict_schema
+    from vitxt_gqa_amd.synth import make_batch, make_noise
+    V, Fn, Pn = 300, 100, 5
+    batch = make_batch(1, Fn, Pn, V=V, seed=3, text_vocab=1000)
+    e1, e2 = make_noise(1, Fn, Pn, 3)
+    cfg = dict(frame_topk=5, ocr_topk=5, frame_num=Fn, ocr_frame_num=Pn)
+    res = {}
+    assert O.ATTENTION_IMPL == "eager"
+    try:
+        for impl in ("eager", "sdpa"):
+            O.ATTENTION_IMPL = impl
+            sd = make_state_dict(state_dict_schema(V, text_vocab=1000), seed=0)
+            for k, v in sd.items():
+                v.requires_grad_(not O.is_dead(k))
+            res[impl] = (O.train_step(sd, batch, cfg, {}, 1, expo_frame=e1, expo_ocr=e2), {k: v.detach().clone() for k, v in sd.items()})
+    finally:
+        O.ATTENTION_IMPL = "eager"
+    (la, ga, a1, a2), (lb, gb, b1, b2) = res["eager"][0], res["sdpa"][0]
+    assert abs(la - lb) < 1e-5 * abs(la) and abs(a1 - b1) < 1e-5 * abs(a1) + 1e-7 and abs(a2 - b2) < 1e-5 * abs(a2) + 1e-7
+    assert abs(ga - gb) < 1e-4 * ga
+    for k, v in res["eager"][1].items():
+        assert (v - res["sdpa"][1][k]).abs().max().item() < 2e-6, k          # one Adam step moves a parameter by lr = 1e-4 at most
