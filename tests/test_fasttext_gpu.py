@@ -37,3 +37,20 @@ def test_fasttext_rows_bit_exact(tmp_path, dim, bucket):
     # a preallocated output (e.g. the arena field the model reads) and the all-empty batch
     out = torch.full((2, 5, dim), 7.0, device="cuda:0")
     assert tab.features([[], []], 5, out=out).abs().max().item() == 0
+
+
+def test_golden_vectors_of_the_real_fasttext_library_on_the_gpu():
+    """The HIP gather + average against vectors of the REAL fasttext module, when tests/golden/make_fasttext_golden.py has been run
+    where that wheel exists (it is in neither the reference checkout nor the build image); skips otherwise."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    vec, binf = os.path.join(golden, "fasttext_vectors.npz"), os.path.join(golden, "fasttext_tiny.bin")
+    if not (os.path.exists(vec) and os.path.exists(binf)):
+        pytest.skip("no fasttext golden vectors: run tests/golden/make_fasttext_golden.py where the fasttext wheel is installed")
+    from vitxt_gqa_amd.fasttext import FastTextTable
+    z = np.load(vec, allow_pickle=True)
+    tab = FastTextTable.load(binf, device="cuda:0")
+    toks = [str(t) for t in z["tokens"]]
+    got = tab.features([toks], len(toks)).cpu().numpy()[0]
+    assert np.allclose(got, z["token_vectors"], atol=1e-6)
