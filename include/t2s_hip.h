@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2S_ABI_VERSION 3
+#define T2S_ABI_VERSION 4
 #define T2S_F32 0
 #define T2S_BF16 1
 #define T2S_HEAD_DIM 64
@@ -101,12 +101,20 @@ int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, const void* o
                       int64_t o_row_stride, int64_t o_batch_stride,
                       float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 /* The same gradients from ONE key-stationary kernel that runs the algorithm's five matrix products per (query, key) pair
- * (S and dP are computed once; the two-kernel form above recomputes them: seven): bf16; attention dropout as above (same mask).  dQ is summed
- * across the 384-key blocks of a (sample, head) with fp32 atomics into dq32 [B, Lq, H*64] (workspace, contents on entry
- * irrelevant: zeroed here) and then rounded once into dq; the float sum makes dq depend on arrival order in its last bits
- * (dk / dv stay deterministic).  row_valid as for t2s_attn_bwd_fill, or NULL (then the caller zero-fills dk / dv). */
+ * (S and dP are computed once; the two-kernel form above recomputes them: seven): bf16; attention dropout as above (same mask).
+ * dQ is a sum over the 384-key blocks of a (sample, head); dq_mode picks how it is formed:
+ *   1  ordered hand-off (default of the Python layer): the key blocks of a pair add their tiles in block order, each reading
+ *      the running fp32 sum of its predecessors and storing the new one with plain write-through stores, the last one writing
+ *      bf16 dq itself - no zero fill, no cast pass, dq BIT-REPRODUCIBLE;
+ *   0  fp32 atomics into a [B, Lq, H*64] buffer + a cast pass (rounds 2-3): dq depends on arrival order in its last bits.
+ * dk / dv are deterministic either way.  workspace: t2s_attn_bwd_fused_workspace_bytes(B, H, Lq) bytes of device memory, contents
+ * on entry irrelevant (the call clears what it needs); word 24 of it (uint32) is a status word: bit 0 set = a bounded spin of
+ * the hand-off timed out (cannot happen unless a workgroup died; dq is then wrong but the launch ended).
+ * row_valid as for t2s_attn_bwd_fill, or NULL (then the caller zero-fills dk / dv). */
+int64_t t2s_attn_bwd_fused_workspace_bytes(int B, int H, int Lq);
 int t2s_attn_bwd_fused(const void* q, const void* k, const void* v, const void* out, const void* dout,
-                       const float* lse, float* delta, void* dq, void* dk, void* dv, float* dq32,
+                       const float* lse, float* delta, void* dq, void* dk, void* dv,
+                       void* workspace, int64_t workspace_bytes, int dq_mode,
                        const int32_t* kv_idx, const int32_t* kv_cnt, const uint8_t* row_valid,
                        int B, int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys,
                        int64_t q_row_stride, int64_t q_batch_stride,

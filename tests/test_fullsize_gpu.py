@@ -216,14 +216,18 @@ def test_attn_bwd_fill_equals_zero_fill_path_full_length():
     a = ops.attn_bwd(x, out, dout, lse, keys, fused=False)                  # fill path (keys.valid8 present), two-kernel form
     b = ops.attn_bwd(x, out, dout, lse, plain, fused=False)                 # zero-fill path
     assert torch.equal(a, b)
-    # the fused five-product form: dK / dV deterministic and equal between its two fill paths, dQ (summed with float atomics)
-    # equal to rounding; all of it within bf16 rounding of the two-kernel form
+    # the fused five-product form: equal between its two fill paths BIT FOR BIT - dK / dV always were, dQ is since its sum across
+    # the key blocks runs as the ordered hand-off (round 4) - and within bf16 rounding of the two-kernel form; the atomic dQ sum of
+    # rounds 2-3 (dq_mode 0) equals the hand-off's to summation-order noise
     fa = ops.attn_bwd(x, out, dout, lse, keys, fused=True)
     fb = ops.attn_bwd(x, out, dout, lse, plain, fused=True)
-    assert torch.equal(fa[..., 768:], fb[..., 768:])
+    assert ops.fused_handoff_status() == 0
+    assert torch.equal(fa, fb)
     sc = a.float().abs().max().item()
-    assert (fa[..., :768].float() - fb[..., :768].float()).abs().max().item() < 1e-2 * sc
     assert (fa.float() - a.float()).abs().max().item() < 3e-2 * sc
+    fc = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=0)
+    assert torch.equal(fa[..., 768:], fc[..., 768:])
+    assert (fa[..., :768].float() - fc[..., :768].float()).abs().max().item() < 1e-2 * sc
 
 
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
@@ -366,7 +370,8 @@ def test_metric_batch_b64_100x100_equals_its_samples_and_its_halves():
     assert set(g64) == {n for n in named if not is_dead_param(n)}
     for n, g in g64.items():
         assert torch.isfinite(g).all(), n
-        assert g.abs().max().item() > 0, "gradient of %s is identically zero at B = 64" % n
+        # (bench.py's synthetic batch teacher-forces vocabulary tokens only: the LayerNorm of PrevPredEmbeddings' OCR branch sees no row)
+        assert g.abs().max().item() > 0 or "prev_pred_embeddings.ocr_layer_norm" in n, "gradient of %s is identically zero at B = 64" % n
     scale = {k: max(1.0, o64[k].abs().max().item()) for k in ("ref_scores", "pos_scores", "neg_scores")}
     # ---- (c) the two halves: scores of all 64 samples, mean of the half gradients
     gsum = None

@@ -458,14 +458,20 @@ def test_c_abi_from_two_threads():
     assert "gelu" in msgs[1] and "gelu" not in msgs[0], msgs
 
 
+@pytest.mark.parametrize("dq_mode", [1, 0])
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
-@pytest.mark.parametrize("B,L1,n_dec,keep", CASES + [(2, 1000, 12, 0.7), (2, 900, 0, 1.0), (1, 1500, 12, 0.3)])
-def test_attention_bwd_fused_five_products(B, L1, n_dec, keep, drop_p):
-    """t2s_attn_bwd_fused (one key-stationary kernel, S and dP computed once, dQ summed across 384-key blocks with fp32 atomics)
-    against the fp64 gradient and against the two-kernel form; dK / dV of rows outside the key list exactly zero, with and
-    without the in-call zero fill."""
+@pytest.mark.parametrize("B,L1,n_dec,keep", CASES + [(2, 1000, 12, 0.7), (2, 900, 0, 1.0), (1, 1500, 12, 0.3), (2, 768, 0, 1.0), (1, 1140, 12, 1.0),
+                                                    (1, 1150, 12, 1.0)])
+def test_attention_bwd_fused_five_products(B, L1, n_dec, keep, drop_p, dq_mode):
+    """t2s_attn_bwd_fused (one key-stationary kernel, S and dP computed once, dQ summed across the 384-key blocks of a pair by the
+    ordered hand-off - dq_mode 1, the default - or with fp32 atomics - dq_mode 0) against the fp64 gradient and against the
+    two-kernel form; dK / dV of rows outside the key list exactly zero, with and without the in-call zero fill.  The last three
+    cases end the key list exactly ON a block boundary (768 = 2 x 384 prefix keys without decoder keys; 1140 + 12 = 3 x 384) and
+    split the 12 decoder keys over two edge blocks (1150 + 12: two keys in the third block, ten in the fourth): who finishes dQ."""
     _need_gpu()
     from vitxt_gqa_amd import ops
+    if dq_mode == 0 and drop_p and L1 < 700:
+        pytest.skip("the atomic form's small dropout cases add nothing over the hand-off's")
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + L1 + 1)
     L = L1 + n_dec
     x = (torch.randn(B, L, 2304, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
@@ -484,7 +490,10 @@ def test_attention_bwd_fused_five_products(B, L1, n_dec, keep, drop_p):
         (gref,) = torch.autograd.grad(ref, xr, dout.double())
         scale = gref.abs().max().item()
     for kl in (keys, ops.KeyList(keys.idx, keys.cnt, keys.n_dec, keys.dec_q0, None, None)):       # in-call fill / caller's zero fill
-        got = ops.attn_bwd(x, out, dout, lse, kl, fused=True, **kw)
+        got = ops.attn_bwd(x, out, dout, lse, kl, fused=True, dq_mode=dq_mode, **kw)
+        assert ops.fused_handoff_status() == 0
+        if dq_mode == 1:                               # the ordered hand-off sums in a fixed order: bit-reproducible
+            assert torch.equal(got, ops.attn_bwd(x, out, dout, lse, kl, fused=True, dq_mode=1, **kw))
         if gref is not None:
             gerr = (got.double() - gref).abs().max().item()
             assert gerr < 3e-2 * max(1.0, scale) * 2, "fused bwd max err %.3e (scale %.3e)" % (gerr, scale)
@@ -494,6 +503,43 @@ def test_attention_bwd_fused_five_products(B, L1, n_dec, keep, drop_p):
             assert got[..., 768:][~kvalid].abs().max().item() == 0
         # dK / dV are deterministic and computed by the same arithmetic as the two-kernel form up to the K pre-scaling path
         assert (got[..., 768:].double() - two[..., 768:].double()).abs().max().item() < 2e-2 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_attention_bwd_fused_handoff_under_uneven_load(drop_p):
+    """The dQ hand-off protocol (csrc/attn_bwd_fused_bf16.hip, FbWork; Guideline 16 R1) where it is stressed: 16 x 12 = 192
+    (sample, head) chains of 1 .. 14 key blocks each (visible keys from 3 % to 100 % of 5 300 rows) - about 1 500 workgroups for 256
+    CUs, so later tickets start while earlier chains are mid-sweep, consumers re-read lines their CU has seen before (the running
+    sums are rewritten in place by every block) and the chains differ in length by an order of magnitude.  Asserted: no spin
+    timed out; two launches give bit-identical gradients; dQ equals the atomic form's to fp32 summation-order noise (one bf16
+    rounding step at most, and only rarely); dK / dV are identical in both forms."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    B, L1, n_dec = 16, 5300, 12
+    L = L1 + n_dec
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.8).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    keep = torch.linspace(0.03, 1.0, B).view(B, 1)
+    valid = (torch.rand(B, L1, generator=g) < keep).to(DEV)
+    valid[:, 0] = True
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
+    kw = dict(drop_p=drop_p, drop_seed=515) if drop_p else {}
+    out, lse = ops.attn_fwd(x, keys, **kw)
+    a = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw)
+    assert ops.fused_handoff_status() == 0
+    for _ in range(3):                                  # warm caches, other tickets orders
+        b = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw)
+        assert ops.fused_handoff_status() == 0
+        assert torch.equal(a, b)
+    c = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=0, **kw)
+    assert torch.equal(a[..., 768:], c[..., 768:])
+    dq_a, dq_c = a[..., :768].float(), c[..., :768].float()
+    diff = (dq_a - dq_c).abs()
+    assert (diff <= 2.0 ** -7 * dq_c.abs().clamp_min(1e-3)).all()                  # at most one bf16 step
+    assert (diff > 0).float().mean().item() < 0.02
+    two = ops.attn_bwd(x, out, dout, lse, keys, fused=False, **kw)
+    assert (a.float() - two.float()).abs().max().item() < 3e-2 * max(1.0, two.float().abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

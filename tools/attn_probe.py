@@ -38,22 +38,24 @@ def main():
     ev[1].record()
     torch.cuda.synchronize()
     # backward: the two-kernel (7-product) and the fused (5-product, no dropout) forms, interleaved rounds in ONE process
-    forms = [("two-kernel", False), ("fused", True)]
+    # (fused: dQ across key blocks by the ordered hand-off, dq_mode 1, and by fp32 atomics + cast, dq_mode 0)
+    forms = [("two-kernel", dict(fused=False)), ("fused/handoff", dict(fused=True, dq_mode=1)), ("fused/atomic", dict(fused=True, dq_mode=0))]
     tb_all = {n: [] for n, _ in forms}
     for n, f in forms:
-        ops.attn_bwd(qkv, out, dout, lse, keys, fused=f, **kw)
+        ops.attn_bwd(qkv, out, dout, lse, keys, **f, **kw)
     torch.cuda.synchronize()
     for _ in range(iters):
         for n, f in forms:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            ops.attn_bwd(qkv, out, dout, lse, keys, fused=f, **kw)
+            ops.attn_bwd(qkv, out, dout, lse, keys, **f, **kw)
             b.record()
             torch.cuda.synchronize()
             tb_all[n].append(a.elapsed_time(b))
     ev[2].record()
     ev[3].record()
     torch.cuda.synchronize()
+    print("   hand-off status word: %d" % ops.fused_handoff_status())
     tf = ev[0].elapsed_time(ev[1]) / iters
     tb = sorted(tb_all["two-kernel"])[len(tb_all["two-kernel"]) // 2]
     dense = 4.0 * B * 12 * L * L * 64
@@ -63,7 +65,7 @@ def main():
           % (B, L, nk, tf, dense / tf / 1e9, execd / tf / 1e9, tb, 2.5 * dense / tb / 1e9, 2.5 * execd / tb / 1e9))
     for n, ts in tb_all.items():
         ts = sorted(ts)
-        print("   bwd %-10s median %.3f ms  min %.3f ms  -> %.1f TF/s on the algorithmic 5 products (executed keys)" % (n, ts[len(ts) // 2], ts[0], 2.5 * execd / ts[len(ts) // 2] / 1e9))
+        print("   bwd %-13s median %.3f ms  min %.3f ms  -> %.1f TF/s on the algorithmic 5 products (executed keys)" % (n, ts[len(ts) // 2], ts[0], 2.5 * execd / ts[len(ts) // 2] / 1e9))
 
 
 if __name__ == "__main__":

@@ -511,8 +511,8 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
                          float* delta, void* dq, void* dk, void* dv, const int32_t* kv_idx, const int32_t* kv_cnt, int B,
                          int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys, int64_t q_row_stride, int64_t q_batch_stride,
                          int64_t kv_row_stride, int64_t kv_batch_stride, int64_t o_row_stride, int64_t o_batch_stride,
-                         float scale, int dtype, float drop_p, uint64_t drop_seed, const uint8_t* row_valid, float* dq32,
-                         t2s_stream_t stream) {
+                         float scale, int dtype, float drop_p, uint64_t drop_seed, const uint8_t* row_valid, void* fused_ws,
+                         int64_t fused_ws_bytes, int fused_handoff, t2s_stream_t stream) {
   T2S_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
   T2S_CHECK_ARG(dtype == T2S_F32 || dtype == T2S_BF16, "attn_bwd: bad dtype %d", dtype);
   T2S_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && idx_cap > 0 && n_dec >= 0 && n_dec <= idx_cap, "attn_bwd: bad shape");
@@ -539,10 +539,11 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   const int64_t rows = (int64_t)B * Lq;
   dim3 gd((unsigned)((rows + 3) / 4)), blk(256);
   dim3 gkv((max_keys + 127) / 128, H, B), gq((Lq + 127) / 128, H, B);
-  if (dq32) {      // fused 5-product form (attn_bwd_fused_bf16.hip): bf16
+  if (fused_ws) {      // fused 5-product form (attn_bwd_fused_bf16.hip): bf16
     T2S_CHECK_ARG(dtype == T2S_BF16, "attn_bwd_fused: bf16 only");
     T2S_CHECK_ARG(Lq * (int64_t)H * 64 < ((int64_t)1 << 31), "attn_bwd_fused: a sample's fp32 dQ rows must span < 2^31 elements");
-    if (int e = launch_attn_bwd_fused_bf16(p, max_keys, dq32, st)) return e;
+    T2S_CHECK_ARG(((int64_t)(Lq + 63) / 64) * 16384 < ((int64_t)1 << 32), "attn_bwd_fused: a (sample, head)'s running dQ sums must span < 4 GB");
+    if (int e = launch_attn_bwd_fused_bf16(p, max_keys, fused_ws, (size_t)fused_ws_bytes, fused_handoff, st)) return e;
   } else if (dtype == T2S_BF16) {
     hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, gd, blk, 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, H, Lq, o_row_stride, o_batch_stride);
     launch_attn_dkdv_bf16(p, max_keys, st);
@@ -575,7 +576,7 @@ extern "C" int t2s_attn_bwd(const void* q, const void* k, const void* v, const v
                             float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream) {
   return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
                        q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed,
-                       nullptr, nullptr, stream);
+                       nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
@@ -590,20 +591,27 @@ extern "C" int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, co
                 "attn_bwd_fill: self-attention layout expected (query rows = prefix rows, then decoder rows; this call's n_dec decoder rows at dec_q0)");
   return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
                        q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed,
-                       row_valid, nullptr, stream);
+                       row_valid, nullptr, 0, 0, stream);
+}
+
+extern "C" int64_t t2s_attn_bwd_fused_workspace_bytes(int B, int H, int Lq) {
+  if (B <= 0 || H <= 0 || Lq <= 0) return 0;
+  return (int64_t)attn_bwd_fused_workspace_bytes(B, H, Lq);
 }
 
 extern "C" int t2s_attn_bwd_fused(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
-                                  float* delta, void* dq, void* dk, void* dv, float* dq32, const int32_t* kv_idx, const int32_t* kv_cnt,
+                                  float* delta, void* dq, void* dk, void* dv, void* workspace, int64_t workspace_bytes, int dq_mode,
+                                  const int32_t* kv_idx, const int32_t* kv_cnt,
                                   const uint8_t* row_valid, int B, int H, int Lq, int idx_cap, int n_dec, int dec_q0, int max_keys,
                                   int64_t q_row_stride, int64_t q_batch_stride, int64_t kv_row_stride, int64_t kv_batch_stride,
                                   int64_t o_row_stride, int64_t o_batch_stride, float scale, int dtype, float drop_p, uint64_t drop_seed,
                                   t2s_stream_t stream) {
-  T2S_CHECK_ARG(dq32, "attn_bwd_fused: the fp32 dQ accumulation buffer is required");
+  T2S_CHECK_ARG(workspace, "attn_bwd_fused: the workspace is required");
+  T2S_CHECK_ARG(dq_mode == 0 || dq_mode == 1, "attn_bwd_fused: dq_mode %d (0 = fp32 atomics, 1 = ordered hand-off)", dq_mode);
   T2S_CHECK_ARG(dtype == T2S_BF16, "attn_bwd_fused: bf16 only");
   T2S_CHECK_ARG(!row_valid || (kv_idx && Lq >= idx_cap && (n_dec == 0 || (dec_q0 >= idx_cap - n_dec && dec_q0 + n_dec <= Lq))),
                 "attn_bwd_fused: row_valid needs the key list and the self-attention layout");
   return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, kv_idx, kv_cnt, B, H, Lq, idx_cap, n_dec, dec_q0, max_keys, q_row_stride,
                        q_batch_stride, kv_row_stride, kv_batch_stride, o_row_stride, o_batch_stride, scale, dtype, drop_p, drop_seed,
-                       row_valid, dq32, stream);
+                       row_valid, workspace, workspace_bytes, dq_mode, stream);
 }

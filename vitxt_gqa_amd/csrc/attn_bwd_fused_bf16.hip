@@ -34,6 +34,37 @@ constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + (FB_QROWS / 2) * 4;   
 constexpr int FB_KIMG = FB_KEYS * 128;
 constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
 
+// ---- dQ across the key blocks of a (sample, head): two forms, chosen per launch (FbWork::handoff).
+// ATOMIC (rounds 2-3): every key block adds its [64 x 64] tile to an fp32 [B Lq, H 64] buffer with float atomics (memory-side,
+//   ~1.3 TB/s chip-wide, arrival-order dependent in the last bits), a cast kernel rounds the sums to bf16.
+// ORDERED HAND-OFF (round 4; cdna_hip_programming.md Appendix B "Attention backward", Guideline 16 recipe R1): the key blocks of a
+//   pair form a chain in block order.  Block k reads the running sum of blocks 0..k-1 of a query tile, adds its own tile in
+//   registers and stores the new running sum; the LAST block of the pair rounds to bf16 and writes dQ itself.  Plain 16-byte
+//   write-through (sc1) stores and sc1 loads instead of atomics, a fixed summation order - dQ is bit-reproducible - no zero fill
+//   and no cast pass.  The running sums live in the ACCUMULATOR-NATIVE layout (per tile: wave quadrant, register group, lane: every
+//   access a lane-linear 1 KB piece).  Protocol per query tile t (flags[pair][t] = number of blocks whose sum is published):
+//     producer  the four waves store their quadrants (sc1); one tile later, behind every wave's s_waitcnt vmcnt(0) and the
+//               workgroup barrier that phase B needs anyway, ONE lane stores flags[t] = k + 1 (sc1 store)
+//     consumer  every wave loads flags[t] (sc1) at the top of tile t, checks it at the end of phase A (spins, bounded, only if
+//               the predecessor has not got there yet), then - behind the barrier - loads the sum with sc1 loads
+//   A block only ever waits for a block with a SMALLER ticket: workgroups draw their (pair, block) from a per-XCD-group ticket
+//   counter (atomic add) in the order they start running, so the block waited for has started, whatever order the hardware
+//   dispatches workgroup ids in: no deadlock by construction; the spin is bounded all the same and a timeout is reported in
+//   status[0] (the sweep then finishes without waiting: wrong dQ, never a hang).
+struct FbWork {
+  float* part;            // hand-off: running sums [B H][nqt][4 quadrants][4 register groups][64 lanes] x 16 B; atomic form: dq32 [B Lq, H 64]
+  unsigned* flags;        // [B H][nqt]
+  unsigned* tickets;      // [3 launches][8 XCD groups]
+  unsigned* status;       // [4]: bit 0 of word 0 = a bounded spin timed out
+  int handoff;
+};
+constexpr int FB_CTRL_WORDS = 64;                       // tickets (24) + status (4), padded: the block the launch zeroes, with the flags behind it
+constexpr unsigned FB_SPIN_LIMIT = 1u << 18;            // ~1-2 us per poll: a few tenths of a second (a legitimate wait is < 1 ms)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fb_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
 // ---- MFMAs with the register file of their accumulator chosen by hand.  With 512 registers per lane the compiler selects the
 // AGPR form for every MFMA and then copies each S / dP tile between the two files around the softmax (816 v_accvgpr_* in
 // the first build of this kernel: more VALU time than the MFMAs themselves).  Here the long-lived dK^T / dV^T accumulators are
@@ -162,16 +193,34 @@ __device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dp
 // complement (the same pipeline with the validity / decoder rule applied to P); MODE 2:
 // the tail launch (plain sweep, loops over the key blocks beyond the static bound).  Separate kernels, so that each is
 // register-allocated for one sweep.
-template <bool USE_IDX, int MODE, bool DROP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams p, float* __restrict__ dq32) {
+template <bool USE_IDX, int MODE, bool DROP, bool HO>
+__global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams p, FbWork w) {
   constexpr bool TAIL = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const stage = smem;                        // 2 x (Q tile | dO tile | -lse*log2e | -delta)
   char* const kimg = smem + 2 * FB_STAGE;          // [384 keys][64 d] bf16, tile_off swizzle
   char* const dsimg = kimg + FB_KIMG;              // [384 keys][64 q] bf16, same layout
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  float* __restrict__ const dq32 = w.part;         // (atomic form)
   int kblk, h, b;
-  if (!attn_xcd_tile(TAIL ? 1 : p.kblocks, p.H, p.B, kblk, h, b)) return;         // workgroup-uniform (attn_common.h)
+  if constexpr (HO && !TAIL) {
+    // ticket: this workgroup is the slot-th one of its XCD group to START (not the slot-th by id), see FbWork
+    unsigned* sl = reinterpret_cast<unsigned*>(smem);
+    if (tid == 0) sl[0] = atomicAdd(w.tickets + MODE * T2S_XCDS + (blockIdx.x % T2S_XCDS), 1u);
+    __syncthreads();
+    const int slot = __builtin_amdgcn_readfirstlane((int)sl[0]);
+    __syncthreads();                               // (the stage buffer is written below)
+    const int g = slot / p.kblocks;
+    const int bh = g * T2S_XCDS + (int)(blockIdx.x % T2S_XCDS);
+    if (bh >= p.H * p.B) return;
+    // (the division runs on the vector ALU: pin the results to scalar registers, or every address and the buffer descriptors
+    // derived from them live in VGPRs and each buffer access becomes a waterfall loop - cdna_hip_programming.md T20)
+    kblk = __builtin_amdgcn_readfirstlane(slot - g * p.kblocks);
+    b = __builtin_amdgcn_readfirstlane(bh / p.H);
+    h = __builtin_amdgcn_readfirstlane(bh - b * p.H);
+  } else {
+    if (!attn_xcd_tile(TAIL ? 1 : p.kblocks, p.H, p.B, kblk, h, b)) return;       // workgroup-uniform (attn_common.h)
+  }
   const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
   const int nk = n_prefix + p.n_dec;
   int kbw = TAIL ? p.kblocks : kblk;
@@ -186,6 +235,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   float* __restrict__ DQ = dq32 + (int64_t)b * p.Lq * (p.H * 64) + h * 64;
   const float c = p.scale * LOG2E;
   const int nqt = (p.Lq + FB_QROWS - 1) / FB_QROWS;
+  const int64_t pair = (int64_t)b * p.H + h;
+  unsigned* const flags_pair = HO ? w.flags + pair * nqt : nullptr;
+  const char* const part_pair = HO ? reinterpret_cast<const char*>(w.part) + pair * nqt * (int64_t)(FB_QROWS * 64 * 4) : nullptr;
   const int sr = tid >> 3, sc = tid & 7;
   // per-lane LDS byte offsets, computed once: row fragment of row lr of a 32-row block (chunk 2s + lh), transposed fragment
   // (rows 4lh + qq and + 8, chunk 4db + 2g1 + (pp >> 1)), dS^T store (row lr, chunk cc); block / tile / image offsets are
@@ -211,9 +263,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     const int kp0 = kbw * FB_KEYS;
     const int nkeys_wg = (nk - kp0) < FB_KEYS ? (nk - kp0) : FB_KEYS;              // valid keys of this workgroup
     const int nks = (nkeys_wg + 15) >> 4;                                          // 16-key steps of the dQ product
-    const bool edge_wg = (kp0 + FB_KEYS > n_prefix);                               // decoder keys or the end of the list inside
+    // decoder keys or the end of the list inside; hand-off: the LAST block of a pair (it writes bf16 dQ) is always an edge block,
+    // also when the list ends exactly on its boundary, so that the straight-line MODE 0 sweep has one output form only
+    const bool edge_wg = (kp0 + FB_KEYS > n_prefix) || (HO && kp0 + FB_KEYS >= nk);
     if (MODE == 0 && edge_wg) return;                                              // (nkeys_wg == FB_KEYS follows from !edge_wg)
     if (MODE == 1 && !edge_wg) return;
+    // hand-off chain position (workgroup-uniform): block 0 has no predecessor, the block that holds the end of the list finishes dQ
+    const bool ho_last = HO && (MODE != 0) && (kp0 + FB_KEYS >= nk);
+    int ho_wait = (HO && !TAIL) ? kbw : 0;                                         // flags[t] must reach this before tile t's sum is read
+    // running sums of this pair through a buffer descriptor: block 0 gets ZERO records - its loads return 0.0 without touching
+    // memory, so the sweep needs no branch around them
+    const __amdgpu_buffer_rsrc_t rs_ld = fb_rsrc(part_pair, (HO && kbw > 0) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
+    const __amdgpu_buffer_rsrc_t rs_st = fb_rsrc(part_pair, HO ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
     // ---- K image of the workgroup's keys, pre-scaled by scale*log2e (one bf16 rounding per element, as the dK/dV kernel's
     // register fragments); rows past the list repeat its last key (their P is forced to 0 below)
 #pragma unroll
@@ -367,6 +428,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #endif
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
+      // hand-off: how far the predecessor has published this tile's running sum - asked now, looked at at the end of phase A
+      unsigned fv = 0;
+      if constexpr (HO && !TAIL) fv = __hip_atomic_load(flags_pair + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // global loads of the next tile in sequence (past the end: clamped rows, harmless).  Pipelined form: issued a third of the way
       // into phase A instead of here - at the top of the tile the memory pipeline is still draining the 16 atomics per lane of the
       // previous tile, and the loads are not needed before the end of the phase
@@ -585,15 +649,46 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #pragma unroll
         for (int u = 0; u < 4; ++u) { bfA[u] = fb_tr(kimg + (16 * u) * 128, vad); bfB[u] = fb_tr(kimg + (16 * (4 + u)) * 128, vad); }
       }
+      if constexpr (HO) {
+        // every wave: its running-sum stores of the PREVIOUS tile have landed (the flag below is stored behind this wait and the
+        // barrier: Guideline 16 R1); the stage loads of this tile are younger and are needed right below anyway
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!TAIL) {
+          int fvs = __builtin_amdgcn_readfirstlane((int)fv);
+          if (fvs < ho_wait) {                               // the predecessor has not published this tile yet: bounded spin
+            unsigned spins = 0;
+            do {
+              __builtin_amdgcn_s_sleep(16);
+              fvs = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flags_pair + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+              if (++spins > FB_SPIN_LIMIT) {                 // never in a correct run: report, stop waiting (wrong dQ, no hang)
+                if (lane == 0) atomicOr(w.status, 1u);
+                ho_wait = 0;
+              }
+            } while (fvs < ho_wait);
+          }
+        }
+      }
       FB_STAGE_WRITE(buf ^ 1);
       FB_TICK(1);                                            // stage write
       __syncthreads();                                       // the dS^T image of this query tile is complete
       FB_TICK(2);                                            // barrier 1
+      if constexpr (HO && !TAIL) {
+        // publish the previous tile's running sum: every wave drained its stores before the barrier above
+        if ((MODE == 0 || !ho_last) && tid == 0 && qt > 0)
+          __hip_atomic_store(flags_pair + (qt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       // ================= phase B: dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
       {
         f32x16 dqacc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqacc[i] = 0.f;
+        // hand-off: the running sum of the blocks before this one (zeros for block 0: zero-record descriptor), in flight under the MFMAs
+        u32x4 pin[4];
+        const unsigned ho_off = (unsigned)((qt * 4 + wave_u) * 4096 + lane * 16);
+        if constexpr (HO) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) pin[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ho_off + g * 1024, 0, 16 /* sc1 */);
+        }
         // steps of 16 keys in groups of 4; full key blocks: 24 steps with the transposed reads of group g+1 in flight under the
         // MFMAs of group g, otherwise the steps that hold valid keys (rows past them may never have been written)
 #ifndef FB_ABL
@@ -681,6 +776,37 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // dS (K c) = c dS K;  dQ = scale dS K = acc * ln 2.  Register r = query row acc_row(r, lh), 32 consecutive dims per
         // half wave: two 128-byte segments per wave instruction
         const int q0 = qt * FB_QROWS + dq_qb * 32;
+        if constexpr (HO) {
+          f32x16 tot;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            // (bit_cast of the WHOLE vector, then the element: bit_cast(float, pin[g][j]) is narrowed by this clang to a one-dword load
+            // whose value stands in for all four elements - seen in the ISA)
+            const f32x4 pf = __builtin_bit_cast(f32x4, pin[r >> 2]);
+            tot[r] = __builtin_fmaf(dqacc[r], 0.6931471805599453f, pf[r & 3]);
+          }
+          if (MODE != 0 && ho_last) {
+            // the last block of the pair: dQ rows in bf16.  Lanes 2i / 2i+1 hold columns 2i / 2i+1 of the same rows: the even lane
+            // takes the odd lane's value of register 2m, the odd lane the even lane's value of register 2m+1 (DPP quad_perm 1,0,3,2),
+            // each then stores ONE 4-byte pair of its own row
+            bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.q_bs + h * 64 + dq_db * 32 + (lr & ~1);
+            const bool odd = lr & 1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+              const float a = tot[2 * m], bb = tot[2 * m + 1];
+              const float send = odd ? a : bb;
+              const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+              const int row = q0 + acc_row(2 * m, lh) + (odd ? 1 : 0);
+              if (row < p.Lq) *reinterpret_cast<uint32_t*>(dqp + (int64_t)row * p.q_rs) = odd ? fb_pack2(recv, bb) : fb_pack2(a, recv);
+            }
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 t4 = {tot[4 * g], tot[4 * g + 1], tot[4 * g + 2], tot[4 * g + 3]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 16 /* sc1: write-through */);
+            }
+          }
+        } else {
         const int rstep = p.H * 64;
         float* rowp = DQ + (int64_t)q0 * rstep + dq_db * 32;          // wave-uniform (dq_qb / dq_db come from readfirstlane)
         const int loff = lr + 4 * lh * rstep;                          // this lane's element offset
@@ -700,10 +826,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             if (q0 + acc_row(r, lh) < p.Lq) FB_DQ_OUT(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
         }
 #undef FB_DQ_OUT
+        }
       }
       FB_TICK(4);                                            // atomics
       if constexpr (!FULL) __syncthreads();                  // every wave is done reading the dS^T image (pipelined form: see phase A)
       FB_TICK(5);                                            // barrier 2
+    }
+    if constexpr (HO) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last tile's stores (the tail launch reads them back in its next key block)
+      if constexpr (!TAIL) {
+        if (MODE == 0 || !ho_last) {                         // workgroup-uniform
+          __syncthreads();
+          if (tid == 0) __hip_atomic_store(flags_pair + (nqt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
 #ifdef FB_STAMP
 #ifndef FB_STAMP_MODE
@@ -756,7 +892,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 // the same pass over the rows: zero the row of the fp32 dQ accumulation buffer, and write the exact-zero dK / dV slices of
 // rows that no key-list entry points at (prefix rows with row_valid == 0; rows behind the prefix other than this call's decoder rows).
 __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
-                                                              float* __restrict__ dq32, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
+                                                              float* __restrict__ dq32 /* NULL: no accumulation buffer to zero (hand-off form) */, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                                                               const uint8_t* __restrict__ row_valid, int valid_len, int dec_q0, int n_dec, int B, int H, int Lq,
                                                               int64_t o_rs, int64_t o_bs, int64_t kv_rs, int64_t kv_bs) {
   const int lane = threadIdx.x & 63;
@@ -766,7 +902,7 @@ __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __re
   const bf16_t* op = o + (int64_t)b * o_bs + (int64_t)q * o_rs;
   const bf16_t* dp = dout + (int64_t)b * o_bs + (int64_t)q * o_rs;
   const int nchunk = H * 16;              // 4-element chunks per row
-  float* zrow = dq32 + row * (int64_t)(H * 64);
+  float* zrow = dq32 ? dq32 + row * (int64_t)(H * 64) : nullptr;
   const bool fill = row_valid && (q < valid_len ? !row_valid[(int64_t)b * valid_len + q] : (q < dec_q0 || q >= dec_q0 + n_dec));
   for (int c0 = 0; c0 < nchunk; c0 += 64) {
     const int ci = c0 + lane;
@@ -774,7 +910,7 @@ __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __re
     if (ci < nchunk) {
       const f32x4 a = Vec4<bf16_t>::load(op + ci * 4), d = Vec4<bf16_t>::load(dp + ci * 4);
       s = a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
-      *reinterpret_cast<f32x4*>(zrow + ci * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (zrow) *reinterpret_cast<f32x4*>(zrow + ci * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
       if (fill) {
         const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
         *reinterpret_cast<bf16x4*>(dk + (int64_t)b * kv_bs + (int64_t)q * kv_rs + ci * 4) = z;
@@ -806,30 +942,61 @@ __global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restri
 
 }  // namespace
 
-// Fused backward (bf16): delta + housekeeping, the 5-product kernel (+ its tail launch, see
-// attn_dkdv_bf16.hip), the fp32 -> bf16 cast of dQ.
-int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, float* dq32, hipStream_t st) {
+// Workspace of the fused backward, in bytes, for (B, H, Lq): control words + flags + the fp32 dQ sums (either form)
+size_t attn_bwd_fused_workspace_bytes(int B, int H, int Lq) {
+  const size_t nqt = ((size_t)Lq + FB_QROWS - 1) / FB_QROWS;
+  const size_t ctrl = ((size_t)FB_CTRL_WORDS * 4 + (size_t)B * H * nqt * 4 + 255) / 256 * 256;
+  const size_t sums = (size_t)B * H * nqt * (FB_QROWS * 64 * 4);        // >= B * Lq * H * 64 * 4, the atomic form's buffer
+  return ctrl + sums + 16384;                                            // + room for the diagnostic build's stamps
+}
+
+// Fused backward (bf16): delta + housekeeping, the 5-product kernel (+ its tail launch, see attn_dkdv_bf16.hip); dQ across key
+// blocks by the ordered hand-off (handoff != 0: no zero fill, no cast pass, bit-reproducible) or by fp32 atomics + the cast.
+int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* workspace, size_t workspace_bytes, int handoff, hipStream_t st) {
   AttnParams p = p_in;
+  if (workspace_bytes < attn_bwd_fused_workspace_bytes(p.B, p.H, p.Lq)) {
+    t2s_set_error("attn_bwd_fused: workspace of %zu bytes, %zu needed (t2s_attn_bwd_fused_workspace_bytes)", workspace_bytes,
+                  attn_bwd_fused_workspace_bytes(p.B, p.H, p.Lq));
+    return 2;
+  }
+  const size_t nqt = ((size_t)p.Lq + FB_QROWS - 1) / FB_QROWS;
+  const size_t ctrl = ((size_t)FB_CTRL_WORDS * 4 + (size_t)p.B * p.H * nqt * 4 + 255) / 256 * 256;
+  FbWork w;
+  w.tickets = reinterpret_cast<unsigned*>(workspace);
+  w.status = w.tickets + 3 * T2S_XCDS;
+  w.flags = w.tickets + FB_CTRL_WORDS;
+  w.part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ctrl);
+  w.handoff = handoff;
+  float* const dq32 = w.part;
   // > 64 KB of LDS per workgroup needs the opt-in; set on every call (idempotent, per device, no state of ours is kept)
-  const void* kernels[] = {reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 0, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 1, false>),
-                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 2, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 0, false>),
-                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 1, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 0, true>),
-                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 1, true>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<true, 2, true>),
-                           reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 0, true>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<false, 1, true>)};
+#define FB_K(I_, M_, D_) reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, true>)
+  const void* kernels[] = {FB_K(true, 0, false), FB_K(true, 1, false), FB_K(true, 2, false), FB_K(false, 0, false), FB_K(false, 1, false),
+                           FB_K(true, 0, true),  FB_K(true, 1, true),  FB_K(true, 2, true),  FB_K(false, 0, true),  FB_K(false, 1, true)};
+#undef FB_K
   for (const void* k : kernels)
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
       t2s_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS per workgroup", FB_SMEM);
       return 3;
     }
+  if (handoff) {
+    // tickets, status and flags: zeroed on every call (a replayed or repeated launch starts from a clean protocol state)
+    if (hipMemsetAsync(workspace, 0, ctrl, st) != hipSuccess) {
+      t2s_set_error("attn_bwd_fused: cannot clear the hand-off control block");
+      return 3;
+    }
+  }
   const int64_t rows = (int64_t)p.B * p.Lq;
   hipLaunchKernelGGL(attn_delta_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)p.o, (const bf16_t*)p.dout, p.delta,
-                     dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs, p.kv_rs, p.kv_bs);
+                     handoff ? nullptr : dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs,
+                     p.kv_rs, p.kv_bs);
   T2S_CHECK_LAUNCH("attn_bwd_fused (delta prep)");
   p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256), tail(attn_xcd_grid(1, p.H, p.B));
+#define FB_LAUNCH2(IDX_, MODE_, DROP_, grid_)                                                                            \
+  if (handoff) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, true>), grid_, block, FB_SMEM, st, p, w);   \
+  else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, false>), grid_, block, FB_SMEM, st, p, w);
 #define FB_LAUNCH(IDX_, MODE_, grid_)                                                                                  \
-  if (p.drop_thresh) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, true>), grid_, block, FB_SMEM, st, p, dq32); \
-  else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, false>), grid_, block, FB_SMEM, st, p, dq32);                \
+  if (p.drop_thresh) { FB_LAUNCH2(IDX_, MODE_, true, grid_) } else { FB_LAUNCH2(IDX_, MODE_, false, grid_) }            \
   T2S_CHECK_LAUNCH("attn_bwd_fused (five-product kernel)");
   if (p.kv_idx) {
     FB_LAUNCH(true, 0, grid);
@@ -840,10 +1007,13 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, float* dq32
     FB_LAUNCH(false, 1, grid);
   }
 #undef FB_LAUNCH
-  const int width = p.H * 64;
-  const int64_t total8 = rows * (width / 8);
-  hipLaunchKernelGGL(attn_dq_cast_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, dq32, (bf16_t*)p.dq, (int64_t)p.Lq, width,
-                     p.q_rs, p.q_bs, total8);
-  T2S_CHECK_LAUNCH("attn_bwd_fused (dQ cast)");
+#undef FB_LAUNCH2
+  if (!handoff) {
+    const int width = p.H * 64;
+    const int64_t total8 = rows * (width / 8);
+    hipLaunchKernelGGL(attn_dq_cast_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, dq32, (bf16_t*)p.dq, (int64_t)p.Lq, width,
+                       p.q_rs, p.q_bs, total8);
+    T2S_CHECK_LAUNCH("attn_bwd_fused (dQ cast)");
+  }
   return 0;
 }

@@ -201,7 +201,8 @@ int launch_attn_fwd_pw_bf16(const AttnParams& p, hipStream_t st);
 // bf16 dK/dV kernel lives in attn_dkdv_bf16.hip
 void launch_attn_dkdv_bf16(const AttnParams& p, int max_keys, hipStream_t st);
 // fused 5-product bf16 backward (delta + housekeeping, main kernel, dQ cast) lives in attn_bwd_fused_bf16.hip
-int launch_attn_bwd_fused_bf16(const AttnParams& p, int max_keys, float* dq32, hipStream_t st);
+int launch_attn_bwd_fused_bf16(const AttnParams& p, int max_keys, void* workspace, size_t workspace_bytes, int handoff, hipStream_t st);
+size_t attn_bwd_fused_workspace_bytes(int B, int H, int Lq);
 
 #define LOG2E 1.4426950408889634f
 

@@ -119,15 +119,28 @@ def attn_fwd(qkv, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, kv=None):
 
 
 # True: bf16 launches (with or without attention dropout) that may see >= ATTN_BWD_FUSED_MIN_KEYS keys use the fused 5-product kernel
-# (t2s_attn_bwd_fused: S and dP computed once, dQ summed across key blocks with fp32 atomics - dQ differs in its last fp32 bits from
-# run to run); False (T2S_ATTN_BWD_FUSED=0): always the two-kernel 7-product form, which is bit-reproducible.
+# (t2s_attn_bwd_fused: S and dP computed once, dQ summed across the key blocks of a (sample, head)); False (T2S_ATTN_BWD_FUSED=0):
+# always the two-kernel 7-product form.  Both are bit-reproducible when the dQ sum runs as the ordered hand-off (ATTN_BWD_DQ_MODE 1,
+# the default: key blocks add their tiles in block order, plain stores); T2S_ATTN_BWD_DQ=atomic restores the fp32-atomic sum of
+# rounds 2-3 (dQ then differs in its last fp32 bits from run to run).
 ATTN_BWD_FUSED = os.environ.get("T2S_ATTN_BWD_FUSED", "1") != "0"
 ATTN_BWD_FUSED_MIN_KEYS = 2048
+ATTN_BWD_DQ_MODE = 0 if os.environ.get("T2S_ATTN_BWD_DQ", "handoff") == "atomic" else 1
 _KEEP_DQ32 = os.environ.get("T2S_KEEP_DQ32", "0") == "1"     # tools/fused_stamps.py: keep the workspace, whose tail holds the diagnostic
 _LAST_DQ32 = None                                             # build's cycle stamps (otherwise it is freed with the call: 2 GB at B=64)
+_LAST_FUSED_WS = None                                         # the most recent workspace (its status word: fused_handoff_status())
+FUSED_CTRL_STATUS_WORD = 24                                   # include/t2s_hip.h: uint32 word of the workspace, bit 0 = a hand-off spin timed out
 
 
-def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, fused=None, kv=None):
+def fused_handoff_status():
+    """Status word of the most recent fused-backward call (synchronises): 0 = clean, bit 0 = a bounded spin of the dQ hand-off timed
+    out (dQ of that call is wrong).  Tests and bench.py read it; a timeout cannot happen unless a workgroup died."""
+    if _LAST_FUSED_WS is None:
+        return 0
+    return int(_LAST_FUSED_WS.view(torch.int32)[FUSED_CTRL_STATUS_WORD].item())
+
+
+def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, fused=None, kv=None, dq_mode=None):
     """Returns dqkv [B, L, 2304] (rows of keys outside the key list get exact zeros in the K/V thirds); with ``kv`` (see
     attn_fwd) returns (dq [B, L, 768], dkv [B, capK, 1536]) - the two-kernel form, positions behind a sample's list zero."""
     global LAST_ATTN_BWD_PRODUCTS
@@ -171,14 +184,18 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     use_fused = fused and qkv.dtype == torch.bfloat16
     LAST_ATTN_BWD_PRODUCTS = 5 if use_fused else 7
     if use_fused:
-        # fp32 dQ accumulation workspace (zeroed in the call); 16 KB of slack behind it for the stamps of the diagnostic build
-        dq32 = torch.empty(B * L * HID + 4096, dtype=torch.float32, device=qkv.device)
+        # workspace: control words, hand-off flags and the fp32 dQ sums (either form); cleared as needed inside the call
+        global _LAST_FUSED_WS, _LAST_DQ32
+        nbytes = int(X.lib().t2s_attn_bwd_fused_workspace_bytes(B, HEADS, L))
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
+        mode = ATTN_BWD_DQ_MODE if dq_mode is None else int(dq_mode)
         if _KEEP_DQ32:
-            global _LAST_DQ32
-            _LAST_DQ32 = dq32
-        X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(dq32), *klist, X.ptr(keys.valid8) if fill_in_kernel else None, *dims, float(drop_p), int(drop_seed),
-                                           X.stream()),
+            _LAST_DQ32 = ws
+        X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(ws), nbytes, mode, *klist, X.ptr(keys.valid8) if fill_in_kernel else None, *dims,
+                                           float(drop_p), int(drop_seed), X.stream()),
                 "t2s_attn_bwd_fused")
+        # keep the 256-byte control block only (a copy enqueued behind the kernels), not the 2 GB workspace
+        _LAST_FUSED_WS = ws[:64].clone()
     elif fill_in_kernel:
         X.check(X.lib().t2s_attn_bwd_fill(*head, *klist, X.ptr(keys.valid8), *dims, float(drop_p), int(drop_seed), X.stream()), "t2s_attn_bwd_fill")
     else:
