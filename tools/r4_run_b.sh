@@ -10,6 +10,8 @@ tail -3 $OUT/pytest_attn.log
 timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 7 0.1 > $OUT/attn_probe_b32.txt 2>&1
 timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 7 0.0 >> $OUT/attn_probe_b32.txt 2>&1
 cat $OUT/attn_probe_b32.txt
+timeout -k 10 300 python3 tools/gemm_epilogue_probe.py > $OUT/gemm_epilogue_probe.txt 2>&1 || { tail -30 $OUT/gemm_epilogue_probe.txt; exit 1; }
+cat $OUT/gemm_epilogue_probe.txt
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q -s > $OUT/pytest.log 2>&1 || { tail -60 $OUT/pytest.log; exit 1; }
 tail -3 $OUT/pytest.log
 timeout -k 10 600 python3 bench.py --no-cpu-baseline > $OUT/bench_handoff.json 2> $OUT/bench.err

@@ -978,9 +978,10 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
       t2s_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS per workgroup", FB_SMEM);
       return 3;
     }
-  if (handoff) {
-    // tickets, status and flags: zeroed on every call (a replayed or repeated launch starts from a clean protocol state)
-    if (hipMemsetAsync(workspace, 0, ctrl, st) != hipSuccess) {
+  {
+    // tickets, status and flags: zeroed on every call (a replayed or repeated launch starts from a clean protocol state); the
+    // atomic form only needs a clean status word
+    if (hipMemsetAsync(workspace, 0, handoff ? ctrl : (size_t)FB_CTRL_WORDS * 4, st) != hipSuccess) {
       t2s_set_error("attn_bwd_fused: cannot clear the hand-off control block");
       return 3;
     }
