@@ -338,10 +338,12 @@ def test_metric_batch_b64_100x100_equals_its_samples_and_its_halves():
     batch = make_batch(B, F, P, V=V, seed=100 + block)
     noise = make_noise(B, F, P, seed=100 + block)
 
-    def sample_list(idx=None):
+    def sample_list(idx=None, masks=None):
         bt = batch if idx is None else {k: v[idx] for k, v in batch.items()}
         s = to_device(bt, DEV)
         s.grounding_noise = tuple((t if idx is None else t[idx]).to(DEV) for t in noise)
+        if masks is not None:          # the selection of the B = 64 run, injected (see (c))
+            s.grounding_masks = {k: v[idx] for k, v in masks.items()}
         return s
 
     s64 = sample_list()
@@ -366,6 +368,7 @@ def test_metric_batch_b64_100x100_equals_its_samples_and_its_halves():
 
     loss64, o64, g64 = run(s64)
     assert loss64 == loss64 and abs(loss64) < float("inf")
+    masks64 = {k: model._last_fwd[k].detach().clone() for k in ("pos_obj_mask", "neg_obj_mask", "pos_ocr_mask", "neg_ocr_mask")}
     named = dict(model.named_parameters())
     assert set(g64) == {n for n in named if not is_dead_param(n)}
     for n, g in g64.items():
@@ -373,16 +376,24 @@ def test_metric_batch_b64_100x100_equals_its_samples_and_its_halves():
         # (bench.py's synthetic batch teacher-forces vocabulary tokens only: the LayerNorm of PrevPredEmbeddings' OCR branch sees no row)
         assert g.abs().max().item() > 0 or "prev_pred_embeddings.ocr_layer_norm" in n, "gradient of %s is identically zero at B = 64" % n
     scale = {k: max(1.0, o64[k].abs().max().item()) for k in ("ref_scores", "pos_scores", "neg_scores")}
-    # ---- (c) the two halves: scores of all 64 samples, mean of the half gradients
+    # ---- (c) the two halves: scores of all 64 samples, mean of the half gradients.  The temporal / spatial selection is a top-k over
+    # bf16-operand scores: a sub-batch runs other library GEMM shapes, so a sample whose k-th and (k+1)-th candidates are a near-tie
+    # may select differently - counted and bounded below (own selection, no injection), while the per-sample FUNCTION is compared
+    # with the B = 64 run's selection injected (sample_list.grounding_masks), which makes every other op comparable row for row.
     gsum = None
+    flipped = 0
     for half in (torch.arange(0, 32), torch.arange(32, 64)):
-        lh, oh, gh = run(sample_list(half))
+        with torch.no_grad():
+            own = model(sample_list(half))["ground_frame"]
+        flipped += int((own != o64["ground_frame"][half]).any(-1).sum())
+        lh, oh, gh = run(sample_list(half, masks64))
         for k in scale:
             err = (oh[k] - o64[k][half]).abs().max().item()
             assert err < 1e-2 * scale[k], (k, err, scale[k])
         assert torch.equal(oh["ground_frame"], o64["ground_frame"][half])
         gsum = gh if gsum is None else {n: gsum[n] + gh[n] for n in gsum}
         del oh, gh
+    assert flipped <= 4, "%d of 64 samples select other frames in a B = 32 run than in the B = 64 run" % flipped
     tot = sum(g.double().norm().item() ** 2 for g in g64.values()) ** 0.5
     worst = 0.0
     for n, g in g64.items():
@@ -392,12 +403,12 @@ def test_metric_batch_b64_100x100_equals_its_samples_and_its_halves():
     del gsum
     # ---- (d) samples 0, 31, 63 alone (B = 1): another grid, other GEMM shapes, the same per-sample function
     for b in (0, 31, 63):
-        _, o1, _ = run(sample_list(torch.tensor([b])))
+        _, o1, _ = run(sample_list(torch.tensor([b]), masks64))
         for k in scale:
             err = (o1[k][0] - o64[k][b]).abs().max().item()
             assert err < 1e-2 * scale[k], (b, k, err, scale[k])
         assert torch.equal(o1["ground_frame"][0], o64["ground_frame"][b])
-    print("B=64 100x100: loss_step0 %.6f (bench %.6f), loss %.6f, total gradient norm %.4e, worst relative half-mean deviation %.2e, %.0f s"
-          % (loss_drop, line["loss_step0"], loss64, tot, worst, time.time() - t_start))
+    print("B=64 100x100: loss_step0 %.6f (bench %.6f), loss %.6f, total gradient norm %.4e, worst relative half-mean deviation %.2e, "
+          "%d of 64 samples select other frames at B = 32, %.0f s" % (loss_drop, line["loss_step0"], loss64, tot, worst, flipped, time.time() - t_start))
     del model, g64, o64
     torch.cuda.empty_cache()
