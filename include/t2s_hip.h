@@ -122,20 +122,6 @@ int t2s_attn_bwd_fused(const void* q, const void* k, const void* v, const void* 
                        int64_t o_row_stride, int64_t o_batch_stride,
                        float scale, int dtype, float drop_p, uint64_t drop_seed, t2s_stream_t stream);
 
-/* ---- own bf16 GEMM with fused epilogues: c[M, N] = act(a[M, K] w[N, K]^T + bias[N]), bf16 operands and
- * outputs, fp32 accumulation; act 0 = identity, 1 = the exact-erf GELU of BertIntermediate (the dense layers of the third-party
- * BERT block called from t2s.py:423-427,538-542,622-626; the library's own fused GELU epilogue is the tanh approximation).
- * With act 1 the pre-activation is rounded to bf16 first (and stored to u_out when given: the backward reads it), so the result
- * equals the two-pass form (library GEMM -> bf16 -> t2s_gelu_fwd) bit for bit up to the GEMM's own summation order.
- * K must be a multiple of 128, N of 4; lda / ldw / ldc are row strides in elements. */
-int t2s_gemm_bias_act(const void* a, const void* w, const void* bias, void* c, void* u_out, const void* act_table,
-                      int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldc, int act, t2s_stream_t stream);
-/* act_table (act 1): GELU of every bf16 value, indexed by its bit pattern - the epilogue's input is the bf16-rounded
- * pre-activation, so 65 536 table entries replace ~56 VALU instructions of erff per element.  t2s_gelu_tables fills
- * fwd_bf16 [65536] (bf16) and / or grad_f32 [65536] (fp32: GELU'(x), for the backward) with the arithmetic of t2s_gelu_fwd /
- * t2s_gelu_bwd evaluated at each value: results bit-equal to those kernels. */
-int t2s_gelu_tables(void* fwd_bf16, void* grad_f32, t2s_stream_t stream);
-
 /* ---- residual + LayerNorm (BertSelfOutput / BertOutput / BertLayerNorm; also
  * t2s.py:87-88,116-117,685-687): z = x + res (res may be NULL); y = (z-mean)/sqrt(var+eps)*g+b,
  * biased variance, eps inside the sqrt.  rows x 768.

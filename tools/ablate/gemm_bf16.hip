@@ -1,3 +1,7 @@
+// PROTOTYPE, measured and NOT shipped (profiles/r04_gemm_epilogue_probe.txt: 651 TFLOP/s against the library's 1 081-1 135 on the
+// FFN-in shape; with the GELU epilogue 6.3-9.0 ms against 4.57 ms for library GEMM + standalone GELU pass).  Built by
+// tools/ablate/build_gemm_probe.sh into tools/ablate/_build/libgemm_probe.so, driven by tools/gemm_epilogue_probe.py.
+//
 // Own bf16 GEMM for the linear layers of the BERT block (the third-party BertIntermediate / BertOutput / BertSelfOutput dense
 // layers called from pythia/models/t2s.py:423-427,538-542,622-626), with the epilogues the library cannot fuse:
 //     C[M, N] = act(A[M, K] W[N, K]^T + bias[N]),   act = identity | exact-erf GELU (the reference's BertIntermediate activation)
@@ -21,7 +25,7 @@
 //     under the epilogue of the current one.
 #include <type_traits>
 
-#include "common.h"
+#include "../../vitxt_gqa_amd/csrc/common.h"
 
 namespace {
 
@@ -250,6 +254,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bias_act_bf16_kernel(GemmParams p
 }  // namespace
 
 // C = act(A W^T + bias): act 0 = identity, 1 = exact-erf GELU (u_out optional: the pre-activation in bf16).
+extern "C" int t2s_gelu_tables(void* fwd_bf16, void* grad_f32, t2s_stream_t stream);
+extern "C" int t2s_gemm_bias_act(const void* a, const void* w, const void* bias, void* c, void* u_out, const void* act_table, int64_t M, int N, int K,
+                                 int64_t lda, int64_t ldw, int64_t ldc, int act, t2s_stream_t stream);
+
 // GELU (fwd_bf16 [65536] bf16) and its derivative (grad_f32 [65536] fp32) of every bf16 value, indexed by the value's bit pattern.
 extern "C" int t2s_gelu_tables(void* fwd_bf16, void* grad_f32, t2s_stream_t stream) {
   T2S_CHECK_ARG(fwd_bf16 || grad_f32, "gelu_tables: null pointers");

@@ -26,8 +26,6 @@ _SIGS = {
     "t2s_attn_bwd_fill": (c_int, [c_void_p] * 13 + [c_int] * 7 + [c_int64] * 6 + [c_float, c_int, c_float, c_uint64, c_void_p]),
     "t2s_attn_bwd_fused_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "t2s_attn_bwd_fused": (c_int, [c_void_p] * 11 + [c_int64, c_int] + [c_void_p] * 3 + [c_int] * 7 + [c_int64] * 6 + [c_float, c_int, c_float, c_uint64, c_void_p]),
-    "t2s_gemm_bias_act": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_void_p]),
-    "t2s_gelu_tables": (c_int, [c_void_p, c_void_p, c_void_p]),
     "t2s_add_layernorm_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_float, c_int, c_int, c_float, c_uint64, c_void_p]),
     "t2s_add_layernorm_fwd_nres": (c_int, [c_void_p] * 11 + [c_int64, c_float, c_int, c_int, c_float, c_uint64, c_void_p]),
     "t2s_layernorm_bwd_parts": (c_int, [c_int64]),

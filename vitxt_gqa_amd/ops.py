@@ -305,36 +305,6 @@ def dropout_mask(n, drop_p, drop_seed, device):
     return out
 
 
-_GELU_TABLES = {}
-
-
-def gelu_tables(device):
-    """(GELU [65536] bf16, GELU' [65536] fp32) of every bf16 value, indexed by bit pattern; built once per device."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    if key not in _GELU_TABLES:
-        f = torch.empty(65536, dtype=torch.bfloat16, device=device)
-        g = torch.empty(65536, dtype=torch.float32, device=device)
-        X.check(X.lib().t2s_gelu_tables(X.ptr(f), X.ptr(g), X.stream()), "t2s_gelu_tables")
-        _GELU_TABLES[key] = (f, g)
-    return _GELU_TABLES[key]
-
-
-def gemm_bias_act(x, w, bias=None, act=0, want_u=False):
-    """act(x [M, K] @ w [N, K]^T + bias) in bf16 with fp32 accumulation: the own MFMA GEMM with fused epilogue (include/t2s_hip.h:
-    t2s_gemm_bias_act).  act 1 = exact-erf GELU; ``want_u`` also returns the bf16 pre-activation.  -> c, or (c, u)."""
-    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.dtype == w.dtype == torch.bfloat16
-    assert x.stride(1) == 1 and w.stride(1) == 1 and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == w.shape[0]))
-    M, K = x.shape
-    N = w.shape[0]
-    c = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
-    u = torch.empty_like(c) if (want_u and act == 1) else None
-    tab = gelu_tables(x.device)[0] if act == 1 else None
-    X.check(X.lib().t2s_gemm_bias_act(X.ptr(x), X.ptr(w), X.ptr(bias), X.ptr(c), X.ptr(u), X.ptr(tab), M, N, K, x.stride(0), w.stride(0), N, int(act),
-                                      X.stream()),
-            "t2s_gemm_bias_act")
-    return (c, u) if u is not None else c
-
-
 def gelu_fwd(u):
     assert u.is_contiguous() and u.numel() % 4 == 0
     y = torch.empty_like(u)
