@@ -29,7 +29,12 @@ for N, K in ((3072, 768), (768, 3072), (2304, 768), (768, 768)):      # dy [B*L,
             continue
         fns["G = %3d" % G] = (lambda G=G: torch.bmm(dy.view(G, B * L // G, N).transpose(1, 2), x.view(G, B * L // G, K)).sum(0, dtype=torch.float32))
     fns["G =   1 (dy^T @ x)"] = lambda: (dy.t() @ x).float()
+    # round 4 (the Cijk_Ailk_Bjlk MT256x256x32 family IS this batched wgrad of the two FFN weights): the transposed product
+    # dW^T[in, out] = x_g^T dy_g - the same operands with the roles of the library's A / B swapped (another tile selection); the caller
+    # would take the [in, out] fp32 sum transposed (2.4 M elements: free)
+    for G in (64, 16):
+        fns["G = %3d, dW^T = x^T dy" % G] = (lambda G=G: torch.bmm(x.view(G, B * L // G, K).transpose(1, 2), dy.view(G, B * L // G, N)).sum(0, dtype=torch.float32))
     r = timeit(fns)
     print("dW[%d, %d], rows = %d" % (N, K, B * L))
     for k, v in r.items():
-        print("   %-22s %7.3f ms %7.1f TFLOP/s" % (k, v, fl / v / 1e9))
+        print("   %-26s %7.3f ms %7.1f TFLOP/s" % (k, v, fl / v / 1e9))

@@ -25,6 +25,7 @@
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int FB_KB = 3;                          // 32-key blocks per wave
 constexpr int FB_WKEYS = 32 * FB_KB;              // 96 keys per wave
 constexpr int FB_KEYS = 4 * FB_WKEYS;             // 384 keys per workgroup
@@ -56,8 +57,42 @@ struct FbWork {
   unsigned* flags;        // [B H][nqt]
   unsigned* tickets;      // [3 launches][8 XCD groups]
   unsigned* status;       // [4]: bit 0 of word 0 = a bounded spin timed out
+  const float* nl;        // [B H][nqt * 64]: -lse * log2(e) per query row, -inf behind Lq (written by attn_delta_prep_kernel)
+  const float* nd;        // [B H][nqt * 64]: -delta per query row, 0 behind Lq
   int handoff;
 };
+// Staging of the Q / dO tiles and their row constants by LDS-DMA (buffer_load ... lds: 1 KB per wave-instruction = 8 rows x 128 B
+// straight into the swizzled tile image - the chunk swizzle is a permutation INSIDE a row, so it goes on the per-lane source address;
+// rows behind Lq are out-of-range records and read as zeros; the row constants arrive pre-scaled from the prep kernel).  Replaces
+// global -> 16 VGPRs -> 4 ds_write_b128 per lane and tile (cdna_hip_programming.md rule 21).  -DFB_DMA=0: the
+// register-staged form of rounds 2-3 (tools/ablate/fb_variants.sh builds it for same-box A/B runs).
+#ifndef FB_DMA
+#define FB_DMA 1
+#endif
+// The DMA is issued through inline asm: told about an LDS-DMA builtin, the compiler orders every later LDS read whose address it cannot
+// prove disjoint (the stage buffer index is a run-time value) behind it with an s_waitcnt vmcnt(0) - in the middle of phase A, a
+// full memory round trip per tile (seen in the ISA).  The waits are placed by hand instead: every wave waits for its own pieces
+// (s_waitcnt vmcnt(0) in FB_STAGE_WRITE) ahead of the barrier that publishes the buffer; the buffer being filled is not read by
+// anyone between the barrier that retired its previous tile and that one.  (M0 = LDS byte address of the piece; one wait state
+// between the M0 write and the DMA.)
+__device__ __forceinline__ u32x4 fb_rsrc_s(const void* base, uint32_t bytes) {        // descriptor in SCALAR registers, by construction
+  const uint64_t a = (uint64_t)base;
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) & 0xffffu;
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ uint32_t fb_lds_addr(const char* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void fb_dma16(u32x4 rs, uint32_t lds, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void fb_dma4(u32x4 rs, uint32_t lds, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
 constexpr int FB_CTRL_WORDS = 64;                       // tickets (24) + status (4), padded: the block the launch zeroes, with the flags behind it
 constexpr unsigned FB_SPIN_LIMIT = 1u << 18;            // ~1-2 us per poll: a few tenths of a second (a legitimate wait is < 1 ms)
 
@@ -71,7 +106,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t fb_rsrc(const void* base, unsi
 // tied to AGPRs ("+a") and the S / dP tiles to VGPRs ("+v"), so no copy exists.  hipcc pads nothing inside or behind an asm
 // statement (cdna_hip_programming.md section 5.7): the leading s_nop 1 covers a VALU-written operand, the s_nop 11 behind the
 // last MFMA of a VGPR chain covers its result being read by VALU code (8-pass MFMA: 12 wait states).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define FB_U4(x) __builtin_bit_cast(u32x4, x)
 __device__ __forceinline__ void fb_mfma_sdp(f32x16& sacc, f32x16& dpacc, const bf16x8 (&qf)[4], const bf16x8 (&kf)[4], const bf16x8 (&dof)[4],
                                             const u32x4 (&vf)[4]) {
@@ -313,18 +347,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #pragma unroll
       for (int i = 0; i < 16; ++i) { dkacc[kb][0][i] = 0.f; dkacc[kb][1][i] = 0.f; dvacc[kb][0][i] = 0.f; dvacc[kb][1][i] = 0.f; }
 
-    // ---- staging of the Q / dO tiles (as attn_dkdv_bf16.hip: uniform 64-bit base + advancing 32-bit offsets, rows past Lq
-    // clamp to the last row and get P = 0 through lse = -inf)
-    uint4 q0r, q1r, d0r, d1r;
-    float lreg, dreg;
-    const char* __restrict__ Qb = reinterpret_cast<const char*>(Q);
-    const char* __restrict__ DOb = reinterpret_cast<const char*>(DO);
-    const uint32_t q_step = (uint32_t)(FB_QROWS * p.q_rs * 2), o_step = (uint32_t)(FB_QROWS * p.o_rs * 2);
-    const uint32_t q_max = (uint32_t)((p.Lq - 1) * p.q_rs * 2) + (uint32_t)sc * 16u, o_max = (uint32_t)((p.Lq - 1) * p.o_rs * 2) + (uint32_t)sc * 16u;
-    uint32_t qo0 = (uint32_t)(sr * p.q_rs * 2) + (uint32_t)sc * 16u, oo0 = (uint32_t)(sr * p.o_rs * 2) + (uint32_t)sc * 16u;
-    uint32_t qo1 = qo0 + (uint32_t)(32 * p.q_rs * 2), oo1 = oo0 + (uint32_t)(32 * p.o_rs * 2);
-    int ld_row = tid & 63;
-    int ld_row0 = 0;              // first query row of the tile being loaded (uniform)
     // attention-probability dropout (attn_common.h): this lane's column key of each key block in both 16-bit halves; the row keys of
     // the tile's 32 query pairs are hashed by threads 0..31 while the tile is staged (dkdv kernel's scheme: the same mask function)
     const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
@@ -334,6 +356,57 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
     const float drop_inv = p.drop_inv;
     uint32_t rkreg = 0;
+    int ld_row0 = 0;              // first query row of the tile being loaded (uniform)
+#if FB_DMA
+    // ---- staging of the Q / dO tiles by LDS-DMA.  A tile is 8 pieces of 8 rows; wave w issues pieces w and w + 4 of Q and of dO.
+    // Lane: row 8 piece + lane / 8, chunk POSITION lane % 8, which holds the logical chunk (lane % 8) ^ tile_f(row); tile_f depends on
+    // bits 1..3 of the row, i.e. on lane / 8 and on the parity of the piece - the same for pieces w and w + 4: ONE offset per operand
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int st_r8 = lane >> 3;
+    const int st_chunk = (lane & 7) ^ tile_f(wave_s * 8 + st_r8);
+    const int voff_q = st_r8 * (int)p.q_rs * 2 + (st_chunk << 4), voff_o = st_r8 * (int)p.o_rs * 2 + (st_chunk << 4);
+    const u32x4 rs_q = fb_rsrc_s(Q, (unsigned)(((int64_t)(p.Lq - 1) * p.q_rs + 64) * 2));
+    const u32x4 rs_o = fb_rsrc_s(DO, (unsigned)(((int64_t)(p.Lq - 1) * p.o_rs + 64) * 2));
+    const u32x4 rs_nl = fb_rsrc_s(w.nl + pair * nqt * FB_QROWS, (unsigned)(nqt * FB_QROWS * 4));
+    const u32x4 rs_nd = fb_rsrc_s(w.nd + pair * nqt * FB_QROWS, (unsigned)(nqt * FB_QROWS * 4));
+    const uint32_t st_lds = __builtin_amdgcn_readfirstlane(fb_lds_addr(stage));
+    const int q_rs2 = __builtin_amdgcn_readfirstlane((int)p.q_rs * 2), o_rs2 = __builtin_amdgcn_readfirstlane((int)p.o_rs * 2);
+    int st_buf = 0;               // stage buffer the next FB_STAGE_LOAD fills (uniform)
+#define FB_STAGE_LOAD()                                                                         \
+  {                                                                                             \
+    const uint32_t dst_ = st_lds + (uint32_t)(st_buf * FB_STAGE + wave_s * 1024);               \
+    const int r0_ = ld_row0 + wave_s * 8;                                                       \
+    fb_dma16(rs_q, dst_, voff_q, r0_ * q_rs2);                                                  \
+    fb_dma16(rs_o, dst_ + FB_TILE, voff_o, r0_ * o_rs2);                                        \
+    fb_dma16(rs_q, dst_ + 4096, voff_q, (r0_ + 32) * q_rs2);                                    \
+    fb_dma16(rs_o, dst_ + FB_TILE + 4096, voff_o, (r0_ + 32) * o_rs2);                          \
+    if (wave_s == 0) fb_dma4(rs_nl, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE), lane * 4, ld_row0 * 4);                   \
+    if (wave_s == 1) fb_dma4(rs_nd, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE + FB_QROWS * 4), lane * 4, ld_row0 * 4);    \
+    if (DROP && tid < FB_QROWS / 2) {                                                           \
+      const int qa_ = ld_row0 + 2 * tid, qb2_ = qa_ + 1;                                        \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1) << 16); \
+    }                                                                                           \
+    ld_row0 += FB_QROWS;                                                                        \
+  }
+    // the DMA pieces of the tile must have landed before the barrier that publishes the buffer: every wave waits for its own
+#define FB_STAGE_WRITE(buf_)                                                                    \
+  {                                                                                             \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+    if (DROP && tid < FB_QROWS / 2) reinterpret_cast<uint32_t*>(stage + (buf_) * FB_STAGE + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
+    st_buf ^= 1;                                                                                \
+  }
+#else
+    // ---- staging of the Q / dO tiles through registers (as attn_dkdv_bf16.hip: uniform 64-bit base + advancing 32-bit offsets, rows
+    // past Lq clamp to the last row and get P = 0 through lse = -inf)
+    uint4 q0r, q1r, d0r, d1r;
+    float lreg, dreg;
+    const char* __restrict__ Qb = reinterpret_cast<const char*>(Q);
+    const char* __restrict__ DOb = reinterpret_cast<const char*>(DO);
+    const uint32_t q_step = (uint32_t)(FB_QROWS * p.q_rs * 2), o_step = (uint32_t)(FB_QROWS * p.o_rs * 2);
+    const uint32_t q_max = (uint32_t)((p.Lq - 1) * p.q_rs * 2) + (uint32_t)sc * 16u, o_max = (uint32_t)((p.Lq - 1) * p.o_rs * 2) + (uint32_t)sc * 16u;
+    uint32_t qo0 = (uint32_t)(sr * p.q_rs * 2) + (uint32_t)sc * 16u, oo0 = (uint32_t)(sr * p.o_rs * 2) + (uint32_t)sc * 16u;
+    uint32_t qo1 = qo0 + (uint32_t)(32 * p.q_rs * 2), oo1 = oo0 + (uint32_t)(32 * p.o_rs * 2);
+    int ld_row = tid & 63;
 #define FB_STAGE_LOAD()                                                                         \
   {                                                                                             \
     const uint32_t a0_ = qo0 < q_max ? qo0 : q_max, b0_ = oo0 < o_max ? oo0 : o_max;            \
@@ -365,6 +438,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     }                                                                                           \
     if (DROP && tid < FB_QROWS / 2) reinterpret_cast<uint32_t*>(base_ + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
   }
+#endif
     FB_STAGE_LOAD();
     FB_STAGE_WRITE(0);
     __syncthreads();
@@ -649,6 +723,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #pragma unroll
         for (int u = 0; u < 4; ++u) { bfA[u] = fb_tr(kimg + (16 * u) * 128, vad); bfB[u] = fb_tr(kimg + (16 * (4 + u)) * 128, vad); }
       }
+      // hand-off: the running sum of the blocks before this one (zeros for block 0: zero-record descriptor)
+      u32x4 pin[4];
+      const unsigned ho_off = (unsigned)((qt * 4 + wave_u) * 4096 + lane * 16);
       if constexpr (HO) {
         // every wave: its running-sum stores of the PREVIOUS tile have landed (the flag below is stored behind this wait and the
         // barrier: Guideline 16 R1); the stage loads of this tile are younger and are needed right below anyway
@@ -669,6 +746,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         }
       }
       FB_STAGE_WRITE(buf ^ 1);
+      if constexpr (HO) {
+        // this wave's own poll has matched: its loads of the sum may go out now (every load of handed-off bytes is an sc1 load issued
+        // by a wave behind its own matching poll) - ahead of the barrier, behind the staging wait (which would wait for them too),
+        // so that they have the barrier and all of phase B to come back
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pin[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ho_off + g * 1024, 0, 16 /* sc1 */);
+      }
       FB_TICK(1);                                            // stage write
       __syncthreads();                                       // the dS^T image of this query tile is complete
       FB_TICK(2);                                            // barrier 1
@@ -682,13 +766,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         f32x16 dqacc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqacc[i] = 0.f;
-        // hand-off: the running sum of the blocks before this one (zeros for block 0: zero-record descriptor), in flight under the MFMAs
-        u32x4 pin[4];
-        const unsigned ho_off = (unsigned)((qt * 4 + wave_u) * 4096 + lane * 16);
-        if constexpr (HO) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) pin[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ho_off + g * 1024, 0, 16 /* sc1 */);
-        }
         // steps of 16 keys in groups of 4; full key blocks: 24 steps with the transposed reads of group g+1 in flight under the
         // MFMAs of group g, otherwise the steps that hold valid keys (rows past them may never have been written)
 #ifndef FB_ABL
@@ -892,6 +969,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 // the same pass over the rows: zero the row of the fp32 dQ accumulation buffer, and write the exact-zero dK / dV slices of
 // rows that no key-list entry points at (prefix rows with row_valid == 0; rows behind the prefix other than this call's decoder rows).
 __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
+                                                              const float* __restrict__ lse, float* __restrict__ nl, float* __restrict__ nd, int nq_pad,
                                                               float* __restrict__ dq32 /* NULL: no accumulation buffer to zero (hand-off form) */, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                                                               const uint8_t* __restrict__ row_valid, int valid_len, int dec_q0, int n_dec, int B, int H, int Lq,
                                                               int64_t o_rs, int64_t o_bs, int64_t kv_rs, int64_t kv_bs) {
@@ -921,7 +999,14 @@ __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __re
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
     s += __shfl_xor(s, 8, 64);
-    if ((lane & 15) == 0 && ci < nchunk) delta[((int64_t)b * H + (ci >> 4)) * Lq + q] = s;
+    if ((lane & 15) == 0 && ci < nchunk) {
+      const int64_t bh = (int64_t)b * H + (ci >> 4);
+      delta[bh * Lq + q] = s;
+      if (nl) {          // the row constants as the fused sweep seeds its accumulators with them (LDS-DMA copies them raw)
+        nl[bh * nq_pad + q] = -(lse[bh * Lq + q] * LOG2E);
+        nd[bh * nq_pad + q] = -s;
+      }
+    }
   }
 }
 
@@ -946,8 +1031,9 @@ __global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restri
 size_t attn_bwd_fused_workspace_bytes(int B, int H, int Lq) {
   const size_t nqt = ((size_t)Lq + FB_QROWS - 1) / FB_QROWS;
   const size_t ctrl = ((size_t)FB_CTRL_WORDS * 4 + (size_t)B * H * nqt * 4 + 255) / 256 * 256;
+  const size_t rowc = 2 * (size_t)B * H * nqt * FB_QROWS * 4;            // -lse log2e and -delta per padded query row (LDS-DMA sources)
   const size_t sums = (size_t)B * H * nqt * (FB_QROWS * 64 * 4);        // >= B * Lq * H * 64 * 4, the atomic form's buffer
-  return ctrl + sums + 16384;                                            // + room for the diagnostic build's stamps
+  return ctrl + rowc + sums + 16384;                                     // + room for the diagnostic build's stamps
 }
 
 // Fused backward (bf16): delta + housekeeping, the 5-product kernel (+ its tail launch, see attn_dkdv_bf16.hip); dQ across key
@@ -965,7 +1051,12 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   w.tickets = reinterpret_cast<unsigned*>(workspace);
   w.status = w.tickets + 3 * T2S_XCDS;
   w.flags = w.tickets + FB_CTRL_WORDS;
-  w.part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ctrl);
+  const size_t rowc_n = (size_t)p.B * p.H * nqt * FB_QROWS;               // elements of each row-constant array
+  float* const nl = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ctrl);
+  float* const nd = nl + rowc_n;
+  w.nl = nl;
+  w.nd = nd;
+  w.part = nd + rowc_n;
   w.handoff = handoff;
   float* const dq32 = w.part;
   // > 64 KB of LDS per workgroup needs the opt-in; set on every call (idempotent, per device, no state of ours is kept)
@@ -987,8 +1078,17 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
     }
   }
   const int64_t rows = (int64_t)p.B * p.Lq;
+#if FB_DMA
+  // rows behind Lq of the padded row-constant arrays: P = exp2(-inf) = 0 there, and -delta must not be a NaN from an earlier use of
+  // the workspace (0 * NaN); the prep kernel overwrites the rows that exist
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(nl), (int)0xFF800000u, rowc_n, st) != hipSuccess ||
+      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(nd), 0, rowc_n, st) != hipSuccess) {
+    t2s_set_error("attn_bwd_fused: cannot initialise the row-constant arrays");
+    return 3;
+  }
+#endif
   hipLaunchKernelGGL(attn_delta_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)p.o, (const bf16_t*)p.dout, p.delta,
-                     handoff ? nullptr : dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs,
+                     (const float*)p.lse, FB_DMA ? nl : nullptr, nd, (int)(nqt * FB_QROWS), handoff ? nullptr : dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs,
                      p.kv_rs, p.kv_bs);
   T2S_CHECK_LAUNCH("attn_bwd_fused (delta prep)");
   p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
