@@ -161,6 +161,30 @@ def test_attention_dropout_mask_statistics():
     assert abs(crest.mean().item()) < 2e-3 and (crest.abs() > 6.5 * sig).float().mean().item() < 2e-3
     print("dropout mask at L=2048: %d identical row pairs (expected ~%.0f from key collisions); other row pairs: %.4f %% beyond 6.5 sigma, max |corr| %.3f"
           % (same, Lq * Lq / 2 ** 16, 100 * (rest.abs() > 6.5 * sig).float().mean().item(), rest.abs().max().item()))
+    del big, z, corr, off, rest, ccorr, coff, crest
+    # The same count at the BENCHMARK's length: L = 10 132 query rows x 10 132 key-list positions of one (sample, head).
+    # Row keys are odd 16-bit numbers (2^15 values), so L^2 / 2 / 2^15 ~ 1 566 of the 51 M row pairs share a key and with it their
+    # whole mask - i.e. about a quarter of the rows have a twin somewhere in the sequence (the reference's Philox draw has none).
+    # Bounded here, from above AND below (the count is what the key width implies, no hidden structure on top of it), together with
+    # the strongly anti-correlated pairs (key ratio -1: the two masks never drop the same key; correlation -p / (1 - p) = -0.11)
+    # and the fraction of all other pairs outside sampling noise.
+    Lb = 10132
+    m = ops.attn_dropout_mask(1, Lb, Lb, 0.1, 11, DEV)[0, 0]                # uint8 [Lb, Lb]
+    z = m.float()
+    mu = z.mean()
+    z = ((z - mu) / z.std()).to(torch.bfloat16)                             # +-: two values, exact enough in bf16 for a count
+    corr = (z @ z.t()).float() / Lb
+    corr.fill_diagonal_(0)
+    same = int((corr > 0.99).sum().item()) // 2
+    expect = Lb * Lb / 2 ** 16
+    twins = int((corr > 0.99).any(1).sum().item())
+    anti = int((corr < -0.09).sum().item()) // 2
+    sig = 1.0 / Lb ** 0.5
+    outl = ((corr.abs() > 6.5 * sig) & (corr < 0.99)).float().mean().item()
+    assert 0.7 * expect < same < 1.3 * expect + 50, (same, expect)
+    assert outl < 2e-3
+    print("dropout mask at L=10132: %d identical row pairs (%.0f expected from 15-bit row keys), %d of %d rows have a twin; %d pairs with "
+          "correlation < -0.09; other pairs beyond 6.5 sigma: %.4f %%" % (same, expect, twins, Lb, anti, 100 * outl))
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
