@@ -39,13 +39,17 @@ def main():
     torch.cuda.synchronize()
     # backward: the two-kernel (7-product) and the fused (5-product, no dropout) forms, interleaved rounds in ONE process
     # (fused: dQ across key blocks by the ordered hand-off, dq_mode 1, and by fp32 atomics + cast, dq_mode 0)
-    forms = [("two-kernel", dict(fused=False)), ("fused/handoff", dict(fused=True, dq_mode=1)), ("fused/atomic", dict(fused=True, dq_mode=0))]
-    tb_all = {n: [] for n, _ in forms}
-    for n, f in forms:
+    # "split": full and edge key blocks as two launches (rounds 2-3, T2S_FB_SPLIT_EDGE=1, read per call); default: one launch
+    forms = [("two-kernel", dict(fused=False), "0"), ("fused/handoff", dict(fused=True, dq_mode=1), "0"), ("fused/atomic", dict(fused=True, dq_mode=0), "0"),
+             ("fused/handoff split", dict(fused=True, dq_mode=1), "1"), ("fused/atomic split", dict(fused=True, dq_mode=0), "1")]
+    tb_all = {n: [] for n, _, _ in forms}
+    for n, f, env in forms:
+        os.environ["T2S_FB_SPLIT_EDGE"] = env
         ops.attn_bwd(qkv, out, dout, lse, keys, **f, **kw)
     torch.cuda.synchronize()
     for _ in range(iters):
-        for n, f in forms:
+        for n, f, env in forms:
+            os.environ["T2S_FB_SPLIT_EDGE"] = env
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             ops.attn_bwd(qkv, out, dout, lse, keys, **f, **kw)
@@ -55,6 +59,7 @@ def main():
     ev[2].record()
     ev[3].record()
     torch.cuda.synchronize()
+    os.environ["T2S_FB_SPLIT_EDGE"] = "0"
     print("   hand-off status word: %d" % ops.fused_handoff_status())
     tf = ev[0].elapsed_time(ev[1]) / iters
     tb = sorted(tb_all["two-kernel"])[len(tb_all["two-kernel"]) // 2]
@@ -65,7 +70,7 @@ def main():
           % (B, L, nk, tf, dense / tf / 1e9, execd / tf / 1e9, tb, 2.5 * dense / tb / 1e9, 2.5 * execd / tb / 1e9))
     for n, ts in tb_all.items():
         ts = sorted(ts)
-        print("   bwd %-13s median %.3f ms  min %.3f ms  -> %.1f TF/s on the algorithmic 5 products (executed keys)" % (n, ts[len(ts) // 2], ts[0], 2.5 * execd / ts[len(ts) // 2] / 1e9))
+        print("   bwd %-20s median %.3f ms  min %.3f ms  -> %.1f TF/s on the algorithmic 5 products (executed keys)" % (n, ts[len(ts) // 2], ts[0], 2.5 * execd / ts[len(ts) // 2] / 1e9))
 
 
 if __name__ == "__main__":

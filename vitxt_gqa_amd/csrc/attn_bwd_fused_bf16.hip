@@ -19,6 +19,8 @@
 // 32 x 32 tile (query sub-block w >> 1, dim block w & 1) of dQ = dS K over ALL 384 keys (both operands by
 // ds_read_b64_tr_b16 from the two images) and adds it to the fp32 dQ buffer: each accumulator register is two 128-byte
 // row segments, the shape the atomics run at full rate for.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "attn_common.h"
@@ -223,6 +225,11 @@ __device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dp
   }
 }
 
+// MODE 3 (round 4, the shipped launch): BOTH kinds of workgroup in ONE launch - one workgroup-uniform branch at the top picks the
+// straight-line sweep or the edge sweep.  As two launches the edge blocks (one per (sample, head): 768 workgroups at B = 64, each a
+// full query sweep for half a block of keys on average) ran alone on the chip for 1.6 - 2.3 ms per call (3 waves of workgroups on 256
+// CUs, 7 - 10 % of the fused backward); in one launch they fill in between the other workgroups.  MODE 0 / 1 remain for A/B runs
+// (T2S_FB_SPLIT_EDGE=1).
 // MODE 0: workgroups whose 384 keys are all valid prefix keys run the software-pipelined sweep, the others exit; MODE 1: the
 // complement (the same pipeline with the validity / decoder rule applied to P); MODE 2:
 // the tail launch (plain sweep, loops over the key blocks beyond the static bound).  Separate kernels, so that each is
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   if constexpr (HO && !TAIL) {
     // ticket: this workgroup is the slot-th one of its XCD group to START (not the slot-th by id), see FbWork
     unsigned* sl = reinterpret_cast<unsigned*>(smem);
-    if (tid == 0) sl[0] = atomicAdd(w.tickets + MODE * T2S_XCDS + (blockIdx.x % T2S_XCDS), 1u);
+    if (tid == 0) sl[0] = atomicAdd(w.tickets + (MODE % 3) * T2S_XCDS + (blockIdx.x % T2S_XCDS), 1u);
     __syncthreads();
     const int slot = __builtin_amdgcn_readfirstlane((int)sl[0]);
     __syncthreads();                               // (the stage buffer is written below)
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     if (MODE == 0 && edge_wg) return;                                              // (nkeys_wg == FB_KEYS follows from !edge_wg)
     if (MODE == 1 && !edge_wg) return;
     // hand-off chain position (workgroup-uniform): block 0 has no predecessor, the block that holds the end of the list finishes dQ
-    const bool ho_last = HO && (MODE != 0) && (kp0 + FB_KEYS >= nk);
+    const bool ho_last = HO && (MODE != 0) && (kp0 + FB_KEYS >= nk);              // (a last block is an edge block: never in the FULL, non-EDGE sweep)
     int ho_wait = (HO && !TAIL) ? kbw : 0;                                         // flags[t] must reach this before tile t's sum is read
     // running sums of this pair through a buffer descriptor: block 0 gets ZERO records - its loads return 0.0 without touching
     // memory, so the sweep needs no branch around them
@@ -457,6 +464,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     constexpr bool FULL = decltype(pipe_tag)::value;         // the software-pipelined phase A (all three key blocks of every wave run)
     constexpr bool EDGE = decltype(edge_tag)::value;         // ... with the validity / decoder rule applied to P
     constexpr bool PREF = FULL && !EDGE;                     // the first operands of tile t+1 are fetched from LDS during phase B of tile t
+    constexpr bool CAN_LAST = EDGE || !FULL;                 // hand-off: only an edge block (or the tail launch) can end a pair's chain
     bf16x8 qf[4], dof[4], kf[4];
     f32x16 sacc[2], dpacc[2];
     const char* kw_ = kimg + wave * (FB_WKEYS * 128);
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       FB_TICK(2);                                            // barrier 1
       if constexpr (HO && !TAIL) {
         // publish the previous tile's running sum: every wave drained its stores before the barrier above
-        if ((MODE == 0 || !ho_last) && tid == 0 && qt > 0)
+        if ((!CAN_LAST || !ho_last) && tid == 0 && qt > 0)
           __hip_atomic_store(flags_pair + (qt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // ================= phase B: dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
@@ -862,7 +870,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             const f32x4 pf = __builtin_bit_cast(f32x4, pin[r >> 2]);
             tot[r] = __builtin_fmaf(dqacc[r], 0.6931471805599453f, pf[r & 3]);
           }
-          if (MODE != 0 && ho_last) {
+          if (CAN_LAST && ho_last) {
             // the last block of the pair: dQ rows in bf16.  Lanes 2i / 2i+1 hold columns 2i / 2i+1 of the same rows: the even lane
             // takes the odd lane's value of register 2m, the odd lane the even lane's value of register 2m+1 (DPP quad_perm 1,0,3,2),
             // each then stores ONE 4-byte pair of its own row
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     if constexpr (HO) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last tile's stores (the tail launch reads them back in its next key block)
       if constexpr (!TAIL) {
-        if (MODE == 0 || !ho_last) {                         // workgroup-uniform
+        if (!CAN_LAST || !ho_last) {                         // workgroup-uniform
           __syncthreads();
           if (tid == 0) __hip_atomic_store(flags_pair + (nqt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -922,7 +930,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #ifndef FB_STAMP_MODE
 #define FB_STAMP_MODE 0      // which kernel of the launch records its stamps (0: full key blocks, 1: the edge blocks)
 #endif
-    if (MODE == FB_STAMP_MODE && lane == 0 && wave == 0) {
+    if ((MODE == FB_STAMP_MODE || (MODE == 3 && FB_STAMP_MODE == (EDGE ? 1 : 0))) && lane == 0 && wave == 0) {
       unsigned long long* dbg = reinterpret_cast<unsigned long long*>(dq32 + (int64_t)p.B * p.Lq * (p.H * 64)) + (int64_t)(blockIdx.x & 255) * 8;
       for (int k = 0; k < 6; ++k) dbg[k] = st_sum[k];
       dbg[6] = (unsigned long long)nqt;
@@ -930,7 +938,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     }
 #endif
     };
-    sweep(std::integral_constant<bool, MODE != 2>{}, std::integral_constant<bool, MODE == 1>{});
+    if constexpr (MODE == 3) {
+      if (edge_wg) sweep(std::true_type{}, std::true_type{});
+      else sweep(std::true_type{}, std::false_type{});
+    } else {
+      sweep(std::integral_constant<bool, MODE != 2>{}, std::integral_constant<bool, MODE == 1>{});
+    }
 #undef FB_LD_QF
 #undef FB_LD_SEEDS
 #undef FB_LD_KF
@@ -1062,7 +1075,8 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   // > 64 KB of LDS per workgroup needs the opt-in; set on every call (idempotent, per device, no state of ours is kept)
 #define FB_K(I_, M_, D_) reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, true>)
   const void* kernels[] = {FB_K(true, 0, false), FB_K(true, 1, false), FB_K(true, 2, false), FB_K(false, 0, false), FB_K(false, 1, false),
-                           FB_K(true, 0, true),  FB_K(true, 1, true),  FB_K(true, 2, true),  FB_K(false, 0, true),  FB_K(false, 1, true)};
+                           FB_K(true, 0, true),  FB_K(true, 1, true),  FB_K(true, 2, true),  FB_K(false, 0, true),  FB_K(false, 1, true),
+                           FB_K(true, 3, false), FB_K(false, 3, false), FB_K(true, 3, true), FB_K(false, 3, true)};
 #undef FB_K
   for (const void* k : kernels)
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
@@ -1099,13 +1113,23 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
 #define FB_LAUNCH(IDX_, MODE_, grid_)                                                                                  \
   if (p.drop_thresh) { FB_LAUNCH2(IDX_, MODE_, true, grid_) } else { FB_LAUNCH2(IDX_, MODE_, false, grid_) }            \
   T2S_CHECK_LAUNCH("attn_bwd_fused (five-product kernel)");
+  const char* split_env = getenv("T2S_FB_SPLIT_EDGE");          // A/B runs: the two-launch form of rounds 2-3 (read per call)
+  const bool split_edge = split_env && split_env[0] == '1';
   if (p.kv_idx) {
-    FB_LAUNCH(true, 0, grid);
-    FB_LAUNCH(true, 1, grid);
+    if (split_edge) {
+      FB_LAUNCH(true, 0, grid);
+      FB_LAUNCH(true, 1, grid);
+    } else {
+      FB_LAUNCH(true, 3, grid);
+    }
     if (p.kblocks * FB_KEYS < p.idx_cap) { FB_LAUNCH(true, 2, tail); }
   } else {
-    FB_LAUNCH(false, 0, grid);
-    FB_LAUNCH(false, 1, grid);
+    if (split_edge) {
+      FB_LAUNCH(false, 0, grid);
+      FB_LAUNCH(false, 1, grid);
+    } else {
+      FB_LAUNCH(false, 3, grid);
+    }
   }
 #undef FB_LAUNCH
 #undef FB_LAUNCH2
