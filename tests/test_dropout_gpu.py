@@ -175,13 +175,13 @@ def test_attention_dropout_mask_statistics():
     z = ((z - mu) / z.std()).to(torch.bfloat16)                             # +-: two values, exact enough in bf16 for a count
     corr = (z @ z.t()).float() / Lb
     corr.fill_diagonal_(0)
-    same = int((corr > 0.99).sum().item()) // 2
+    same = int((corr > 0.9).sum().item()) // 2                              # (bf16 z: an identical pair's correlation comes out as 1 +- 1 %; any other pair's is < 0.15)
     expect = Lb * Lb / 2 ** 16
-    twins = int((corr > 0.99).any(1).sum().item())
+    twins = int((corr > 0.9).any(1).sum().item())
     anti = int((corr < -0.09).sum().item()) // 2
     sig = 1.0 / Lb ** 0.5
-    outl = ((corr.abs() > 6.5 * sig) & (corr < 0.99)).float().mean().item()
-    assert 0.7 * expect < same < 1.3 * expect + 50, (same, expect)
+    outl = ((corr.abs() > 6.5 * sig) & (corr < 0.9)).float().mean().item()
+    assert 0.6 * expect < same < 1.4 * expect + 50, (same, expect)
     assert outl < 2e-3
     print("dropout mask at L=10132: %d identical row pairs (%.0f expected from 15-bit row keys), %d of %d rows have a twin; %d pairs with "
           "correlation < -0.09; other pairs beyond 6.5 sigma: %.4f %%" % (same, expect, twins, Lb, anti, 100 * outl))

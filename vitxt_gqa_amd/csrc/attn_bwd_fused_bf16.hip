@@ -314,7 +314,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     int ho_wait = (HO && !TAIL) ? kbw : 0;                                         // flags[t] must reach this before tile t's sum is read
     // running sums of this pair through a buffer descriptor: block 0 gets ZERO records - its loads return 0.0 without touching
     // memory, so the sweep needs no branch around them
-    const __amdgpu_buffer_rsrc_t rs_ld = fb_rsrc(part_pair, (HO && kbw > 0) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
+#ifndef FB_HO_ABL
+#define FB_HO_ABL 0      // timing-only switches of diagnostic builds (results wrong): 1 = every block's sum loads read zeros (no memory access), 2 = no
+                         // flag load / poll, 4 = plain instead of write-through stores, 8 = no stores of the sum; 0 in every product build
+#endif
+    const __amdgpu_buffer_rsrc_t rs_ld = fb_rsrc(part_pair, (HO && kbw > 0 && !(FB_HO_ABL & 1)) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
     const __amdgpu_buffer_rsrc_t rs_st = fb_rsrc(part_pair, HO ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
     // ---- K image of the workgroup's keys, pre-scaled by scale*log2e (one bf16 rounding per element, as the dK/dV kernel's
     // register fragments); rows past the list repeat its last key (their P is forced to 0 below)
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       const int buf = qt & 1;
       // hand-off: how far the predecessor has published this tile's running sum - asked now, looked at at the end of phase A
       unsigned fv = 0;
-      if constexpr (HO && !TAIL) fv = __hip_atomic_load(flags_pair + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (HO && !TAIL && !(FB_HO_ABL & 2)) fv = __hip_atomic_load(flags_pair + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // global loads of the next tile in sequence (past the end: clamped rows, harmless).  Pipelined form: issued a third of the way
       // into phase A instead of here - at the top of the tile the memory pipeline is still draining the 16 atomics per lane of the
       // previous tile, and the loads are not needed before the end of the phase
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (!TAIL) {
           int fvs = __builtin_amdgcn_readfirstlane((int)fv);
-          if (fvs < ho_wait) {                               // the predecessor has not published this tile yet: bounded spin
+          if (!(FB_HO_ABL & 2) && fvs < ho_wait) {                               // the predecessor has not published this tile yet: bounded spin
             unsigned spins = 0;
             do {
               __builtin_amdgcn_s_sleep(16);
@@ -888,7 +892,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const f32x4 t4 = {tot[4 * g], tot[4 * g + 1], tot[4 * g + 2], tot[4 * g + 3]};
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 16 /* sc1: write-through */);
+              if (!(FB_HO_ABL & 8))
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, (FB_HO_ABL & 4) ? 0 : 16 /* sc1: write-through */);
+              else
+                asm volatile("" ::"v"(t4));
             }
           }
         } else {

@@ -100,6 +100,7 @@ class GradBuckets:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (single_rank_collectives and dist.is_initialized())
         self.launched = 0          # collectives launched since construction
+        self.launch_events = None  # set to a list to record (bucket index, CUDA event on the compute stream) at every launch (tools/bucket_timing.py)
         self.average = average
         params = [p for p in params if p.requires_grad]
         # gradients become ready roughly in reverse construction order
@@ -139,6 +140,10 @@ class GradBuckets:
                 if self.average and self.world > 1:
                     flat.div_(self.world)
                 self.launched += 1
+                if self.launch_events is not None and flat.is_cuda:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.launch_events.append((bi, ev))
                 self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return hook
 
