@@ -42,6 +42,8 @@ def main():
     # "split": full and edge key blocks as two launches (rounds 2-3, T2S_FB_SPLIT_EDGE=1, read per call); default: one launch
     forms = [("two-kernel", dict(fused=False), "0"), ("fused/handoff", dict(fused=True, dq_mode=1), "0"), ("fused/atomic", dict(fused=True, dq_mode=0), "0"),
              ("fused/handoff split", dict(fused=True, dq_mode=1), "1"), ("fused/atomic split", dict(fused=True, dq_mode=0), "1")]
+    if os.environ.get("T2S_PROBE_FORMS") == "shipped":          # PMC passes: only the forms the product runs
+        forms = forms[:2]
     tb_all = {n: [] for n, _, _ in forms}
     for n, f, env in forms:
         os.environ["T2S_FB_SPLIT_EDGE"] = env

@@ -6,6 +6,7 @@ ARGS=${@:-8 10120 1.0 12 2}
 OUT=/root/repo/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export T2S_PROBE_FORMS=shipped      # tools/attn_probe.py: only the backward forms the product runs (two-kernel + fused with the dQ hand-off)
 i=0
 for pm in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" \
           "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA SQ_WAVES" \
