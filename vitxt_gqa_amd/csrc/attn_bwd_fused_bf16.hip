@@ -36,6 +36,8 @@ constexpr int FB_TILE = FB_QROWS * 128;           // bytes of a 64-row bf16 tile
 constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + (FB_QROWS / 2) * 4;   // Q | dO | -lse*log2e | -delta | dropout row keys (pairs)
 constexpr int FB_KIMG = FB_KEYS * 128;
 constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
+constexpr int FB_SUMS = FB_QROWS * 64 * 4;        // hand-off: the predecessor's running sum of one query tile, prefetched into LDS (16 KB)
+constexpr int FB_SMEM_TOTAL = FB_SMEM + FB_SUMS;
 
 // ---- dQ across the key blocks of a (sample, head): two forms, chosen per launch (FbWork::handoff).
 // ATOMIC (rounds 2-3): every key block adds its [64 x 64] tile to an fp32 [B Lq, H 64] buffer with float atomics (memory-side,
@@ -71,6 +73,13 @@ struct FbWork {
 #ifndef FB_DMA
 #define FB_DMA 1
 #endif
+// Hand-off: the predecessor's running sum of tile t+1 is fetched by LDS-DMA into a 16 KB LDS region at the END of tile t (its flag was
+// checked one tile ahead), lands under phase A of tile t+1 and is read back from LDS behind phase B - instead of four register loads
+// issued ahead of phase B, whose memory latency phase B alone does not cover (profiles/r04_handoff_ablation.txt: ~2.5 % of the kernel).
+// -DFB_HO_PREFETCH=0: the register form.
+#ifndef FB_HO_PREFETCH
+#define FB_HO_PREFETCH FB_DMA
+#endif
 // The DMA is issued through inline asm: told about an LDS-DMA builtin, the compiler orders every later LDS read whose address it cannot
 // prove disjoint (the stage buffer index is a run-time value) behind it with an s_waitcnt vmcnt(0) - in the middle of phase A, a
 // full memory round trip per tile (seen in the ISA).  The waits are placed by hand instead: every wave waits for its own pieces
@@ -91,6 +100,9 @@ __device__ __forceinline__ uint32_t fb_lds_addr(const char* p) {
 }
 __device__ __forceinline__ void fb_dma16(u32x4 rs, uint32_t lds, int voff, int soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void fb_dma16_sc1(u32x4 rs, uint32_t lds, int voff, int soff) {      // handed-off bytes: every load of them bypasses L1 (sc1)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
 }
 __device__ __forceinline__ void fb_dma4(u32x4 rs, uint32_t lds, int voff, int soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
@@ -320,6 +332,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #endif
     const __amdgpu_buffer_rsrc_t rs_ld = fb_rsrc(part_pair, (HO && kbw > 0 && !(FB_HO_ABL & 1)) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
     const __amdgpu_buffer_rsrc_t rs_st = fb_rsrc(part_pair, HO ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
+    constexpr bool HP = HO && !TAIL && FB_HO_PREFETCH;                              // sum prefetched through LDS (block 0 has none: uniform branch)
+    const bool ho_first = kbw == 0;
     // ---- K image of the workgroup's keys, pre-scaled by scale*log2e (one bf16 rounding per element, as the dK/dV kernel's
     // register fragments); rows past the list repeat its last key (their P is forced to 0 below)
 #pragma unroll
@@ -450,6 +464,39 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     if (DROP && tid < FB_QROWS / 2) reinterpret_cast<uint32_t*>(base_ + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
   }
 #endif
+    // hand-off with prefetch: tile 0's sum must be published before its DMA goes out (later tiles: checked one tile ahead, inside the sweep)
+    const u32x4 rs_sum = HP ? fb_rsrc_s(part_pair, (unsigned)(nqt * FB_SUMS)) : u32x4{0u, 0u, 0u, 0u};
+    const uint32_t hp_lds = HP ? __builtin_amdgcn_readfirstlane(fb_lds_addr(smem + FB_SMEM)) + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 4096u : 0u;
+#define FB_SUM_DMA(qt_)                                                                         \
+  {                                                                                             \
+    const int so_ = ((qt_) * 4 + __builtin_amdgcn_readfirstlane(wave)) * 4096;                  \
+    fb_dma16_sc1(rs_sum, hp_lds, lane * 16, so_);                                               \
+    fb_dma16_sc1(rs_sum, hp_lds + 1024, lane * 16, so_ + 1024);                                 \
+    fb_dma16_sc1(rs_sum, hp_lds + 2048, lane * 16, so_ + 2048);                                 \
+    fb_dma16_sc1(rs_sum, hp_lds + 3072, lane * 16, so_ + 3072);                                 \
+  }
+#define FB_FLAG_WAIT(addr_, fv_)      /* bounded spin until *addr_ >= ho_wait (fv_: a value already read from it) */  \
+  {                                                                                             \
+    int fvs_ = __builtin_amdgcn_readfirstlane((int)(fv_));                                      \
+    if (!(FB_HO_ABL & 2) && fvs_ < ho_wait) {                                                   \
+      unsigned spins_ = 0;                                                                      \
+      do {                                                                                      \
+        __builtin_amdgcn_s_sleep(16);                                                           \
+        fvs_ = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load((addr_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); \
+        if (++spins_ > FB_SPIN_LIMIT) {     /* never in a correct run: report, stop waiting (wrong dQ, no hang) */          \
+          if (lane == 0) atomicOr(w.status, 1u);                                                \
+          ho_wait = 0;                                                                          \
+        }                                                                                       \
+      } while (fvs_ < ho_wait);                                                                 \
+    }                                                                                           \
+  }
+    if constexpr (HP) {
+      if (!ho_first) {
+        const unsigned f0_ = __hip_atomic_load(flags_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FB_FLAG_WAIT(flags_pair, f0_);
+        FB_SUM_DMA(0);
+      }
+    }
     FB_STAGE_LOAD();
     FB_STAGE_WRITE(0);
     __syncthreads();
@@ -516,7 +563,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       const int buf = qt & 1;
       // hand-off: how far the predecessor has published this tile's running sum - asked now, looked at at the end of phase A
       unsigned fv = 0;
-      if constexpr (HO && !TAIL && !(FB_HO_ABL & 2)) fv = __hip_atomic_load(flags_pair + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (prefetch form: the flag of the NEXT tile, whose sum is fetched at the end of this one)
+      const int fq = HP ? (qt + 1 < nqt ? qt + 1 : qt) : qt;
+      if constexpr (HO && !TAIL && !(FB_HO_ABL & 2)) fv = __hip_atomic_load(flags_pair + fq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // global loads of the next tile in sequence (past the end: clamped rows, harmless).  Pipelined form: issued a third of the way
       // into phase A instead of here - at the top of the tile the memory pipeline is still draining the 16 atomics per lane of the
       // previous tile, and the loads are not needed before the end of the phase
@@ -742,23 +791,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // every wave: its running-sum stores of the PREVIOUS tile have landed (the flag below is stored behind this wait and the
         // barrier: Guideline 16 R1); the stage loads of this tile are younger and are needed right below anyway
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (!TAIL) {
-          int fvs = __builtin_amdgcn_readfirstlane((int)fv);
-          if (!(FB_HO_ABL & 2) && fvs < ho_wait) {                               // the predecessor has not published this tile yet: bounded spin
-            unsigned spins = 0;
-            do {
-              __builtin_amdgcn_s_sleep(16);
-              fvs = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flags_pair + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-              if (++spins > FB_SPIN_LIMIT) {                 // never in a correct run: report, stop waiting (wrong dQ, no hang)
-                if (lane == 0) atomicOr(w.status, 1u);
-                ho_wait = 0;
-              }
-            } while (fvs < ho_wait);
-          }
-        }
+        if constexpr (!TAIL) FB_FLAG_WAIT(flags_pair + fq, fv);          // the predecessor has not published that tile yet: bounded spin
       }
       FB_STAGE_WRITE(buf ^ 1);
-      if constexpr (HO) {
+      if constexpr (HO && !HP) {
         // this wave's own poll has matched: its loads of the sum may go out now (every load of handed-off bytes is an sc1 load issued
         // by a wave behind its own matching poll) - ahead of the barrier, behind the staging wait (which would wait for them too),
         // so that they have the barrier and all of phase B to come back
@@ -866,6 +902,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // half wave: two 128-byte segments per wave instruction
         const int q0 = qt * FB_QROWS + dq_qb * 32;
         if constexpr (HO) {
+          if constexpr (HP) {          // the sum arrived by DMA under phase A (waited for in FB_STAGE_WRITE); block 0 has none
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              pin[g] = ho_first ? u32x4{0u, 0u, 0u, 0u}
+                                : *reinterpret_cast<const u32x4*>(smem + FB_SMEM + wave_u * 4096 + g * 1024 + lane * 16);
+          }
           f32x16 tot;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -897,6 +939,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
               else
                 asm volatile("" ::"v"(t4));
             }
+          }
+          if constexpr (HP) {          // next tile's sum: its flag was checked at the end of this tile's phase A; the LDS region was read just above
+            if (!ho_first && qt + 1 < nqt) FB_SUM_DMA(qt + 1);
           }
         } else {
         const int rstep = p.H * 64;
@@ -960,6 +1005,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dkacc[kb][0]), "+a"(dkacc[kb][1]), "+a"(dvacc[kb][0]), "+a"(dvacc[kb][1]));
 #undef FB_STAGE_LOAD
 #undef FB_STAGE_WRITE
+#undef FB_SUM_DMA
+#undef FB_FLAG_WAIT
 
     // ---- dK / dV of this wave's keys
 #pragma unroll
@@ -1086,8 +1133,8 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
                            FB_K(true, 3, false), FB_K(false, 3, false), FB_K(true, 3, true), FB_K(false, 3, true)};
 #undef FB_K
   for (const void* k : kernels)
-    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
-      t2s_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS per workgroup", FB_SMEM);
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM_TOTAL) != hipSuccess) {
+      t2s_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS per workgroup", FB_SMEM_TOTAL);
       return 3;
     }
   {
@@ -1115,8 +1162,8 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256), tail(attn_xcd_grid(1, p.H, p.B));
 #define FB_LAUNCH2(IDX_, MODE_, DROP_, grid_)                                                                            \
-  if (handoff) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, true>), grid_, block, FB_SMEM, st, p, w);   \
-  else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, false>), grid_, block, FB_SMEM, st, p, w);
+  if (handoff) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, true>), grid_, block, FB_SMEM_TOTAL, st, p, w);   \
+  else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, false>), grid_, block, FB_SMEM_TOTAL, st, p, w);
 #define FB_LAUNCH(IDX_, MODE_, grid_)                                                                                  \
   if (p.drop_thresh) { FB_LAUNCH2(IDX_, MODE_, true, grid_) } else { FB_LAUNCH2(IDX_, MODE_, false, grid_) }            \
   T2S_CHECK_LAUNCH("attn_bwd_fused (five-product kernel)");
