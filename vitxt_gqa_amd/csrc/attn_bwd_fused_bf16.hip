@@ -73,12 +73,15 @@ struct FbWork {
 #ifndef FB_DMA
 #define FB_DMA 1
 #endif
-// Hand-off: the predecessor's running sum of tile t+1 is fetched by LDS-DMA into a 16 KB LDS region at the END of tile t (its flag was
-// checked one tile ahead), lands under phase A of tile t+1 and is read back from LDS behind phase B - instead of four register loads
-// issued ahead of phase B, whose memory latency phase B alone does not cover (profiles/r04_handoff_ablation.txt: ~2.5 % of the kernel).
-// -DFB_HO_PREFETCH=0: the register form.
+// Hand-off experiment, built and measured, NOT shipped (-DFB_HO_PREFETCH=1; needs FB_DMA): the predecessor's running sum of tile t+1
+// fetched by LDS-DMA into a 16 KB LDS region at the END of tile t (its flag checked one tile ahead), landing under phase A of tile t+1
+// and read back from LDS behind phase B - instead of four register loads issued ahead of the barrier, whose memory latency phase B
+// alone does not quite cover (profiles/r04_handoff_ablation.txt: ~2.5 % of the kernel).  Correct (all fused tests green), and 2.5 - 4 %
+// SLOWER than the register loads (profiles/r04_handoff_prefetch_ab.txt: 23.72 vs 23.13 ms with dropout, 20.22 vs 19.46 without, B = 32):
+// four more DMA pieces per wave and tile cost more issue time than the latency they hide (MI355X_MICROARCH.md prices a piece at 60 - 185
+// cycles inside a busy phase), and the look-ahead poll needs the predecessor 2.3 instead of 1.3 tiles ahead.
 #ifndef FB_HO_PREFETCH
-#define FB_HO_PREFETCH FB_DMA
+#define FB_HO_PREFETCH 0
 #endif
 // The DMA is issued through inline asm: told about an LDS-DMA builtin, the compiler orders every later LDS read whose address it cannot
 // prove disjoint (the stage buffer index is a run-time value) behind it with an s_waitcnt vmcnt(0) - in the middle of phase A, a
