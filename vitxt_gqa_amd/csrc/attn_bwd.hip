@@ -103,7 +103,9 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   }
   const int qdec = qrow - p.dec_q0;
   const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
-  const uint32_t rk2 = DROP ? attn_drop_rowkey16(salt, qr) * 0x10001u : 0u;      // this lane's row key in both 16-bit halves
+  const uint32_t rh = DROP ? attn_drop_rowhash(salt, qr) : 0u;                   // this lane's row hash; its row key of a tile's key window in
+  uint32_t rk2 = 0;                                                              // both 16-bit halves is derived per tile (DQ_ROWKEY)
+#define DQ_ROWKEY(t_) if (DROP) rk2 = attn_drop_rowkey16w(rh, ((t_) * BK) / ATTN_DROP_KWIN) * 0x10001u;
   const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
   const uint32_t inv_bits = __builtin_bit_cast(uint32_t, p.drop_inv);
   uint32_t ckreg = 0;
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     for (int t = t0; t < t1; ++t) {
       const int buf = t & 1;
+      DQ_ROWKEY(t);                                      // row key of this tile's key window
       STAGE_LOAD_ROWS();                                 // tile t+1 (past the end: clamped copies, harmless)
       IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
       CK_LOAD(t + 1);
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_f32_kernel(AttnParams p) {
       if (p.drop_thresh) {
         int qg = qt * 32 + qi;
         qg = qg < p.Lq ? qg : p.Lq - 1;
-        keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg), attn_drop_colkey16(salt, kpos), p.drop_thresh);
+        keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg, kpos / ATTN_DROP_KWIN), attn_drop_colkey16(salt, kpos), p.drop_thresh);
         dpv = keep ? dpv * p.drop_inv : 0.f;
       }
       dpacc[r] = pv * (dpv - del_s[qi]);       // dS uses the UNdropped probability
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_f32_kernel(AttnParams p) {
   const float c = p.scale * LOG2E;
   const int qdec = qrow - p.dec_q0;
   const uint32_t salt = attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h));
-  const uint32_t rk = attn_drop_rowkey16(salt, qr);
+  const uint32_t rh = attn_drop_rowhash(salt, qr);
   const int sr = tid >> 4, sc = tid & 15;
   f32x16 dqacc[2];
 #pragma unroll
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_f32_kernel(AttnParams p) {
         const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
         const float pv = ok ? fast_exp2(sacc[kbk][r] * c - lse2) : 0.f;
         float dpv = dpacc[kbk][r];
-        if (p.drop_thresh) dpv = attn_drop_keep16(rk, attn_drop_colkey16(salt, pos), p.drop_thresh) ? dpv * p.drop_inv : 0.f;
+        if (p.drop_thresh) dpv = attn_drop_keep16(attn_drop_rowkey16w(rh, pos / ATTN_DROP_KWIN), attn_drop_colkey16(salt, pos), p.drop_thresh) ? dpv * p.drop_inv : 0.f;
         dpacc[kbk][r] = pv * (dpv - del);
       }
 #pragma unroll

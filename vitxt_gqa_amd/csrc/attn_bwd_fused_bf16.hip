@@ -31,6 +31,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int FB_KB = 3;                          // 32-key blocks per wave
 constexpr int FB_WKEYS = 32 * FB_KB;              // 96 keys per wave
 constexpr int FB_KEYS = 4 * FB_WKEYS;             // 384 keys per workgroup
+static_assert(FB_KEYS == ATTN_DROP_KWIN, "a fused key block is one row-key window of the dropout mask");
 constexpr int FB_QROWS = 64;
 constexpr int FB_TILE = FB_QROWS * 128;           // bytes of a 64-row bf16 tile
 constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + (FB_QROWS / 2) * 4;   // Q | dO | -lse*log2e | -delta | dropout row keys (pairs)
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     if (wave_s == 1) fb_dma4(rs_nd, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE + FB_QROWS * 4), lane * 4, ld_row0 * 4);    \
     if (DROP && tid < FB_QROWS / 2) {                                                           \
       const int qa_ = ld_row0 + 2 * tid, qb2_ = qa_ + 1;                                        \
-      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1) << 16); \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kbw) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1, kbw) << 16); /* window = this key block */ \
     }                                                                                           \
     ld_row0 += FB_QROWS;                                                                        \
   }
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     lreg = LSE[r2c_]; dreg = DELTA[r2c_];       /* raw: arithmetic on them HERE would make the wave wait for the loads here */  \
     if (DROP && tid < FB_QROWS / 2) {                                                           \
       const int qa_ = ld_row0 + 2 * tid, qb2_ = qa_ + 1;                                        \
-      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1) << 16); \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kbw) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1, kbw) << 16); /* window = this key block */ \
     }                                                                                           \
     qo0 += q_step; oo0 += o_step; qo1 += q_step; oo1 += o_step;                                 \
     ld_row += FB_QROWS; ld_row0 += FB_QROWS;                                                    \
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
               for (int r = 0; r < 16; ++r) {
                 int qg = qt * FB_QROWS + sb * 32 + acc_row(r, lh);
                 qg = qg < p.Lq ? qg : p.Lq - 1;
-                const bool keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg), ck16, p.drop_thresh);
+                const bool keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg, kbw), ck16, p.drop_thresh);
                 // the chain was seeded with -delta: dP' = dP - delta;  dS = P (keep ? dP / (1-p) : 0) - P delta
                 const float nd = del_s[sb * 32 + acc_row(r, lh)];
                 dpacc[r] = sacc[r] * ((keep ? (dpacc[r] - nd) * drop_inv : 0.f) + nd);

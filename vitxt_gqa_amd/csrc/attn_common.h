@@ -45,7 +45,14 @@ struct AttnParams {
 // independent and uniform over keys (colkey16 independent uniform odd values) and vice versa.  NOT the reference's i.i.d.
 // Philox draw: two rows are related by t2 = (rk2 / rk1) t1, a multiplicative scramble; rows share a mask only if their keys
 // collide (2^-15 per pair) and are visibly correlated only for a handful of special key ratios (1, -1, small odd numbers and
-// their inverses).  (The first form of this function, (rowkey ^ colkey) * 0x9E37, cost one instruction more per pair and left
+// their inverses).
+// Round 4: the ROW key is a function of (row, key WINDOW): a window = ATTN_DROP_KWIN = 384 consecutive key-list positions, and
+// rowkey16w(h, w) = high 16 bits of h * ((2 w + 1) * 0x9E3779B1) | 1 with h the row's 32-bit hash.  With ONE 16-bit key per row, 1 100 -
+// 1 600 of the 51 M row pairs of a (sample, head) at L = 10 132 drew the same key and with it the same mask over ALL keys (a quarter
+// of the rows had such a twin: tests/test_dropout_gpu.py).  Now two rows collide per window (independently, 2^-15 each): a pair
+// shares its mask over 384 keys of 10 132 at most, never everywhere.  Cost: none in the key-stationary kernels (a workgroup's keys lie
+// in one window: 384 is the fused kernel's block, three of the dK/dV kernel's), one multiply + shift + or per 64-key tile and query
+// block in the query-stationary ones.  (The first form of this function, (rowkey ^ colkey) * 0x9E37, cost one instruction more per pair and left
 // 0.8 % of the row pairs correlated beyond 6.5 sigma: tests/test_dropout_gpu.py measures both properties.)
 __device__ __forceinline__ uint32_t attn_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -55,14 +62,20 @@ __device__ __forceinline__ uint32_t attn_drop_salt(uint32_t seed_lo, uint32_t se
   return attn_hash32(seed_lo ^ attn_hash32(seed_hi ^ (bh * 0x9E3779B1u)));
 }
 #ifdef T2S_ABL_NOHASH   // timing-only ablation (tools/ablate): key generation without its cost; never defined in a product build
-__device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q) { return ((salt + (uint32_t)q) & 0xFFFFu) | 1u; }
+__device__ __forceinline__ uint32_t attn_drop_rowhash(uint32_t salt, int q) { return salt + (uint32_t)q; }
+__device__ __forceinline__ uint32_t attn_drop_rowkey16w(uint32_t rowhash, int kwin) { return ((rowhash + (uint32_t)kwin) & 0xFFFFu) | 1u; }
 __device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) { return ((salt ^ (uint32_t)kpos) & 0xFFFFu) | 1u; }
 #else
-__device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q) { return (attn_hash32(salt + (uint32_t)q * 0x85EBCA6Bu) >> 16) | 1u; }
+__device__ __forceinline__ uint32_t attn_drop_rowhash(uint32_t salt, int q) { return attn_hash32(salt + (uint32_t)q * 0x85EBCA6Bu); }
+__device__ __forceinline__ uint32_t attn_drop_rowkey16w(uint32_t rowhash, int kwin) {
+  return ((rowhash * ((2u * (uint32_t)kwin + 1u) * 0x9E3779B1u)) >> 16) | 1u;
+}
 __device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) {
   return (attn_hash32((salt ^ 0xC2B2AE35u) + (uint32_t)kpos * 0x27D4EB2Fu) >> 16) | 1u;
 }
 #endif
+constexpr int ATTN_DROP_KWIN = 384;          // key-list positions per row-key window (the fused backward's key block)
+__device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q, int kwin) { return attn_drop_rowkey16w(attn_drop_rowhash(salt, q), kwin); }
 // generic per-element form (fp32 kernels, mask export).  The 16-bit product is read as a SIGNED number and compared with
 // thresh - 32768: the same drop probability thresh / 65536 as an unsigned 16-bit compare, without the flip of the top
 // bit the unsigned form needs before a signed saturating subtract (one VALU instruction per score pair in VALU-bound loops).

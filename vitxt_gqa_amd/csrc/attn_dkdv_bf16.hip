@@ -118,7 +118,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_dkdv_bf16_kernel(AttnParams p
     lreg = LSE[r2c_]; dreg = DELTA[r2c_];       /* raw: arithmetic on them HERE would make the wave wait for the loads here */  \
     if (DROP && tid < QROWS / 2) {                                                              \
       const int qa_ = ld_row0 + 2 * tid, qb_ = qa_ + 1;                                         \
-      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1) | (attn_drop_rowkey16(salt, qb_ < p.Lq ? qb_ : p.Lq - 1) << 16); \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kp0 / ATTN_DROP_KWIN) |                                            \
+              (attn_drop_rowkey16(salt, qb_ < p.Lq ? qb_ : p.Lq - 1, kp0 / ATTN_DROP_KWIN) << 16);       /* (the block's keys lie in one window) */ \
     }                                                                                           \
     qo0 += q_step; oo0 += o_step; qo1 += q_step; oo1 += o_step;                                 \
     ld_row += QROWS; ld_row0 += QROWS;                                                          \

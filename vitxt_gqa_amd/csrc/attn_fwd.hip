@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnParams p) {
     for (int t = 0; t < 32; ++t) qf[t] = qp[2 * t];
   }
   const uint32_t salt = attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h));
-  const uint32_t rk = attn_drop_rowkey16(salt, qrc);
+  const uint32_t rh = attn_drop_rowhash(salt, qrc);
   f32x16 oacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const float pv = fast_exp2(sacc[kbk][r] * c - mc);
         lsum += pv;                                        // the normaliser sums the UNdropped probabilities
-        const bool keep = !p.drop_thresh || attn_drop_keep16(rk, attn_drop_colkey16(salt, t * BK + kbk * 32 + acc_row(r, lh)), p.drop_thresh);
+        const int kp_ = t * BK + kbk * 32 + acc_row(r, lh);
+        const bool keep = !p.drop_thresh || attn_drop_keep16(attn_drop_rowkey16w(rh, kp_ / ATTN_DROP_KWIN), attn_drop_colkey16(salt, kp_), p.drop_thresh);
         sacc[kbk][r] = keep ? pv : 0.f;
       }
     l_run = l_run * alpha + lsum;
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(256) void attn_drop_mask_kernel(uint8_t* __restrict
                                                             int Lk, uint32_t thresh) {
   const int b = blockIdx.z, h = blockIdx.y, q = blockIdx.x;
   const uint32_t salt = attn_drop_salt(seed_lo, seed_hi, (uint32_t)(b * H + h));
-  const uint32_t rk = attn_drop_rowkey16(salt, q);
+  const uint32_t rh = attn_drop_rowhash(salt, q);
   for (int k = threadIdx.x; k < Lk; k += 256)
-    out[(((int64_t)b * H + h) * Lq + q) * Lk + k] = attn_drop_keep16(rk, attn_drop_colkey16(salt, k), thresh) ? 1 : 0;
+    out[(((int64_t)b * H + h) * Lq + q) * Lk + k] = attn_drop_keep16(attn_drop_rowkey16w(rh, k / ATTN_DROP_KWIN), attn_drop_colkey16(salt, k), thresh) ? 1 : 0;
 }
 
 int check_common(const AttnParams& p, int dtype) {

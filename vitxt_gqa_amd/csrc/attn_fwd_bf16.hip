@@ -98,13 +98,13 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
 
   // Q -> LDS, pre-scaled: lane (q = lr, half lh) owns c * Q[q][16s + 8lh .. +7] and is the only reader of what it wrote
   int qdec[QB];             // decoder step of the lane's query row (negative: not a decoder row)
-  uint32_t rk2[QB];            // dropout: the lane's row key in both 16-bit halves
+  uint32_t rk2[QB], rh[QB];    // dropout: the lane's row key of the current key window in both 16-bit halves; its 32-bit row hash
   const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int qrow = q0 + qb * 32 + lr;
     const int qr = qrow < p.Lq ? qrow : p.Lq - 1;
-    if (DROP) rk2[qb] = attn_drop_rowkey16(salt, qr) * 0x10001u;
+    if (DROP) { rh[qb] = attn_drop_rowhash(salt, qr); rk2[qb] = 0; }
     const bf16_t* qp = Q + (int64_t)qr * p.q_rs + 8 * lh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -213,6 +213,10 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
   const int ngen = ntiles > 0 ? 1 + (ntiles - nedge0) : 0;
   for (int g = 0; g < ngen; ++g) {
     const int t = g == 0 ? 0 : nedge0 + g - 1;
+    if (DROP) {                                         // row keys of this tile's key window (a 64-key tile lies inside one 384-key window)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) rk2[qb] = attn_drop_rowkey16w(rh[qb], (t * BK) / ATTN_DROP_KWIN) * 0x10001u;
+    }
     __syncthreads();
     STAGE_LOAD(t);
     CK_LOAD(t);
@@ -302,6 +306,10 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
       IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
       CK_LOAD(t + 1);
       const int kb = buf * 2 * TILE_BYTES, vb = kb + TILE_BYTES;
+      if (DROP) {                                       // (one multiply + shift + or per query block and tile)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) rk2[qb] = attn_drop_rowkey16w(rh[qb], (t * BK) / ATTN_DROP_KWIN) * 0x10001u;
+      }
       float lsum[QB];
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) lsum[qb] = 0.f;
@@ -422,7 +430,7 @@ void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st) {
   // The repair launch below is this file's either way.
   const char* pw_env = getenv("T2S_ATTN_FWD_PW");
   const bool use_pw = pw_env && pw_env[0] == '1';
-  if (use_pw && p.Lq > 256 && launch_attn_fwd_pw_bf16(p, st) == 0) {
+  if (use_pw && p.Lq > 256 && !p.drop_thresh && launch_attn_fwd_pw_bf16(p, st) == 0) {      // (without dropout only: round 4's windowed row keys are not in that pipeline)
   } else if (p.drop_thresh) launch_fwd<true, false>(p, st);
   else launch_fwd<false, false>(p, st);
   // The steady-state loop exists only when some sample can have more than one whole tile of prefix keys; only then can

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pw_bf16_kernel(AttnParams p) 
   for (int qb = 0; qb < 2; ++qb) {
     const int qrow = q0 + qb * 32 + lr;
     const int qr = qrow < p.Lq ? qrow : p.Lq - 1;
-    rk2[qb] = DROP ? attn_drop_rowkey16(salt, qr) * 0x10001u : 0u;
+    rk2[qb] = DROP ? attn_drop_rowkey16(salt, qr, 0) * 0x10001u : 0u;      // (launch_attn_fwd_pw_bf16 declines dropout launches since round 4: the
+                                                                           //  row key changes per 384-key window, which this pipeline does not do)
     const bf16_t* qp = Q + (int64_t)qr * p.q_rs + 8 * lh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
