@@ -617,7 +617,9 @@ def test_ocr_encoding_tail_matches_the_framework_ops(dtype, tol, drop_p):
 @pytest.mark.parametrize("B,L1,n_dec,keep", [(1, 515, 12, 1.0), (2, 1400, 12, 0.7), (1, 300, 0, 0.9)])
 def test_attention_fwd_one_wave_per_simd_variant(B, L1, n_dec, keep, drop_p, monkeypatch):
     """The opt-in forward kernel of csrc/attn_fwd_pw_bf16.hip (T2S_ATTN_FWD_PW=1; slower than the shipped one, kept for A/B
-    runs) computes the same attention: same dropout mask, so the two outputs differ by bf16 roundings only."""
+    runs) computes the same attention: the two outputs differ by bf16 roundings only.  (Since round 4 it declines launches with
+    attention dropout - the row key of the mask changes per 384-key window, which its pipeline does not do - and the shipped kernel
+    runs instead: the dropout cases then compare the shipped kernel with itself.)"""
     _need_gpu()
     from vitxt_gqa_amd import ops
     g = torch.Generator(device="cpu").manual_seed(77 + L1)

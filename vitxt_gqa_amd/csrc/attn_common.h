@@ -47,7 +47,7 @@ struct AttnParams {
 // collide (2^-15 per pair) and are visibly correlated only for a handful of special key ratios (1, -1, small odd numbers and
 // their inverses).
 // Round 4: the ROW key is a function of (row, key WINDOW): a window = ATTN_DROP_KWIN = 384 consecutive key-list positions, and
-// rowkey16w(h, w) = high 16 bits of h * ((2 w + 1) * 0x9E3779B1) | 1 with h the row's 32-bit hash.  With ONE 16-bit key per row, 1 100 -
+// rowkey16w(h, w) = high 16 bits of h * (odd 32-bit hash of w) | 1 with h the row's 32-bit hash.  With ONE 16-bit key per row, 1 100 -
 // 1 600 of the 51 M row pairs of a (sample, head) at L = 10 132 drew the same key and with it the same mask over ALL keys (a quarter
 // of the rows had such a twin: tests/test_dropout_gpu.py).  Now two rows collide per window (independently, 2^-15 each): a pair
 // shares its mask over 384 keys of 10 132 at most, never everywhere.  Cost: none in the key-stationary kernels (a workgroup's keys lie
@@ -67,8 +67,11 @@ __device__ __forceinline__ uint32_t attn_drop_rowkey16w(uint32_t rowhash, int kw
 __device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) { return ((salt ^ (uint32_t)kpos) & 0xFFFFu) | 1u; }
 #else
 __device__ __forceinline__ uint32_t attn_drop_rowhash(uint32_t salt, int q) { return attn_hash32(salt + (uint32_t)q * 0x85EBCA6Bu); }
+// (the window multiplier is itself a HASH of the window index, a wave-uniform scalar computation: with small odd multiples
+//  (2 w + 1) c of one constant, two rows whose hashes differ by d with d c mod 2^32 small collided in EVERY window at once - 4 identical
+//  row pairs at L = 2 048 in the first form of this function, against 0 expected)
 __device__ __forceinline__ uint32_t attn_drop_rowkey16w(uint32_t rowhash, int kwin) {
-  return ((rowhash * ((2u * (uint32_t)kwin + 1u) * 0x9E3779B1u)) >> 16) | 1u;
+  return ((rowhash * (attn_hash32((uint32_t)kwin * 0x9E3779B1u + 0x5bd1e995u) | 1u)) >> 16) | 1u;
 }
 __device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) {
   return (attn_hash32((salt ^ 0xC2B2AE35u) + (uint32_t)kpos * 0x27D4EB2Fu) >> 16) | 1u;
