@@ -145,8 +145,8 @@ def test_attention_dropout_mask_statistics():
     # that structure does and does not do, measured on a long sequence: the PAIRS of rows (and of columns) are uncorrelated - mean
     # pairwise correlation ~ 0, all but a fraction of a percent of the pairs inside 6.5 sigma of sampling noise.  Since round 4 the row
     # key changes with every 384-key window, so two rows whose keys collide in one window (2^-15 per pair and window) share 384 keys'
-    # worth of mask, not all of it: NO identical row pairs any more (there were ~L^2 / 2^16 of them with one key per row).  Columns
-    # whose 16-bit keys collide (2^-15 per pair) still share their mask over all rows.
+    # worth of mask, not all of it: NO identical row pairs any more (there were ~L^2 / 2^16 of them with one key per row).  The column
+    # key changes with every 256-row window of queries in the same way: no identical column pairs either (9 at Lk = 2 048 before).
     Lq = Lk = 2048
     big = ops.attn_dropout_mask(1, Lq, Lk, 0.1, 7, DEV)[0, 0].float()          # one (sample, head): [Lq, Lk]
     z = (big - big.mean()) / big.std()
@@ -161,10 +161,11 @@ def test_attention_dropout_mask_statistics():
     coff = ccorr - torch.diag(torch.diag(ccorr))
     crest = coff[coff < 0.999]
     assert abs(crest.mean().item()) < 2e-3 and (crest.abs() > 6.5 * sig).float().mean().item() < 2e-3
-    csame = int((coff > 0.999).sum().item()) // 2                           # identical COLUMNS = colliding column keys: still ~Lk^2 / 2^16
-    assert csame <= 10 + 4 * Lk * Lk / 2 ** 16
-    print("dropout mask at L=2048: %d identical row pairs, %d identical column pairs (~%.0f expected from 15-bit column keys); other row pairs: "
-          "%.4f %% beyond 6.5 sigma, max |corr| %.3f" % (same, csame, Lk * Lk / 2 ** 16, 100 * (rest.abs() > 6.5 * sig).float().mean().item(), rest.abs().max().item()))
+    csame = int((coff > 0.999).sum().item()) // 2                           # identical COLUMNS: none since the column key is per row window
+    assert csame == 0
+    print("dropout mask at L=2048: %d identical row pairs, %d identical column pairs; other row pairs: %.4f %% beyond 6.5 sigma, max |corr| %.3f; "
+          "column pairs: %.4f %% beyond 6.5 sigma, max |corr| %.3f" % (same, csame, 100 * (rest.abs() > 6.5 * sig).float().mean().item(), rest.abs().max().item(),
+                                                                         100 * (crest.abs() > 6.5 * sig).float().mean().item(), crest.abs().max().item()))
     del big, z, corr, off, rest, ccorr, coff, crest
     # The same at the BENCHMARK's length: L = 10 132 query rows x 10 132 key-list positions of one (sample, head).  With one
     # 16-bit key per row (rounds 1-3) this counted 1 098 identical row pairs - 1 872 of the 10 132 rows had a twin with the SAME mask over
@@ -183,8 +184,13 @@ def test_attention_dropout_mask_statistics():
     outl = (corr.abs() > 6.5 * sig).float().mean().item()
     assert same == 0 and strong == 0, (same, strong)
     assert outl < 2e-3
-    print("dropout mask at L=10132: %d identical row pairs, %d with |correlation| > 0.5, max |correlation| %.3f; pairs beyond 6.5 sigma: %.4f %%"
-          % (same, strong, corr.abs().max().item(), 100 * outl))
+    ccorr = (z.t() @ z).float() / Lb                                        # the same over the 51 M column pairs
+    ccorr.fill_diagonal_(0)
+    csame, cstrong = int((ccorr > 0.9).sum().item()) // 2, int((ccorr.abs() > 0.5).sum().item()) // 2
+    coutl = (ccorr.abs() > 6.5 * sig).float().mean().item()
+    assert csame == 0 and cstrong == 0 and coutl < 2e-3, (csame, cstrong, coutl)
+    print("dropout mask at L=10132: %d identical row pairs, %d with |correlation| > 0.5, max |correlation| %.3f; pairs beyond 6.5 sigma: %.4f %%; "
+          "columns: %d identical, max |correlation| %.3f, beyond 6.5 sigma %.4f %%" % (same, strong, corr.abs().max().item(), 100 * outl, csame, ccorr.abs().max().item(), 100 * coutl))
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])

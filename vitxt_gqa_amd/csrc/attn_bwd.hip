@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
 #define CK_LOAD(t_)                                                                                 \
   if (DROP && tid < 32) {                                                                           \
     const int kp_ = (t_) * BK + 2 * tid;                                                            \
-    ckreg = attn_drop_colkey16(salt, kp_) | (attn_drop_colkey16(salt, kp_ + 1) << 16);              \
+    ckreg = attn_drop_colkey16(salt, kp_, (qblk * 128) / ATTN_DROP_QWIN) | (attn_drop_colkey16(salt, kp_ + 1, (qblk * 128) / ATTN_DROP_QWIN) << 16); \
   }
 
   int ka[4];                 // row fragment: row lr, chunk 2s + lh
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkdv_f32_kernel(AttnParams p) {
       if (p.drop_thresh) {
         int qg = qt * 32 + qi;
         qg = qg < p.Lq ? qg : p.Lq - 1;
-        keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg, kpos / ATTN_DROP_KWIN), attn_drop_colkey16(salt, kpos), p.drop_thresh);
+        keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg, kpos / ATTN_DROP_KWIN), attn_drop_colkey16(salt, kpos, qg / ATTN_DROP_QWIN), p.drop_thresh);
         dpv = keep ? dpv * p.drop_inv : 0.f;
       }
       dpacc[r] = pv * (dpv - del_s[qi]);       // dS uses the UNdropped probability
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq_f32_kernel(AttnParams p) {
         const bool ok = pos < nk && (pos < n_prefix || qdec >= pos - n_prefix);
         const float pv = ok ? fast_exp2(sacc[kbk][r] * c - lse2) : 0.f;
         float dpv = dpacc[kbk][r];
-        if (p.drop_thresh) dpv = attn_drop_keep16(attn_drop_rowkey16w(rh, pos / ATTN_DROP_KWIN), attn_drop_colkey16(salt, pos), p.drop_thresh) ? dpv * p.drop_inv : 0.f;
+        if (p.drop_thresh) dpv = attn_drop_keep16(attn_drop_rowkey16w(rh, pos / ATTN_DROP_KWIN), attn_drop_colkey16(salt, pos, qr / ATTN_DROP_QWIN), p.drop_thresh) ? dpv * p.drop_inv : 0.f;
         dpacc[kbk][r] = pv * (dpv - del);
       }
 #pragma unroll

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
     uint32_t ck2[FB_KB];
 #pragma unroll
-    for (int kb = 0; kb < FB_KB; ++kb) ck2[kb] = DROP ? attn_drop_colkey16(salt, kp0 + wave * FB_WKEYS + kb * 32 + lr) * 0x10001u : 0u;
+    for (int kb = 0; kb < FB_KB; ++kb) ck2[kb] = 0u;         // (set per 256-row window of query rows at the top of every fourth tile)
     const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
     const float drop_inv = p.drop_inv;
     uint32_t rkreg = 0;
@@ -565,6 +565,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #endif
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
+      if (DROP && (qt & (ATTN_DROP_QWIN / FB_QROWS - 1)) == 0) {      // a new 256-row window of query rows: re-hash this lane's three column keys
+#pragma unroll
+        for (int kb = 0; kb < FB_KB; ++kb)
+          ck2[kb] = attn_drop_colkey16(salt, kp0 + wave * FB_WKEYS + kb * 32 + lr, (qt * FB_QROWS) / ATTN_DROP_QWIN) * 0x10001u;
+      }
       // hand-off: how far the predecessor has published this tile's running sum - asked now, looked at at the end of phase A
       unsigned fv = 0;
       // (prefetch form: the flag of the NEXT tile, whose sum is fetched at the end of this one)

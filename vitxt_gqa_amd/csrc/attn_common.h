@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t attn_drop_salt(uint32_t seed_lo, uint32_t se
 #ifdef T2S_ABL_NOHASH   // timing-only ablation (tools/ablate): key generation without its cost; never defined in a product build
 __device__ __forceinline__ uint32_t attn_drop_rowhash(uint32_t salt, int q) { return salt + (uint32_t)q; }
 __device__ __forceinline__ uint32_t attn_drop_rowkey16w(uint32_t rowhash, int kwin) { return ((rowhash + (uint32_t)kwin) & 0xFFFFu) | 1u; }
-__device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) { return ((salt ^ (uint32_t)kpos) & 0xFFFFu) | 1u; }
+__device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos, int qwin) { return ((salt ^ (uint32_t)(kpos + qwin)) & 0xFFFFu) | 1u; }
 #else
 __device__ __forceinline__ uint32_t attn_drop_rowhash(uint32_t salt, int q) { return attn_hash32(salt + (uint32_t)q * 0x85EBCA6Bu); }
 // (the window multiplier is itself a HASH of the window index, a wave-uniform scalar computation: with small odd multiples
@@ -73,11 +73,17 @@ __device__ __forceinline__ uint32_t attn_drop_rowhash(uint32_t salt, int q) { re
 __device__ __forceinline__ uint32_t attn_drop_rowkey16w(uint32_t rowhash, int kwin) {
   return ((rowhash * (attn_hash32((uint32_t)kwin * 0x9E3779B1u + 0x5bd1e995u) | 1u)) >> 16) | 1u;
 }
-__device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos) {
-  return (attn_hash32((salt ^ 0xC2B2AE35u) + (uint32_t)kpos * 0x27D4EB2Fu) >> 16) | 1u;
+// ... and, symmetrically, the COLUMN key is per (key-list position, ROW window of ATTN_DROP_QWIN = 256 query rows): two keys whose
+// column keys collide are dropped together for 256 queries, not for every query of the head.  Free in the query-stationary kernels
+// (a workgroup's 128 or 256 query rows lie in one window: the staged keys are hashed with it), a re-hash of the lane's keys every
+// fourth 64-row tile in the key-stationary ones.
+__device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos, int qwin) {
+  const uint32_t ch = attn_hash32((salt ^ 0xC2B2AE35u) + (uint32_t)kpos * 0x27D4EB2Fu);
+  return ((ch * (attn_hash32((uint32_t)qwin * 0x85EBCA6Bu + 0x1b873593u) | 1u)) >> 16) | 1u;
 }
 #endif
 constexpr int ATTN_DROP_KWIN = 384;          // key-list positions per row-key window (the fused backward's key block)
+constexpr int ATTN_DROP_QWIN = 256;          // query rows per column-key window (the forward's workgroup)
 __device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q, int kwin) { return attn_drop_rowkey16w(attn_drop_rowhash(salt, q), kwin); }
 // generic per-element form (fp32 kernels, mask export).  The 16-bit product is read as a SIGNED number and compared with
 // thresh - 32768: the same drop probability thresh / 65536 as an unsigned 16-bit compare, without the flip of the top

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_kernel(AttnParams p) {
         const float pv = fast_exp2(sacc[kbk][r] * c - mc);
         lsum += pv;                                        // the normaliser sums the UNdropped probabilities
         const int kp_ = t * BK + kbk * 32 + acc_row(r, lh);
-        const bool keep = !p.drop_thresh || attn_drop_keep16(attn_drop_rowkey16w(rh, kp_ / ATTN_DROP_KWIN), attn_drop_colkey16(salt, kp_), p.drop_thresh);
+        const bool keep = !p.drop_thresh || attn_drop_keep16(attn_drop_rowkey16w(rh, kp_ / ATTN_DROP_KWIN), attn_drop_colkey16(salt, kp_, qrc / ATTN_DROP_QWIN), p.drop_thresh);
         sacc[kbk][r] = keep ? pv : 0.f;
       }
     l_run = l_run * alpha + lsum;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_drop_mask_kernel(uint8_t* __restrict
   const uint32_t salt = attn_drop_salt(seed_lo, seed_hi, (uint32_t)(b * H + h));
   const uint32_t rh = attn_drop_rowhash(salt, q);
   for (int k = threadIdx.x; k < Lk; k += 256)
-    out[(((int64_t)b * H + h) * Lq + q) * Lk + k] = attn_drop_keep16(attn_drop_rowkey16w(rh, k / ATTN_DROP_KWIN), attn_drop_colkey16(salt, k), thresh) ? 1 : 0;
+    out[(((int64_t)b * H + h) * Lq + q) * Lk + k] = attn_drop_keep16(attn_drop_rowkey16w(rh, k / ATTN_DROP_KWIN), attn_drop_colkey16(salt, k, q / ATTN_DROP_QWIN), thresh) ? 1 : 0;
 }
 
 int check_common(const AttnParams& p, int dtype) {

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
 #define CK_LOAD(t_)                                                                                 \
   if (DROP && tid < 32) {                                                                           \
     const int kp_ = (t_) * BK + 2 * tid;                                                            \
-    ckreg = attn_drop_colkey16(salt, kp_) | (attn_drop_colkey16(salt, kp_ + 1) << 16);              \
+    ckreg = attn_drop_colkey16(salt, kp_, (qblk * BQ) / ATTN_DROP_QWIN) | (attn_drop_colkey16(salt, kp_ + 1, (qblk * BQ) / ATTN_DROP_QWIN) << 16); /* (BQ divides the window) */ \
   }
   // key-list lookups run one tile ahead of the row loads that depend on them (otherwise every tile waits out a full
   // index-load latency before its K/V loads can even be issued)

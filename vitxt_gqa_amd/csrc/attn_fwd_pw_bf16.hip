@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pw_bf16_kernel(AttnParams p) 
     PW_G_LD1(kr0, vr0, 0); PW_G_LD1(kr1, vr1, 1);                                                   \
     if (DROP && tid < 32) {                                                                         \
       const int kp_ = gt_ * GK + 2 * tid;                                                           \
-      ckreg = attn_drop_colkey16(salt, kp_) | (attn_drop_colkey16(salt, kp_ + 1) << 16);            \
+      ckreg = attn_drop_colkey16(salt, kp_, 0) | (attn_drop_colkey16(salt, kp_ + 1, 0) << 16);            \
     }                                                                                               \
   }
 #define G_WRITE()        /* into buffer 0: K image at 0, V image at FT (first 64 rows of each) */                \
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pw_bf16_kernel(AttnParams p) 
 #define F_CK(u_)         /* column keys of the 64 key pairs of steady tile u_: threads 0..63 */                  \
   if (DROP && tid < 64) {                                                                           \
     const int kp_ = GK + (u_) * FK + 2 * tid;                                                       \
-    ckreg = attn_drop_colkey16(salt, kp_) | (attn_drop_colkey16(salt, kp_ + 1) << 16);              \
+    ckreg = attn_drop_colkey16(salt, kp_, 0) | (attn_drop_colkey16(salt, kp_ + 1, 0) << 16);              \
   }
 #define PW_F_WR1(kr_, vr_, i_)                                                                      \
   *reinterpret_cast<uint4*>(kb_ + tile_off(sr + 32 * (i_), sc)) = kr_;                              \
