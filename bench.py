@@ -454,6 +454,11 @@ def main():
         "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30, "recompute_activations": bool(recompute),
     }
     if not args.forward_only:
+        from vitxt_gqa_amd import ops as _ops
+        # how the fused attention backward sums dQ across key blocks, and the status word of its last call (0: no bounded spin of the
+        # hand-off ever timed out; read here, behind the timed region's synchronisation)
+        res["attn_bwd_dq"] = {"mode": "ordered hand-off (bit-reproducible)" if _ops.ATTN_BWD_DQ_MODE == 1 else "fp32 atomics",
+                              "status": _ops.fused_handoff_status()}
         res["loss"] = float(last.detach())
         # the loss of the FIRST executed step (warm-up or timed): a function of --seed, the name-seeded weights and the block-seeded
         # batch alone - tests/test_fullsize_gpu.py recomputes it at B=64
