@@ -34,6 +34,27 @@ constexpr int BK = 64;                     // keys per tile
 constexpr int TILE_BYTES = BK * 128;       // one 64-row bf16 tile image
 constexpr float BIG = 1.2089258e24f;       // 2^80
 
+// -DT2S_FWD_DMA=1 (experiment; default 0): the K / V tiles gathered by LDS-DMA (buffer_load ... lds with a per-lane SOURCE
+// address = the key-list row, the chunk swizzle on that address, one 1 KB piece = 8 rows per wave-instruction) instead of global -> VGPR ->
+// ds_write_b128.  Issued through inline asm for the reason given in attn_bwd_fused_bf16.hip (the compiler would drain the DMA before the
+// next LDS read it cannot prove disjoint); every wave waits for its own pieces ahead of the barrier that publishes the buffer.
+#ifndef T2S_FWD_DMA
+#define T2S_FWD_DMA 0
+#endif
+typedef uint32_t fwd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fwd_u32x4 fwd_rsrc_s(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  fwd_u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) & 0xffffu;
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void fwd_dma16(fwd_u32x4 rs, uint32_t lds, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rs) : "memory", "m0");
+}
+
 // experiment switches (tools/ablate/README.md): T2S_FWD_OCC = waves per SIMD the register budget is sized for,
 // T2S_FWD_QREG = keep the pre-scaled Q fragments in registers instead of re-reading them from LDS every tile
 #ifndef T2S_FWD_OCC
@@ -138,6 +159,25 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
     ri0 = USE_IDX ? (uint32_t)idx[p0_] : (uint32_t)p0_;                                             \
     ri1 = USE_IDX ? (uint32_t)idx[p1_] : (uint32_t)p1_;                                             \
   }
+#if T2S_FWD_DMA
+  // lane (sr, sc) of wave w = row 8 w + lane / 8, chunk POSITION lane % 8 of pieces w and w + 4 of the K and of the V tile: the position holds
+  // the logical chunk sc ^ tile_f(row) (tile_f is the same 32 rows further down), fetched from the lane's key-list row
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t dma_chunk = (uint32_t)((sc ^ tile_f(sr)) * 8);
+  const fwd_u32x4 rs_k = fwd_rsrc_s(K, (uint32_t)(((int64_t)(p.idx_cap > p.Lq ? p.idx_cap : p.Lq) * p.kv_rs) * 2)), rs_v = fwd_rsrc_s(V, (uint32_t)(((int64_t)(p.idx_cap > p.Lq ? p.idx_cap : p.Lq) * p.kv_rs) * 2));
+  const uint32_t smem_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  int dma_buf = 0;                     // the buffer the next STAGE_LOAD_ROWS fills (uniform)
+#define STAGE_LOAD_ROWS()                                                                           \
+  {                                                                                                 \
+    const uint32_t o0_ = (ri0 * (uint32_t)p.kv_rs + dma_chunk) * 2u;                                \
+    const uint32_t o1_ = (ri1 * (uint32_t)p.kv_rs + dma_chunk) * 2u;                                \
+    const uint32_t d_ = smem_lds + (uint32_t)(dma_buf * 2 * TILE_BYTES + wave_s * 1024);            \
+    fwd_dma16(rs_k, d_, o0_);                                                                       \
+    fwd_dma16(rs_v, d_ + TILE_BYTES, o0_);                                                          \
+    fwd_dma16(rs_k, d_ + 4096, o1_);                                                                \
+    fwd_dma16(rs_v, d_ + TILE_BYTES + 4096, o1_);                                                   \
+  }
+#else
 #define STAGE_LOAD_ROWS()                                                                           \
   {                                                                                                 \
     const uint32_t o0_ = (ri0 * (uint32_t)p.kv_rs + (uint32_t)sc * 8u) * 2u;                        \
@@ -147,11 +187,24 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
     kr1 = *reinterpret_cast<const uint4*>(K + o1_);                                                 \
     vr1 = *reinterpret_cast<const uint4*>(V + o1_);                                                 \
   }
+#endif
+#if T2S_FWD_DMA
+#define DMA_BUF(x_) dma_buf = (x_);
+#else
+#define DMA_BUF(x_)
+#endif
 #define STAGE_LOAD(t_)                                                                              \
   {                                                                                                 \
     IDX_LOAD(t_);                                                                                   \
     STAGE_LOAD_ROWS();                                                                              \
   }
+#if T2S_FWD_DMA
+#define STAGE_WRITE(buf_)      /* the pieces were aimed at dma_buf when they were issued: here they only have to have landed */  \
+  {                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+    if (DROP && tid < 32) ck_s[buf_][tid] = ckreg;                                                  \
+  }
+#else
 #define STAGE_WRITE(buf_)                                                                           \
   {                                                                                                 \
     char* kb_ = smem + (buf_) * 2 * TILE_BYTES + tile_off(sr, sc);                                  \
@@ -161,6 +214,7 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
     *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + 4096) = vr1;                                       \
     if (DROP && tid < 32) ck_s[buf_][tid] = ckreg;                                                  \
   }
+#endif
 
 #ifdef T2S_FWD_QREG
   bf16x8 qreg[QB][4];
@@ -218,6 +272,7 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
       for (int qb = 0; qb < QB; ++qb) rk2[qb] = attn_drop_rowkey16w(rh[qb], (t * BK) / ATTN_DROP_KWIN) * 0x10001u;
     }
     __syncthreads();
+    DMA_BUF(0);
     STAGE_LOAD(t);
     CK_LOAD(t);
     STAGE_WRITE(0);
@@ -284,6 +339,7 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
   // ---- steady state: tiles [1, nfast), K/V double-buffered in LDS
   if (nfast > 1) {
     __syncthreads();
+    DMA_BUF(1);
     STAGE_LOAD(1);
     CK_LOAD(1);
     STAGE_WRITE(1);
@@ -302,6 +358,7 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
   }
     for (int t = 1; t < nfast; ++t) {
       const int buf = t & 1;
+      DMA_BUF(buf ^ 1);
       STAGE_LOAD_ROWS();                                 // tile t+1 (after the last fast tile: an unused, harmless load)
       IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
       CK_LOAD(t + 1);
@@ -368,6 +425,7 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
 #undef IDX_LOAD
 #undef CK_LOAD
 #undef STAGE_WRITE
+#undef DMA_BUF
 
   // ---- epilogue: normalise, stage O through LDS (per-wave 32 x 64 tile, 144-B rows), store whole rows
   __syncthreads();
