@@ -37,10 +37,8 @@ o, lse = ops.attn_fwd(qkv, keys, **kw)
 for _ in range(3):
     ops.attn_bwd(qkv, o, dout, lse, keys, fused=True, **kw)
 torch.cuda.synchronize()
-# the stamps sit behind the fp32 dQ sums of the workspace: control block (64 words + one flag per (pair, tile), padded to 256 B) first
-nqt = (L + 63) // 64
-ctrl_floats = ((64 * 4 + B * 12 * nqt * 4 + 255) // 256 * 256) // 4 + 2 * B * 12 * nqt * 64          # + the two row-constant arrays
-d = ops._LAST_DQ32[ctrl_floats + B * L * 768:].view(torch.int64).view(-1, 8)[:256].cpu()
+# the stamps sit in the last 16 KB of the workspace (FbWork.dbg)
+d = ops._LAST_DQ32.view(torch.uint8)[-16384:].view(torch.int64).view(-1, 8)[:256].cpu()
 d = d[d[:, 6] > 0]
 names = ["phase A", "stage write", "barrier 1", "phase B", "atomics", "barrier 2"]
 if slots:

@@ -64,8 +64,15 @@ struct FbWork {
   unsigned* status;       // [4]: bit 0 of word 0 = a bounded spin timed out
   const float* nl;        // [B H][nqt * 64]: -lse * log2(e) per query row, -inf behind Lq (written by attn_delta_prep_kernel)
   const float* nd;        // [B H][nqt * 64]: -delta per query row, 0 behind Lq
+  unsigned long long* dbg; // the workspace's tail: diagnostic builds only (-DFB_STAMP: cycle stamps; -DFB_TIMELINE: one record per workgroup)
   int handoff;
 };
+// tail of the workspace for the diagnostic builds (tools/fused_stamps.py, tools/fused_timeline.py); a product build never writes it
+#ifdef FB_TIMELINE
+constexpr size_t FB_DBG_BYTES = 16384 + (size_t)131072 * 32;      // stamps of 256 workgroups + 32 B per workgroup of a launch
+#else
+constexpr size_t FB_DBG_BYTES = 16384;
+#endif
 // Staging of the Q / dO tiles and their row constants by LDS-DMA (buffer_load ... lds: 1 KB per wave-instruction = 8 rows x 128 B
 // straight into the swizzled tile image - the chunk swizzle is a permutation INSIDE a row, so it goes on the per-lane source address;
 // rows behind Lq are out-of-range records and read as zeros; the row constants arrive pre-scaled from the prep kernel).  Replaces
@@ -259,6 +266,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   char* const dsimg = kimg + FB_KIMG;              // [384 keys][64 q] bf16, same layout
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   float* __restrict__ const dq32 = w.part;         // (atomic form)
+#ifdef FB_TIMELINE   // diagnostic build only: when and where every workgroup ran (100 MHz real-time counter, HW_ID / XCC_ID)
+  const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int kblk, h, b;
   if constexpr (HO && !TAIL) {
     // ticket: this workgroup is the slot-th one of its XCD group to START (not the slot-th by id), see FbWork
@@ -992,7 +1002,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #define FB_STAMP_MODE 0      // which kernel of the launch records its stamps (0: full key blocks, 1: the edge blocks)
 #endif
     if ((MODE == FB_STAMP_MODE || (MODE == 3 && FB_STAMP_MODE == (EDGE ? 1 : 0))) && lane == 0 && wave == 0) {
-      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(dq32 + (int64_t)p.B * p.Lq * (p.H * 64)) + (int64_t)(blockIdx.x & 255) * 8;
+      unsigned long long* dbg = w.dbg + (int64_t)(blockIdx.x & 255) * 8;
       for (int k = 0; k < 6; ++k) dbg[k] = st_sum[k];
       dbg[6] = (unsigned long long)nqt;
       dbg[7] = ((st_t0 - st_c0) * 1000ull) / (__builtin_amdgcn_s_memrealtime() - st_r0 + 1);       // MHz / 100 * 1000
@@ -1037,6 +1047,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             *reinterpret_cast<bf16x4*>(dvp + d) = v4;
           }
       }
+#ifdef FB_TIMELINE
+    if (!TAIL && tid == 0 && blockIdx.x < 131072u) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+      unsigned long long* tl = w.dbg + 2048 + (size_t)blockIdx.x * 4;
+      tl[0] = tl_r0;
+      tl[1] = __builtin_amdgcn_s_memrealtime();
+      tl[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+      tl[3] = (unsigned long long)(unsigned)kbw | ((unsigned long long)(unsigned)b << 8) | ((unsigned long long)(unsigned)h << 24) |
+              ((unsigned long long)(unsigned)nkeys_wg << 32) | ((unsigned long long)(edge_wg ? 1u : 0u) << 48);
+    }
+#endif
     if (TAIL) __syncthreads();                               // the next key block rewrites the K image
   } while (TAIL && (++kbw) * FB_KEYS < nk);
 }
@@ -1109,7 +1131,7 @@ size_t attn_bwd_fused_workspace_bytes(int B, int H, int Lq) {
   const size_t ctrl = ((size_t)FB_CTRL_WORDS * 4 + (size_t)B * H * nqt * 4 + 255) / 256 * 256;
   const size_t rowc = 2 * (size_t)B * H * nqt * FB_QROWS * 4;            // -lse log2e and -delta per padded query row (LDS-DMA sources)
   const size_t sums = (size_t)B * H * nqt * (FB_QROWS * 64 * 4);        // >= B * Lq * H * 64 * 4, the atomic form's buffer
-  return ctrl + rowc + sums + 16384;                                     // + room for the diagnostic build's stamps
+  return ctrl + rowc + sums + FB_DBG_BYTES;                              // + room for the diagnostic builds' stamps
 }
 
 // Fused backward (bf16): delta + housekeeping, the 5-product kernel (+ its tail launch, see attn_dkdv_bf16.hip); dQ across key
@@ -1134,6 +1156,10 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   w.nd = nd;
   w.part = nd + rowc_n;
   w.handoff = handoff;
+  w.dbg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + attn_bwd_fused_workspace_bytes(p.B, p.H, p.Lq) - FB_DBG_BYTES);
+#if defined(FB_TIMELINE) || defined(FB_STAMP)
+  if (hipMemsetAsync(w.dbg, 0, FB_DBG_BYTES, st) != hipSuccess) return 3;
+#endif
   float* const dq32 = w.part;
   // > 64 KB of LDS per workgroup needs the opt-in; set on every call (idempotent, per device, no state of ours is kept)
 #define FB_K(I_, M_, D_) reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, true>)
