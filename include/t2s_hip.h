@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2S_ABI_VERSION 4
+#define T2S_ABI_VERSION 5
 #define T2S_F32 0
 #define T2S_BF16 1
 #define T2S_HEAD_DIM 64
@@ -148,6 +148,16 @@ int t2s_add_layernorm_fwd_nres(const void* x, const void* res_z, const float* re
                                const float* beta, void* y, void* y_lo, void* z_out, float* stats,
                                int64_t rows, float eps, int x_dtype, int stream_dtype, float drop_p,
                                uint64_t drop_seed, t2s_stream_t stream);
+
+/* Pre-LayerNorm residual block of the ViT frame-feature producer (tools/video_feat/obtain_vit_feat.py:37-53 runs transformers'
+ * ViTLayer: x = x + attn(LN(x)); x = x + mlp(LN(x)); final LayerNorm on the CLS row): in one pass over the rows of the fp32 stream
+ * h [rows, width] (row stride h_row_stride elements), h <- h + branch + bias (branch: [rows, width] GEMM output of branch_dtype,
+ * bias fp32 [width]; both may be NULL: plain LayerNorm, h untouched), then y = LN(h) * gamma + beta with biased variance and eps
+ * inside the sqrt, written as y_dtype (bf16: the next GEMM's operand; f32: the final LayerNorm).  width: a multiple of 4, at most
+ * 1280 (ViT-L: 1024). */
+int t2s_wide_add_layernorm_fwd(float* h, int64_t h_row_stride, const void* branch, int branch_dtype,
+                               const float* bias, const float* gamma, const float* beta, void* y,
+                               int y_dtype, int64_t rows, int width, float eps, t2s_stream_t stream);
 
 /* dz = LN backward wrt z (= grad of both x and res); dgamma_part/dbeta_part: [n_part, 768] fp32
  * partial sums (n_part = t2s_layernorm_bwd_parts(rows)); the caller reduces over dim 0.

@@ -16,6 +16,47 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
+@pytest.mark.parametrize("width", [128, 768, 1024, 1280])
+def test_wide_add_layernorm_kernel(width):
+    """t2s_wide_add_layernorm_fwd (the pre-LN block's residual update + next LayerNorm in one pass) against torch: the updated stream
+    bit for bit (same fp32 adds in the same order), the normalised rows within fp32 round-off / one bf16 ulp; plain LayerNorm form
+    (no branch) leaves the stream untouched; strided rows (the CLS rows of a [B, L, W] stream)."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from vitxt_gqa_amd.vit import add_layernorm
+    torch.manual_seed(width)
+    rows = 1001
+    h = torch.randn(rows, width, device="cuda") * 3 + 0.5
+    br = torch.randn(rows, width, device="cuda").to(torch.bfloat16)
+    bias, g, b = (torch.randn(width, device="cuda") for _ in range(3))
+    want_h = h + br.float() + bias
+    want = F.layer_norm(want_h, (width,), g, b, 1e-12)
+    h1 = h.clone()
+    y32 = add_layernorm(h1, br, bias, g, b, 1e-12, torch.float32)
+    assert torch.equal(h1, want_h)
+    assert (y32 - want).abs().max().item() < 2e-5
+    h2 = h.clone()
+    y16 = add_layernorm(h2, br, bias, g, b, 1e-12, torch.bfloat16)
+    assert torch.equal(h2, want_h) and y16.dtype == torch.bfloat16
+    assert (y16.float() - want).abs().max().item() <= 2 ** -7 * want.abs().max().item()
+    h3 = h.clone()
+    y = add_layernorm(h3, None, None, g, b, 1e-12, torch.float32)
+    assert torch.equal(h3, h) and (y - F.layer_norm(h, (width,), g, b, 1e-12)).abs().max().item() < 2e-5
+    # strided rows: row 0 of every sample of a [B, L, W] stream; the other rows stay as they were
+    s3 = torch.randn(5, 7, width, device="cuda")
+    keep = s3.clone()
+    brc = torch.randn(5, width, device="cuda").to(torch.bfloat16)
+    yc = add_layernorm(s3[:, 0], brc, bias, g, b, 1e-12, torch.float32)
+    assert torch.equal(s3[:, 1:], keep[:, 1:]) and torch.equal(s3[:, 0], keep[:, 0] + brc.float() + bias)
+    assert (yc - F.layer_norm(s3[:, 0], (width,), g, b, 1e-12)).abs().max().item() < 2e-5
+    # an fp32 branch (the fp32 operand mode of the producer)
+    h4 = h.clone()
+    y4 = add_layernorm(h4, br.float(), bias, g, b, 1e-12, torch.float32)
+    assert torch.equal(h4, want_h) and torch.equal(y4, y32)
+    with pytest.raises(RuntimeError, match="width"):
+        add_layernorm(torch.zeros(4, 2048, device="cuda"), None, None, torch.ones(2048, device="cuda"), torch.zeros(2048, device="cuda"), 1e-12, torch.float32)
+
+
 @pytest.mark.parametrize("hidden,heads,layers,ffn,img", [(128, 2, 2, 256, 32), (1024, 16, 2, 4096, 224)])
 def test_cls_features_match_hf_vit(hidden, heads, layers, ffn, img):
     _need_gpu()

@@ -49,6 +49,8 @@ ws = ops._LAST_DQ32
 tail_bytes = 16384 + 131072 * 32
 tl = ws.view(torch.uint8)[-tail_bytes + 16384:].view(torch.int64).view(-1, 4).cpu()
 tl = tl[tl[:, 1] > 0]
+allwg = tl
+tl = tl[tl[:, 3] >= 0]                                     # bit 63 marks a workgroup that had no key block to sweep (left at once)
 r0, r1 = tl[:, 0].double(), tl[:, 1].double()
 t0 = r0.min()
 r0, r1 = (r0 - t0) / 100.0, (r1 - t0) / 100.0             # microseconds
@@ -91,3 +93,33 @@ print("gap on a CU between two consecutive workgroups: median %.1f us, p90 %.1f,
 pc = torch.tensor(per_cu)
 print("busy time per CU / span: min %.3f, median %.3f, max %.3f" % (pc.min().item() / span, pc.median().item() / span, pc.max().item() / span))
 print("workgroups per XCD: " + " ".join("%d" % int((xcc == x).sum()) for x in range(8)))
+# the workgroups that leave at once (key blocks beyond a sample's list: the grid is sized by the static bound)
+dm = allwg[allwg[:, 3] < 0]
+if len(dm):
+    d0, d1 = (dm[:, 0].double() - t0) / 100.0, (dm[:, 1].double() - t0) / 100.0
+    print("workgroups that leave at once: %d, run time median %.2f us, p90 %.2f, max %.2f; started over %.1f .. %.1f ms of the span"
+          % (len(dm), (d1 - d0).median().item(), (d1 - d0).quantile(0.9).item(), (d1 - d0).max().item(), d0.min().item() / 1e3, d0.max().item() / 1e3))
+    dhw, dxcc = dm[:, 2] & 0xFFFFFFFF, (dm[:, 2] >> 32) & 0xF
+    dcu = ((dxcc * 8 + ((dhw >> 13) & 0x7)) * 2 + ((dhw >> 12) & 0x1)) * 16 + ((dhw >> 8) & 0xF)
+    # how much of each gap between two sweeps on a CU is covered by such workgroups, and how many sit in it
+    cov, cnt, big = [], [], []
+    for c in torch.unique(cuid):
+        m = cuid == c
+        s_, e_ = r0[m], r1[m]
+        o_ = torch.argsort(s_)
+        s_, e_ = s_[o_], e_[o_]
+        md = dcu == c
+        ds, de = d0[md], d1[md]
+        for i in range(len(s_) - 1):
+            inside = (ds >= e_[i]) & (de <= s_[i + 1])
+            gap = (s_[i + 1] - e_[i]).item()
+            cnt.append(int(inside.sum()))
+            cov.append((de[inside] - ds[inside]).sum().item())
+            if gap > 50:
+                big.append((gap, int(inside.sum()), (de[inside] - ds[inside]).sum().item()))
+    cnt_t, cov_t = torch.tensor(cnt, dtype=torch.double), torch.tensor(cov)
+    print("per gap between two sweeps on a CU: leave-at-once workgroups inside: mean %.2f, max %d; their run time covers %.1f %% of all gap time"
+          % (cnt_t.mean().item(), int(cnt_t.max().item()), 100 * cov_t.sum().item() / max(g.clamp(min=0).sum().item(), 1e-9)))
+    if big:
+        bg = torch.tensor(big)
+        print("gaps > 50 us: %d, holding on average %.1f such workgroups that cover %.1f %% of those gaps" % (len(big), bg[:, 1].mean().item(), 100 * bg[:, 2].sum().item() / bg[:, 0].sum().item()))

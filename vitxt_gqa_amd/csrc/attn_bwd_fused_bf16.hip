@@ -64,6 +64,8 @@ struct FbWork {
   unsigned* status;       // [4]: bit 0 of word 0 = a bounded spin timed out
   const float* nl;        // [B H][nqt * 64]: -lse * log2(e) per query row, -inf behind Lq (written by attn_delta_prep_kernel)
   const float* nd;        // [B H][nqt * 64]: -delta per query row, 0 behind Lq
+  const unsigned* slots;  // [8 XCD groups][groups + 1]: first ticket of each (sample, head) pair of the group, then the group's total (prep kernel)
+  int groups;             // (sample, head) pairs per XCD group = ceil(B H / 8)
   unsigned long long* dbg; // the workspace's tail: diagnostic builds only (-DFB_STAMP: cycle stamps; -DFB_TIMELINE: one record per workgroup)
   int handoff;
 };
@@ -268,21 +270,50 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   float* __restrict__ const dq32 = w.part;         // (atomic form)
 #ifdef FB_TIMELINE   // diagnostic build only: when and where every workgroup ran (100 MHz real-time counter, HW_ID / XCC_ID)
   const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
+#define FB_TL_DUMMY()                                                                                                        \
+  if (tid == 0 && blockIdx.x < 131072u) {                                                                                    \
+    unsigned hw_, xcc_;                                                                                                      \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); \
+    unsigned long long* tl_ = w.dbg + 2048 + (size_t)blockIdx.x * 4;                                                         \
+    tl_[0] = tl_r0;                                                                                                          \
+    tl_[1] = __builtin_amdgcn_s_memrealtime();                                                                               \
+    tl_[2] = (unsigned long long)hw_ | ((unsigned long long)xcc_ << 32);                                                     \
+    tl_[3] = 1ull << 63;                                                                                                     \
+  }
+#else
+#define FB_TL_DUMMY()
 #endif
   int kblk, h, b;
   if constexpr (HO && !TAIL) {
     // ticket: this workgroup is the slot-th one of its XCD group to START (not the slot-th by id), see FbWork
+    // Tickets are COMPACT: slot s of XCD group x is the s-th key block that exists in the group's pairs (table of first slots per
+    // pair, built by the prep kernel from the key counts), not the s-th of a [pairs][kblocks] rectangle sized by the static key
+    // bound.  The workgroups the grid has beyond a group's total leave at once - and they are the LAST to start, where the
+    // rectangle had up to kblocks - 1 of them in a row between two pairs, each holding a whole CU for a launch, an atomic round
+    // trip and a count load (tools/fused_timeline.py: CUs 90 % busy over the launch, median gap between two sweeps 12 us).
     unsigned* sl = reinterpret_cast<unsigned*>(smem);
-    if (tid == 0) sl[0] = atomicAdd(w.tickets + (MODE % 3) * T2S_XCDS + (blockIdx.x % T2S_XCDS), 1u);
+    const int xg = (int)(blockIdx.x % T2S_XCDS);
+    const unsigned* __restrict__ tab = w.slots + xg * (w.groups + 1);
+    if (tid == 0) {
+      unsigned* tk = w.tickets + (MODE % 3) * T2S_XCDS + xg;
+      // (a stale read only errs on the low side: then the atomic decides)
+      sl[0] = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tab[w.groups] ? 0xFFFFFFFFu : atomicAdd(tk, 1u);
+    }
     __syncthreads();
-    const int slot = __builtin_amdgcn_readfirstlane((int)sl[0]);
+    const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)sl[0]);
     __syncthreads();                               // (the stage buffer is written below)
-    const int g = slot / p.kblocks;
-    const int bh = g * T2S_XCDS + (int)(blockIdx.x % T2S_XCDS);
-    if (bh >= p.H * p.B) return;
+    if (slot >= tab[w.groups]) { FB_TL_DUMMY(); return; }
+    int g = 0;                                     // the pair whose slot range holds this ticket: count the first-slots <= slot
+    for (int base = 0; base < w.groups; base += 64) {
+      const int gi = base + lane;
+      const unsigned first = gi < w.groups ? tab[gi] : 0xFFFFFFFFu;
+      g += __builtin_popcountll(__ballot(first <= slot));
+    }
+    g = __builtin_amdgcn_readfirstlane(g) - 1;
+    const int bh = g * T2S_XCDS + xg;
     // (the division runs on the vector ALU: pin the results to scalar registers, or every address and the buffer descriptors
     // derived from them live in VGPRs and each buffer access becomes a waterfall loop - cdna_hip_programming.md T20)
-    kblk = __builtin_amdgcn_readfirstlane(slot - g * p.kblocks);
+    kblk = __builtin_amdgcn_readfirstlane((int)(slot - tab[g]));
     b = __builtin_amdgcn_readfirstlane(bh / p.H);
     h = __builtin_amdgcn_readfirstlane(bh - b * p.H);
   } else {
@@ -291,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
   const int nk = n_prefix + p.n_dec;
   int kbw = TAIL ? p.kblocks : kblk;
-  if (kbw * FB_KEYS >= nk) return;                 // uniform per workgroup
+  if (kbw * FB_KEYS >= nk) { FB_TL_DUMMY(); return; }     // uniform per workgroup
   const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
   const bf16_t* __restrict__ Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_bs + h * 64;
   const bf16_t* __restrict__ DO = reinterpret_cast<const bf16_t*>(p.dout) + (int64_t)b * p.o_bs + h * 64;
@@ -1070,8 +1101,26 @@ __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __re
                                                               const float* __restrict__ lse, float* __restrict__ nl, float* __restrict__ nd, int nq_pad,
                                                               float* __restrict__ dq32 /* NULL: no accumulation buffer to zero (hand-off form) */, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                                                               const uint8_t* __restrict__ row_valid, int valid_len, int dec_q0, int n_dec, int B, int H, int Lq,
-                                                              int64_t o_rs, int64_t o_bs, int64_t kv_rs, int64_t kv_bs) {
+                                                              int64_t o_rs, int64_t o_bs, int64_t kv_rs, int64_t kv_bs,
+                                                              unsigned* __restrict__ slots, int groups, const int32_t* __restrict__ kv_cnt, int dense_keys,
+                                                              int kblocks) {
   const int lane = threadIdx.x & 63;
+  // the fused sweep's ticket table (FbWork.slots): per XCD group the first slot of each of its (sample, head) pairs = running count of
+  // the key blocks that exist (the sample's key count, capped by the launch's static bound), then the group's total
+  if (slots && blockIdx.x == 0 && threadIdx.x < T2S_XCDS) {
+    unsigned acc = 0;
+    unsigned* t = slots + threadIdx.x * (groups + 1);
+    for (int g = 0; g < groups; ++g) {
+      t[g] = acc;
+      const int bh = g * T2S_XCDS + (int)threadIdx.x;
+      if (bh < B * H) {
+        const int nk = (kv_cnt ? kv_cnt[bh / H] : dense_keys) + n_dec;
+        const int nb = (nk + FB_KEYS - 1) / FB_KEYS;
+        acc += (unsigned)(nb < kblocks ? nb : kblocks);
+      }
+    }
+    t[groups] = acc;
+  }
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (int64_t)B * Lq) return;
   const int b = (int)(row / Lq), q = (int)(row % Lq);
@@ -1128,7 +1177,8 @@ __global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restri
 // Workspace of the fused backward, in bytes, for (B, H, Lq): control words + flags + the fp32 dQ sums (either form)
 size_t attn_bwd_fused_workspace_bytes(int B, int H, int Lq) {
   const size_t nqt = ((size_t)Lq + FB_QROWS - 1) / FB_QROWS;
-  const size_t ctrl = ((size_t)FB_CTRL_WORDS * 4 + (size_t)B * H * nqt * 4 + 255) / 256 * 256;
+  const size_t groups = ((size_t)B * H + T2S_XCDS - 1) / T2S_XCDS;
+  const size_t ctrl = ((size_t)FB_CTRL_WORDS * 4 + (size_t)B * H * nqt * 4 + T2S_XCDS * (groups + 1) * 4 + 255) / 256 * 256;
   const size_t rowc = 2 * (size_t)B * H * nqt * FB_QROWS * 4;            // -lse log2e and -delta per padded query row (LDS-DMA sources)
   const size_t sums = (size_t)B * H * nqt * (FB_QROWS * 64 * 4);        // >= B * Lq * H * 64 * 4, the atomic form's buffer
   return ctrl + rowc + sums + FB_DBG_BYTES;                              // + room for the diagnostic builds' stamps
@@ -1144,11 +1194,15 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
     return 2;
   }
   const size_t nqt = ((size_t)p.Lq + FB_QROWS - 1) / FB_QROWS;
-  const size_t ctrl = ((size_t)FB_CTRL_WORDS * 4 + (size_t)p.B * p.H * nqt * 4 + 255) / 256 * 256;
+  const size_t groups = ((size_t)p.B * p.H + T2S_XCDS - 1) / T2S_XCDS;
+  const size_t ctrl = ((size_t)FB_CTRL_WORDS * 4 + (size_t)p.B * p.H * nqt * 4 + T2S_XCDS * (groups + 1) * 4 + 255) / 256 * 256;
   FbWork w;
   w.tickets = reinterpret_cast<unsigned*>(workspace);
   w.status = w.tickets + 3 * T2S_XCDS;
   w.flags = w.tickets + FB_CTRL_WORDS;
+  unsigned* const slots = w.flags + (size_t)p.B * p.H * nqt;          // behind the flags, inside the control block
+  w.slots = slots;
+  w.groups = (int)groups;
   const size_t rowc_n = (size_t)p.B * p.H * nqt * FB_QROWS;               // elements of each row-constant array
   float* const nl = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ctrl);
   float* const nd = nl + rowc_n;
@@ -1190,11 +1244,11 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
     return 3;
   }
 #endif
+  p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   hipLaunchKernelGGL(attn_delta_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)p.o, (const bf16_t*)p.dout, p.delta,
                      (const float*)p.lse, FB_DMA ? nl : nullptr, nd, (int)(nqt * FB_QROWS), handoff ? nullptr : dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs,
-                     p.kv_rs, p.kv_bs);
+                     p.kv_rs, p.kv_bs, handoff ? slots : nullptr, (int)groups, p.kv_idx ? p.kv_cnt : nullptr, p.idx_cap - p.n_dec, p.kblocks);
   T2S_CHECK_LAUNCH("attn_bwd_fused (delta prep)");
-  p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256), tail(attn_xcd_grid(1, p.H, p.B));
 #define FB_LAUNCH2(IDX_, MODE_, DROP_, grid_)                                                                            \
   if (handoff) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, true>), grid_, block, FB_SMEM_TOTAL, st, p, w);   \

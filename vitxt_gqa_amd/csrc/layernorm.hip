@@ -344,6 +344,63 @@ __global__ __launch_bounds__(256, 2) void ocr_tail_bwd_kernel(const float* __res
   }
 }
 
+// Pre-LayerNorm block of the ViT frame-feature producer (tools/video_feat/obtain_vit_feat.py:37-53 runs transformers' ViTLayer:
+// x = x + attn(LN(x)); x = x + mlp(LN(x))): the residual update and the NEXT LayerNorm in one pass over the rows of the fp32 stream.
+//   h <- h + branch + bias   (branch: the bf16 GEMM output of the block just finished, bias: that dense layer's fp32 bias; both optional)
+//   y  = LN(h) * gamma + beta  in bf16 (the next GEMM's operand) or fp32 (the final LayerNorm)
+// Row width W <= 256 * NV, a multiple of 4 (ViT-L: 1024 = 4 vectors per lane; lanes behind W idle), one wavefront per row, the row
+// held in registers.
+template <int NV, typename TB, typename TY>
+__global__ __launch_bounds__(256) void wide_add_layernorm_fwd_kernel(float* __restrict__ h, const TB* __restrict__ branch,
+                                                                     const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, TY* __restrict__ y, int64_t rows,
+                                                                     int64_t h_stride, int W, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e < W) {
+      v[i] = *reinterpret_cast<const f32x4*>(h + row * h_stride + e);
+      if (branch) {
+        v[i] += Vec4<TB>::load(branch + row * W + e);
+        if (bias) v[i] += *reinterpret_cast<const f32x4*>(bias + e);
+        *reinterpret_cast<f32x4*>(h + row * h_stride + e) = v[i];
+      }
+    }
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float inv_w = 1.f / (float)W;
+  const float mean = wave_sum(s) * inv_w;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if ((i * 64 + lane) * 4 < W) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[i][j] - mean;
+        sq += d * d;
+      }
+    }
+  const float rstd = 1.f / sqrtf(wave_sum(sq) * inv_w + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    if (e < W) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + e);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + e);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      Vec4<TY>::store(y + row * W + e, o);
+    }
+  }
+}
+
 int bwd_parts(int64_t rows) {
   int64_t n = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   return (int)(n < BWD_MAX_PARTS ? (n < 1 ? 1 : n) : BWD_MAX_PARTS);
@@ -504,5 +561,34 @@ extern "C" int t2s_ocr_tail_bwd(const float* g_out, const void* a, int a_dtype, 
     hipLaunchKernelGGL(ocr_tail_bwd_kernel<float>, grid, block, 0, st, g_out, (const float*)a, bbox, w_box, b_box, gamma_a, gamma_b, stats, (float*)d_a,
                        part, rows, drop);
   T2S_CHECK_LAUNCH("ocr_tail_bwd");
+  return 0;
+}
+
+extern "C" int t2s_wide_add_layernorm_fwd(float* h, int64_t h_row_stride, const void* branch, int branch_dtype, const float* bias,
+                                          const float* gamma, const float* beta, void* y, int y_dtype, int64_t rows, int width, float eps,
+                                          t2s_stream_t stream) {
+  T2S_CHECK_ARG(h && gamma && beta && y, "wide_add_layernorm_fwd: null pointer");
+  T2S_CHECK_ARG(rows > 0 && is_dt(y_dtype) && (!branch || is_dt(branch_dtype)), "wide_add_layernorm_fwd: bad rows / dtype");
+  T2S_CHECK_ARG(width >= 4 && width <= 1280 && width % 4 == 0, "wide_add_layernorm_fwd: width %d is not a multiple of 4 in [4, 1280]", width);
+  T2S_CHECK_ARG(h_row_stride >= width && h_row_stride % 4 == 0, "wide_add_layernorm_fwd: bad row stride %lld", (long long)h_row_stride);
+  T2S_CHECK_ARG(branch || !bias, "wide_add_layernorm_fwd: a bias without a branch");
+  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int combo = ((branch && branch_dtype == T2S_BF16) ? 2 : 0) + (y_dtype == T2S_BF16 ? 1 : 0);
+#define WIDE_LN2(NV_, TB_, TY_)                                                                                                         \
+  hipLaunchKernelGGL((wide_add_layernorm_fwd_kernel<NV_, TB_, TY_>), grid, block, 0, st, h, (const TB_*)branch, bias, gamma, beta,      \
+                     (TY_*)y, rows, h_row_stride, width, eps)
+#define WIDE_LN(NV_)                                                \
+  switch (combo) {                                                  \
+    case 0: WIDE_LN2(NV_, float, float); break;                     \
+    case 1: WIDE_LN2(NV_, float, bf16_t); break;                    \
+    case 2: WIDE_LN2(NV_, bf16_t, float); break;                    \
+    default: WIDE_LN2(NV_, bf16_t, bf16_t); break;                  \
+  }
+  const int nv = (width + 255) / 256;
+  if (nv == 1) { WIDE_LN(1) } else if (nv == 2) { WIDE_LN(2) } else if (nv == 3) { WIDE_LN(3) } else if (nv == 4) { WIDE_LN(4) } else { WIDE_LN(5) }
+#undef WIDE_LN
+#undef WIDE_LN2
+  T2S_CHECK_LAUNCH("wide_add_layernorm_fwd");
   return 0;
 }

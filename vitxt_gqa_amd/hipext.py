@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2S_HIP_LIB") or os.path.join(_HERE, "libt2s_hip.so")      # override: kernel build experiments only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 T2S_F32, T2S_BF16 = 0, 1
 
@@ -27,6 +27,7 @@ _SIGS = {
     "t2s_attn_bwd_fused_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "t2s_attn_bwd_fused": (c_int, [c_void_p] * 11 + [c_int64, c_int] + [c_void_p] * 3 + [c_int] * 7 + [c_int64] * 6 + [c_float, c_int, c_float, c_uint64, c_void_p]),
     "t2s_add_layernorm_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_float, c_int, c_int, c_float, c_uint64, c_void_p]),
+    "t2s_wide_add_layernorm_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p]),
     "t2s_add_layernorm_fwd_nres": (c_int, [c_void_p] * 11 + [c_int64, c_float, c_int, c_int, c_float, c_uint64, c_void_p]),
     "t2s_layernorm_bwd_parts": (c_int, [c_int64]),
     "t2s_add_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_float, c_uint64, c_void_p]),

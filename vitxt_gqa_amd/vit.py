@@ -14,7 +14,6 @@ import os
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import hipext as X
 from . import ops
@@ -32,6 +31,24 @@ def preprocess(images, size=224):
         a = np.asarray(im, dtype=np.float32) * (1.0 / 255.0)
         out.append(((a - 0.5) / 0.5).transpose(2, 0, 1))
     return torch.from_numpy(np.stack(out))
+
+
+def add_layernorm(h, branch, bias, gamma, beta, eps, out_dtype):
+    """One pass over the rows of the fp32 stream h [..., W] (updated IN PLACE): h += branch + bias (both optional), returns
+    LN(h) * gamma + beta as out_dtype (t2s_wide_add_layernorm_fwd; W a multiple of 4, <= 1280).  h may be a strided row view (the CLS rows)."""
+    W = h.shape[-1]
+    rows = h.numel() // W
+    assert h.dtype == torch.float32 and h.is_cuda and h.stride(-1) == 1
+    stride = W if h.dim() == 1 or h.is_contiguous() else h.stride(-2)
+    if not h.is_contiguous():
+        assert h.dim() == 2, "a non-contiguous stream must be a [rows, W] view with one row stride"
+    if branch is not None:
+        assert branch.dtype in (torch.bfloat16, torch.float32) and branch.is_contiguous() and branch.numel() == rows * W
+    y = torch.empty(h.shape, dtype=out_dtype, device=h.device)
+    X.check(X.lib().t2s_wide_add_layernorm_fwd(X.ptr(h), stride, X.ptr(branch) if branch is not None else None,
+                                               X.dtype_code(branch) if branch is not None else 0, X.ptr(bias) if bias is not None else None, X.ptr(gamma), X.ptr(beta), X.ptr(y),
+                                               X.dtype_code(y), rows, W, float(eps), X.stream()), "t2s_wide_add_layernorm_fwd")
+    return y
 
 
 def attention_dense(qkv, n_heads):
@@ -116,15 +133,21 @@ class ViTFeatureExtractor:
         h = (patches.to(dt) @ self.w_patch.t()).float() + self.b_patch
         h = torch.cat([self.cls.expand(B, -1, -1), h], 1) + self.pos
         L = h.shape[1]
-        for ly in self.layers:
-            y = F.layer_norm(h, (self.h,), ly["ln1"][0], ly["ln1"][1], self.eps).to(dt)
+        h = h.contiguous()
+        # pre-LN blocks: the residual update of one block and the LayerNorm in front of the next are ONE pass over the stream
+        y = add_layernorm(h, None, None, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], self.eps, dt)
+        for i, ly in enumerate(self.layers):
             qkv = torch.addmm(ly["b_qkv"], y.view(B * L, self.h), ly["w_qkv"].t()).view(B, L, 3 * self.h)
             att = attention_dense(qkv.contiguous(), self.nh)
-            h = h + (att.view(B * L, self.h) @ ly["w_ao"].t()).float().view(B, L, self.h) + ly["b_ao"]
-            y = F.layer_norm(h, (self.h,), ly["ln2"][0], ly["ln2"][1], self.eps).to(dt)
+            y = add_layernorm(h, att.view(B * L, self.h) @ ly["w_ao"].t(), ly["b_ao"], ly["ln2"][0], ly["ln2"][1], self.eps, dt)
             u = ops.gelu_fwd(torch.addmm(ly["b_i"], y.view(B * L, self.h), ly["w_i"].t()))
-            h = h + (u @ ly["w_o"].t()).float().view(B, L, self.h) + ly["b_o"]
-        return F.layer_norm(h[:, 0], (self.h,), self.ln_f[0], self.ln_f[1], self.eps)
+            if i + 1 < self.nl:
+                nxt = self.layers[i + 1]["ln1"]
+                y = add_layernorm(h, u @ ly["w_o"].t(), ly["b_o"], nxt[0], nxt[1], self.eps, dt)
+            else:
+                # last block: only the CLS rows are read (last_hidden_state[:, 0, :]); their residual update + the final LayerNorm
+                cls_branch = (u.view(B, L, self.ffn)[:, 0].contiguous() @ ly["w_o"].t())
+                return add_layernorm(h[:, 0], cls_branch, ly["b_o"], self.ln_f[0], self.ln_f[1], self.eps, torch.float32)
 
 
 def extract_video_features(model, frames_dir, out_dir, batch=64, size=224):
