@@ -50,6 +50,11 @@ tail_bytes = 16384 + 131072 * 32
 tl = ws.view(torch.uint8)[-tail_bytes + 16384:].view(torch.int64).view(-1, 4).cpu()
 tl = tl[tl[:, 1] > 0]
 allwg = tl
+if os.environ.get("FB_TL_SAVE"):                           # raw records [n, 4] int64 (start, end: 10 ns ticks; HW_ID | XCC_ID << 32; key block word) + workgroup ids
+    import numpy as np
+    full = ws.view(torch.uint8)[-tail_bytes + 16384:].view(torch.int64).view(-1, 4).cpu()
+    ids = torch.nonzero(full[:, 1] > 0).flatten()
+    np.savez_compressed(os.environ["FB_TL_SAVE"], rec=full[ids].numpy(), wg=ids.numpy())
 tl = tl[tl[:, 3] >= 0]                                     # bit 63 marks a workgroup that had no key block to sweep (left at once)
 r0, r1 = tl[:, 0].double(), tl[:, 1].double()
 t0 = r0.min()
