@@ -1079,12 +1079,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
           }
       }
 #ifdef FB_TIMELINE
+    if (!TAIL && lane == 0 && wave != 0 && blockIdx.x < 131072u)      // the LAST wave's end (the CU is free for the next workgroup only then)
+      atomicMax(w.dbg + 2048 + (size_t)blockIdx.x * 4 + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     if (!TAIL && tid == 0 && blockIdx.x < 131072u) {
       unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
       unsigned long long* tl = w.dbg + 2048 + (size_t)blockIdx.x * 4;
       tl[0] = tl_r0;
-      tl[1] = __builtin_amdgcn_s_memrealtime();
+      atomicMax(tl + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
       tl[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
       tl[3] = (unsigned long long)(unsigned)kbw | ((unsigned long long)(unsigned)b << 8) | ((unsigned long long)(unsigned)h << 24) |
               ((unsigned long long)(unsigned)nkeys_wg << 32) | ((unsigned long long)(edge_wg ? 1u : 0u) << 48);
