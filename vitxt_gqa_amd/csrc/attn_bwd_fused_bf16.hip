@@ -83,6 +83,11 @@ constexpr size_t FB_DBG_BYTES = 16384;
 #ifndef FB_DMA
 #define FB_DMA 1
 #endif
+// Dropout masks of the pipelined sweep as KEEP words applied to the fp32 dP values by one v_and_b32_sdwa per score (round 4; 0: the
+// drop words + v_bfe_i32 / v_ashrrev_i32 + v_bfi_b32 of rounds 2-3, kept for same-box A/B builds)
+#ifndef FB_SDWA
+#define FB_SDWA 1
+#endif
 // Hand-off experiment, built and measured, NOT shipped (-DFB_HO_PREFETCH=1; needs FB_DMA): the predecessor's running sum of tile t+1
 // fetched by LDS-DMA into a 16 KB LDS region at the END of tile t (its flag checked one tile ahead), landing under phase A of tile t+1
 // and read back from LDS behind phase B - instead of four register loads issued ahead of the barrier, whose memory latency phase B
@@ -231,8 +236,13 @@ __device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], con
   sacc[par][r0] = p0;                                  // dS uses the UNdropped probability
   sacc[par][r1] = p1;
   if (DROP) {                                          // registers (2m, 2m+1) are two consecutive queries of this lane's key: one packed mask word
+#if FB_SDWA
+    mw[M] = attn_drop_pair_kept(rkw, ck2, th2);        // 0xFFFF in every KEPT half (th2 = attn_drop_thresh2k)
+    pfw[M] = fb_pack2(p0, p1) & mw[M];                 // dV uses the dropped one (scaled by 1/(1-p) at the end)
+#else
     mw[M] = attn_drop_pair_dropped(rkw, ck2, th2);     // 0xFFFF in every dropped half
-    pfw[M] = attn_drop_apply(fb_pack2(p0, p1), mw[M]); // dV uses the dropped one (scaled by 1/(1-p) at the end)
+    pfw[M] = attn_drop_apply(fb_pack2(p0, p1), mw[M]);
+#endif
   } else {
     pfw[M] = fb_pack2(p0, p1);
   }
@@ -243,7 +253,12 @@ __device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dp
                                       const float nd1, const float inv) {
   constexpr int par = I & 1;
   if (DROP) {
+#if FB_SDWA
+    // (one v_and_b32_sdwa per score: the kept-half word, sign-extended by the operand selector, is the fp32 mask)
+    const float d0 = attn_drop_keep_lo(dpacc[par][2 * M], mw[M]), d1 = attn_drop_keep_hi(dpacc[par][2 * M + 1], mw[M]);
+#else
     const float d0 = attn_drop_zero_lo(dpacc[par][2 * M], mw[M]), d1 = attn_drop_zero_hi(dpacc[par][2 * M + 1], mw[M]);
+#endif
     dsw[M] = fb_pack2(sacc[par][2 * M] * __builtin_fmaf(d0, inv, nd0), sacc[par][2 * M + 1] * __builtin_fmaf(d1, inv, nd1));
   } else {
     dsw[M] = fb_pack2(sacc[par][2 * M] * dpacc[par][2 * M], sacc[par][2 * M + 1] * dpacc[par][2 * M + 1]);
@@ -423,7 +438,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     uint32_t ck2[FB_KB];
 #pragma unroll
     for (int kb = 0; kb < FB_KB; ++kb) ck2[kb] = 0u;         // (set per 256-row window of query rows at the top of every fourth tile)
+#if FB_SDWA
+    const uint32_t th2 = attn_drop_thresh2k(p.drop_thresh);      // (the pipelined sweep's masks are KEEP words)
+#else
     const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
+#endif
     const float drop_inv = p.drop_inv;
     uint32_t rkreg = 0;
     int ld_row0 = 0;              // first query row of the tile being loaded (uniform)

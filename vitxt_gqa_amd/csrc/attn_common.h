@@ -109,6 +109,28 @@ __device__ __forceinline__ uint32_t attn_drop_pair_dropped(uint32_t a2, uint32_t
   const s16x2 m = __builtin_bit_cast(s16x2, attn_drop_pair_diff(a2, b2, thresh2s)) >> 15;
   return __builtin_bit_cast(uint32_t, m);
 }
+// The KEEP form of the same test: 0xFFFF in every KEPT half (kept iff t >= ths  <=>  (ths - 1) - t < 0: v_pk_mul_lo_u16,
+// v_pk_sub_i16 clamp with the operands the other way round, v_pk_ashrrev_i16).  Such a word clears a packed bf16 pair with ONE v_and_b32
+// and an fp32 value with ONE v_and_b32_sdwa (attn_drop_keep_lo / _hi below: the 16-bit half, sign-extended by the operand selector, is
+// the 32-bit mask) - no per-score mask expansion.  thresh2k = attn_drop_thresh2k(thresh).
+__device__ __forceinline__ uint32_t attn_drop_thresh2k(uint32_t thresh) { return (((thresh ^ 0x8000u) - 1u) & 0xFFFFu) * 0x10001u; }
+__device__ __forceinline__ uint32_t attn_drop_pair_kept(uint32_t a2, uint32_t b2, uint32_t thresh2k) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 t = __builtin_bit_cast(u16x2, a2) * __builtin_bit_cast(u16x2, b2);
+  const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, thresh2k), __builtin_bit_cast(s16x2, t));
+  return __builtin_bit_cast(uint32_t, d >> 15);
+}
+__device__ __forceinline__ float attn_drop_keep_lo(float x, uint32_t kword) {
+  float r;
+  asm("v_and_b32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(x), "v"(kword));
+  return r;
+}
+__device__ __forceinline__ float attn_drop_keep_hi(float x, uint32_t kword) {
+  float r;
+  asm("v_and_b32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(x), "v"(kword));
+  return r;
+}
 // word of two bf16 probabilities with the dropped halves cleared (v_bfi_b32)
 __device__ __forceinline__ uint32_t attn_drop_apply(uint32_t w, uint32_t dropped) { return w & ~dropped; }
 
