@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
   const uint32_t rh = DROP ? attn_drop_rowhash(salt, qr) : 0u;                   // this lane's row hash; its row key of a tile's key window in
   uint32_t rk2 = 0;                                                              // both 16-bit halves is derived per tile (DQ_ROWKEY)
 #define DQ_ROWKEY(t_) if (DROP) rk2 = attn_drop_rowkey16w(rh, ((t_) * BK) / ATTN_DROP_KWIN) * 0x10001u;
-  const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
-  const uint32_t inv_bits = __builtin_bit_cast(uint32_t, p.drop_inv);
+  const uint32_t th2 = attn_drop_thresh2k(p.drop_thresh);      // (keep words: attn_drop_pair_kept)
+  const float inv_f = p.drop_inv;
   uint32_t ckreg = 0;
   // column keys of key pair `tid` of tile t_ (threads 0..31), staged beside the K/V tile
 #define CK_LOAD(t_)                                                                                 \
@@ -199,9 +199,9 @@ __global__ __launch_bounds__(256, 2) void attn_dq_bf16_kernel(AttnParams p) {
       }                                                                                             \
       float dpv = dpacc[kbk_][r];                                                                   \
       if (DROP) {   /* dA = dD * M / (1 - p): registers (r, r+1), r even, are the key pair (kbk*32 + acc_row(r, lh)) / 2;       \
-                       M / (1 - p) as a float that is 1/(1-p) or 0: the constant AND the sign of the pair's diff half */   \
-        const uint32_t d_ = attn_drop_pair_diff(rk2, ck_s[buf][(kbk_) * 16 + 4 * (r >> 2) + 2 * lh + ((r & 3) >> 1)], th2); \
-        const float g_ = __builtin_bit_cast(float, inv_bits & ~((r & 1) ? attn_drop_hi32(d_) : attn_drop_lo32(d_)));       \
+                       M / (1 - p) as a float that is 1/(1-p) or 0: the constant AND the pair's keep half (v_and_b32_sdwa) */ \
+        const uint32_t d_ = attn_drop_pair_kept(rk2, ck_s[buf][(kbk_) * 16 + 4 * (r >> 2) + 2 * lh + ((r & 3) >> 1)], th2); \
+        const float g_ = (r & 1) ? attn_drop_keep_hi(inv_f, d_) : attn_drop_keep_lo(inv_f, d_);                            \
         dpv = __builtin_fmaf(dpv, g_, -del);                                                        \
       }                                                                                             \
       dpacc[kbk_][r] = pv * dpv;                                                                    \

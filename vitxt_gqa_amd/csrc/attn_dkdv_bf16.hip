@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_dkdv_bf16_kernel(AttnParams p
   // are hashed by threads 0..31 while the tile is staged
   const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
   uint32_t ck2 = 0u;                                      // this lane's column key of the current 256-row window (set in the sweep)
-  const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
+  const uint32_t th2 = attn_drop_thresh2k(p.drop_thresh);      // (keep words: attn_drop_pair_kept)
   // loads the NEXT tile in sequence (tile 0 first; past the last tile: clamped copies of the last row, harmless)
 #define STAGE_LOAD(qt_unused_)                                                                  \
   {                                                                                             \
