@@ -505,17 +505,20 @@ def test_attention_bwd_fused_five_products(B, L1, n_dec, keep, drop_p, dq_mode):
         assert (got[..., 768:].double() - two[..., 768:].double()).abs().max().item() < 2e-2 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("B", [16, 3])
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
-def test_attention_bwd_fused_handoff_under_uneven_load(drop_p):
+def test_attention_bwd_fused_handoff_under_uneven_load(drop_p, B):
     """The dQ hand-off protocol (csrc/attn_bwd_fused_bf16.hip, FbWork; Guideline 16 R1) where it is stressed: 16 x 12 = 192
     (sample, head) chains of 1 .. 14 key blocks each (visible keys from 3 % to 100 % of 5 300 rows) - about 1 500 workgroups for 256
     CUs, so later tickets start while earlier chains are mid-sweep, consumers re-read lines their CU has seen before (the running
     sums are rewritten in place by every block) and the chains differ in length by an order of magnitude.  Asserted: no spin
     timed out; two launches give bit-identical gradients; dQ equals the atomic form's to fp32 summation-order noise (one bf16
-    rounding step at most, and only rarely); dK / dV are identical in both forms."""
+    rounding step at most, and only rarely); dK / dV are identical in both forms.  The tickets are compact over the key blocks that
+    exist (slot table built by the prep kernel): B = 3 gives 36 pairs = 4 full XCD groups + one with 4 of 8 members (empty table tails)
+    with one-block and fourteen-block chains side by side."""
     _need_gpu()
     from vitxt_gqa_amd import ops
-    B, L1, n_dec = 16, 5300, 12
+    L1, n_dec = 5300, 12
     L = L1 + n_dec
     g = torch.Generator().manual_seed(41)
     x = (torch.randn(B, L, 2304, generator=g) * 0.8).to(DEV).to(torch.bfloat16)
