@@ -411,6 +411,52 @@ def test_pruned_kv_path_with_a_violated_structural_bound_stays_in_bounds():
     assert (out[1].float() - want[1].float()).abs().max().item() < 2e-2 and (lse[1] - wlse[1]).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_pruned_kv_backward_takes_the_fused_form(drop_p):
+    """The pos / neg MMT passes hand the backward a COMPACT K | V buffer (only the rows that are keys: KeyList.compact) and a short
+    list (<= 549 / 74 keys for 10 132 query rows).  With the ordered hand-off the fused five-product kernel is the faster form there
+    too (profiles/r04_light_launches.txt), so ops.attn_bwd routes that call through it: same gradients as the two-kernel form
+    (bf16 tolerance; dK / dV rows behind a sample's list exactly zero), bit-reproducible, and equal to the un-pruned self-attention
+    path's gradients gathered at the key rows."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    B, L1, n_dec = 2, 1500, 12
+    L = L1 + n_dec
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    valid = torch.zeros(B, L1, dtype=torch.bool)
+    valid[0, torch.randperm(L1, generator=g)[:70]] = True
+    valid[1, torch.randperm(L1, generator=g)[:520]] = True
+    valid = valid.to(DEV)
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1, cap_hint=537 + n_dec)
+    keys.bound_is_structural = True
+    keys_c, flat, capK = keys.compact(L)
+    q = x[..., :768].contiguous()
+    kv = x.view(B * L, 2304).index_select(0, flat)[:, 768:].contiguous().view(B, capK, 1536)
+    kw = dict(drop_p=drop_p, drop_seed=99) if drop_p else {}
+    out, lse = ops.attn_fwd(q, keys_c, kv=kv, **kw)
+    assert ops._fused_policy(None, q, keys_c, L, 1) and not ops._fused_policy(None, q, keys_c, 20, 1) and not ops._fused_policy(None, q, keys_c, L, 0)
+    dq_f, dkv_f = ops.attn_bwd(q, out, dout, lse, keys_c, kv=kv, **kw)                    # default policy: fused, hand-off
+    assert ops.LAST_ATTN_BWD_PRODUCTS == 5 and ops.fused_handoff_status() == 0
+    dq_g, dkv_g = ops.attn_bwd(q, out, dout, lse, keys_c, kv=kv, **kw)
+    assert torch.equal(dq_f, dq_g) and torch.equal(dkv_f, dkv_g)
+    dq_t, dkv_t = ops.attn_bwd(q, out, dout, lse, keys_c, kv=kv, fused=False, **kw)
+    assert ops.LAST_ATTN_BWD_PRODUCTS == 7
+    sq, sk = dq_t.float().abs().max().item(), dkv_t.float().abs().max().item()
+    assert (dq_f.float() - dq_t.float()).abs().max().item() < 3e-2 * max(1.0, sq)
+    assert (dkv_f.float() - dkv_t.float()).abs().max().item() < 2e-2 * max(1.0, sk)
+    live = torch.arange(capK, device=DEV).unsqueeze(0) < (keys_c.cnt + n_dec).unsqueeze(1)
+    assert dkv_f[~live].abs().max().item() == 0
+    # the un-pruned path (same list over the fused QKV buffer): dQ the same, dK / dV of the listed rows the same rows of its output
+    out_u, lse_u = ops.attn_fwd(x, keys, **kw)
+    assert (out_u.float() - out.float()).abs().max().item() < 1e-6
+    full = ops.attn_bwd(x, out_u, dout, lse_u, keys, fused=True, **kw)
+    assert (full[..., :768].float() - dq_f.float()).abs().max().item() < 3e-2 * max(1.0, sq)
+    gathered = full.view(B * L, 2304).index_select(0, flat)[:, 768:].view(B, capK, 1536)
+    assert (gathered[live].float() - dkv_f[live].float()).abs().max().item() < 2e-2 * max(1.0, sk)
+
+
 def test_c_abi_from_two_threads():
     """nn.DataParallel (the reference's shipped default, base_trainer.py:121-126) calls forward from one Python thread per
     replica: the C ABI keeps no global mutable state and its error string is thread-local.  Two threads hammer different

@@ -125,6 +125,7 @@ def attn_fwd(qkv, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, kv=None):
 # rounds 2-3 (dQ then differs in its last fp32 bits from run to run).
 ATTN_BWD_FUSED = os.environ.get("T2S_ATTN_BWD_FUSED", "1") != "0"
 ATTN_BWD_FUSED_MIN_KEYS = 2048
+ATTN_BWD_FUSED_MIN_ROWS = 1024
 ATTN_BWD_DQ_MODE = 0 if os.environ.get("T2S_ATTN_BWD_DQ", "handoff") == "atomic" else 1
 _KEEP_DQ32 = os.environ.get("T2S_KEEP_DQ32", "0") == "1"     # tools/fused_stamps.py: keep the workspace, whose tail holds the diagnostic
 _LAST_DQ32 = None                                             # build's cycle stamps (otherwise it is freed with the call: 2 GB at B=64)
@@ -140,6 +141,29 @@ def fused_handoff_status():
     return int(_LAST_FUSED_WS.view(torch.int32)[FUSED_CTRL_STATUS_WORD].item())
 
 
+def _fused_policy(fused, qkv, keys, L, mode):
+    """Which backward form a call takes when the caller does not say.  With the ordered hand-off (dq_mode 1, the default) the fused
+    five-product kernel wins at EVERY key count of a long query sequence - B = 64, L = 10 132: 3.2 vs 4.6 ms at 75 keys, 6.0 vs 8.5 at 550,
+    15.1 vs 19.4 at 1 939 (profiles/r04_light_launches.txt) - so the pos / neg passes' short lists take it too.  With fp32 atomics it only
+    pays once the list is long (the round 2-3 rule: a static key bound of >= 2 048), and sequences of a few rows (text_bert: 20) stay on
+    the two-kernel form (a 147 KB-LDS workgroup per (sample, head) for one query tile)."""
+    if fused is None:
+        fused = ATTN_BWD_FUSED and (keys.cap_hint >= ATTN_BWD_FUSED_MIN_KEYS or (mode == 1 and L >= ATTN_BWD_FUSED_MIN_ROWS))
+    return bool(fused) and qkv.dtype == torch.bfloat16
+
+
+def _call_fused(head, klist3, tail, B, L, mode, device):
+    # workspace: control words, hand-off flags and the fp32 dQ sums (either form); cleared as needed inside the call
+    global _LAST_FUSED_WS, _LAST_DQ32
+    nbytes = int(X.lib().t2s_attn_bwd_fused_workspace_bytes(B, HEADS, L))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    if _KEEP_DQ32:
+        _LAST_DQ32 = ws
+    X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(ws), nbytes, mode, *klist3, *tail), "t2s_attn_bwd_fused")
+    # keep the 256-byte control block only (a copy enqueued behind the kernels), not the 2 GB workspace
+    _LAST_FUSED_WS = ws[:64].clone()
+
+
 def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, fused=None, kv=None, dq_mode=None):
     """Returns dqkv [B, L, 2304] (rows of keys outside the key list get exact zeros in the K/V thirds); with ``kv`` (see
     attn_fwd) returns (dq [B, L, 768], dkv [B, capK, 1536]) - the two-kernel form, positions behind a sample's list zero."""
@@ -148,16 +172,23 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     assert out.is_contiguous() and dout.is_contiguous() and out.shape == (B, L, HID) and dout.shape == (B, L, HID)
     assert lse.shape == (B, HEADS, L) and lse.is_contiguous()
     _check_keys(keys, B, L)
+    mode = ATTN_BWD_DQ_MODE if dq_mode is None else int(dq_mode)
     if kv is not None:
         q, k, v = _split_views(qkv, kv, keys)
         dq_, dkv = torch.empty_like(qkv), torch.zeros_like(kv)
         delta = torch.empty_like(lse)
-        LAST_ATTN_BWD_PRODUCTS = 7
-        X.check(X.lib().t2s_attn_bwd(X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(dout), X.ptr(lse), X.ptr(delta),
-                                     X.ptr(dq_), X.ptr(dkv[..., :HID]), X.ptr(dkv[..., HID:]), X.ptr(keys.idx), X.ptr(keys.cnt),
-                                     B, HEADS, L, keys.idx.shape[1], keys.n_dec, keys.dec_q0, keys.cap_hint,
-                                     q.stride(1), q.stride(0), k.stride(1), k.stride(0), out.stride(1), out.stride(0),
-                                     scale, X.dtype_code(qkv), float(drop_p), int(drop_seed), X.stream()), "t2s_attn_bwd")
+        args = (B, HEADS, L, keys.idx.shape[1], keys.n_dec, keys.dec_q0, keys.cap_hint,
+                q.stride(1), q.stride(0), k.stride(1), k.stride(0), out.stride(1), out.stride(0),
+                scale, X.dtype_code(qkv), float(drop_p), int(drop_seed), X.stream())
+        head = (X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(dout), X.ptr(lse), X.ptr(delta),
+                X.ptr(dq_), X.ptr(dkv[..., :HID]), X.ptr(dkv[..., HID:]))
+        if _fused_policy(fused, qkv, keys, L, mode):
+            # the compact key buffer through the fused form (dk / dv rows behind a sample's list stay the zeros written above)
+            LAST_ATTN_BWD_PRODUCTS = 5
+            _call_fused(head, (X.ptr(keys.idx), X.ptr(keys.cnt), None), args, B, L, mode, qkv.device)
+        else:
+            LAST_ATTN_BWD_PRODUCTS = 7
+            X.check(X.lib().t2s_attn_bwd(*head, X.ptr(keys.idx), X.ptr(keys.cnt), *args), "t2s_attn_bwd")
         return dq_, dkv
     q, k, v = _attn_views(qkv)
     cap = keys.idx.shape[1]
@@ -176,26 +207,11 @@ def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0
     dims = (B, HEADS, L, cap, keys.n_dec, keys.dec_q0, keys.cap_hint,
             qkv.stride(1), qkv.stride(0), qkv.stride(1), qkv.stride(0), out.stride(1), out.stride(0),
             scale, X.dtype_code(qkv))
-    # default policy: the fused form for launches that may see most of the sequence as keys; launches with a small static key
-    # bound (the pos / neg passes: <= 537 / 62 keys) stay on the two-kernel form, whose 128-key blocks and two waves per SIMD
-    # suit a handful of keys better than 384-key blocks at one wave per SIMD (tools/attn_probe.py: 0.88 vs 1.9 ms at 516 keys, B=8)
-    if fused is None:
-        fused = ATTN_BWD_FUSED and keys.cap_hint >= ATTN_BWD_FUSED_MIN_KEYS
-    use_fused = fused and qkv.dtype == torch.bfloat16
+    use_fused = _fused_policy(fused, qkv, keys, L, mode)
     LAST_ATTN_BWD_PRODUCTS = 5 if use_fused else 7
     if use_fused:
-        # workspace: control words, hand-off flags and the fp32 dQ sums (either form); cleared as needed inside the call
-        global _LAST_FUSED_WS, _LAST_DQ32
-        nbytes = int(X.lib().t2s_attn_bwd_fused_workspace_bytes(B, HEADS, L))
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
-        mode = ATTN_BWD_DQ_MODE if dq_mode is None else int(dq_mode)
-        if _KEEP_DQ32:
-            _LAST_DQ32 = ws
-        X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(ws), nbytes, mode, *klist, X.ptr(keys.valid8) if fill_in_kernel else None, *dims,
-                                           float(drop_p), int(drop_seed), X.stream()),
-                "t2s_attn_bwd_fused")
-        # keep the 256-byte control block only (a copy enqueued behind the kernels), not the 2 GB workspace
-        _LAST_FUSED_WS = ws[:64].clone()
+        _call_fused(head, (*klist, X.ptr(keys.valid8) if fill_in_kernel else None), (*dims, float(drop_p), int(drop_seed), X.stream()), B, L, mode,
+                    qkv.device)
     elif fill_in_kernel:
         X.check(X.lib().t2s_attn_bwd_fill(*head, *klist, X.ptr(keys.valid8), *dims, float(drop_p), int(drop_seed), X.stream()), "t2s_attn_bwd_fill")
     else:
