@@ -78,13 +78,15 @@ class AttnTimer:
             if dense >= min_flops:
                 vis = float((cnt.sum() + cnt.numel() * nd).item())
                 alg = 2.0 * products * 12 * 64 * L * vis
-                big.append((a.elapsed_time(b) * 1e-3, dense, alg, alg * executed / products, executed))
+                big.append((a.elapsed_time(b) * 1e-3, dense, alg, alg * executed / products, executed, vis / max(1, cnt.numel())))
         if not big:
             return None
         t, f, fx, fe = sum(x[0] for x in big), sum(x[1] for x in big), sum(x[2] for x in big), sum(x[3] for x in big)
         fused = [x for x in big if x[4] == 5]
         tf = sum(x[0] for x in fused)
-        return dict(launches=len(big), avg_ms=1e3 * t / len(big), tflops_dense=f / t / 1e12, tflops=fx / t / 1e12, tflops_executed=fe / t / 1e12,
+        long_ = [x for x in big if x[5] >= 2048]          # launches whose lists average >= 2 048 keys (the ref pass and QTV)
+        return dict(long_launches=len(long_), long_avg_ms=(1e3 * sum(x[0] for x in long_) / len(long_)) if long_ else None,
+                    launches=len(big), avg_ms=1e3 * t / len(big), tflops_dense=f / t / 1e12, tflops=fx / t / 1e12, tflops_executed=fe / t / 1e12,
                     total_ms=1e3 * t, fused_launches=len(fused), fused_avg_ms=(1e3 * tf / len(fused)) if fused else None,
                     fused_tflops=(sum(x[2] for x in fused) / tf / 1e12) if fused else None)
 
@@ -513,15 +515,18 @@ def main():
                      "traffic_over_algorithmic": (traffic.get("attn_bwd") / alg_bwd) if traffic.get("attn_bwd") else None,
                      "launches": att_b["launches"], "fused_5_product_launches": att_b["fused_launches"], "avg_launch_ms": att_b["avg_ms"],
                      "fused_avg_launch_ms": att_b["fused_avg_ms"], "fused_achieved": att_b["fused_tflops"],
+                     "long_list_launches": att_b["long_launches"], "long_list_avg_launch_ms": att_b["long_avg_ms"],
                      "ms_per_step": att_b["total_ms"] / args.steps, "achieved_executed": att_b["tflops_executed"],
                      "note": "achieved = ALGORITHMIC backward FLOPs over the visible keys (5 products: 10*12*64*L*sum_b(visible keys) per "
                              "launch) / HIP-event time around ops.attn_bwd; achieved_executed counts the products the kernels really "
                              "run (7 per (query, key) pair in the two-kernel form, which recomputes S and dP; 5 in the fused form); "
                              "fused_avg_launch_ms / fused_achieved: the launches that took the fused form alone (their group in a rocprofv3 "
-                             "kernel trace: attn_delta_prep + attn_bwd_fused<.,0,.> + attn_bwd_fused<.,1,.> + attn_dq_cast); "
+                             "kernel trace: attn_delta_prep + attn_bwd_fused<.,3,.>; with the dQ hand-off every launch of a long sequence, "
+                             "the short lists of the pos / neg passes included); long_list_avg_launch_ms: the launches whose lists average "
+                             ">= 2 048 keys (the ref pass and QTV: the 45 ms launches); "
                              "mfma_busy: SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle of the fused kernel alone (profiles/mfma_busy.json); "
                              "traffic_over_algorithmic: PMC bytes per launch / (Q, K, V, O, dO read + dQ, dK, dV written once) - the "
-                             "fp32 dQ atomics of the fused form are the excess (DESIGN section 5)"}
+                             "running fp32 dQ sums every key block reads and writes are the excess (DESIGN section 5)"}
     # `roofline` = the dominant kernel group of the step (the attention backward in a train step, the forward otherwise)
     if bwd_block is not None:
         res["roofline"], res["roofline_fwd"] = bwd_block, fwd_block
