@@ -2,8 +2,9 @@
 //
 // The two-kernel form (attn_dkdv_bf16.hip + attn_dq_bf16_kernel) needs no cross-workgroup sum but computes S = Q K^T and
 // dP = dO V^T twice: 7 products.  Here ONE key-stationary kernel computes S and dP once and also forms dQ += dS K; what it
-// costs is a sum of dQ across the key blocks of a (sample, head), done with fp32 atomics.  Sizing that sum decides the
-// geometry (cdna_hip_programming.md Guideline 12, MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s chip-wide):
+// costs is a sum of dQ across the key blocks of a (sample, head) - by an ordered hand-off of running sums (round 4, the shipped
+// form) or with fp32 atomics (rounds 2-3, dq_mode 0): "dQ across the key blocks" below.  The atomic form sized the geometry
+// (cdna_hip_programming.md Guideline 12, MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s chip-wide):
 // a workgroup of KB keys adds a [q-tile x 64] fp32 tile per query tile = 256 B per query row per 10*64*KB FLOPs, i.e.
 // 2.5 * KB FLOP per atomic byte.  KB = 128 (the dK/dV kernel's block) caps the kernel at 0.42 PFLOP/s, below what the
 // two-kernel form already reaches; KB = 384 puts the cap at 1.25 PFLOP/s.  So: 4 waves, ONE wave per SIMD with the whole
@@ -17,8 +18,8 @@
 // the MFMA C operand), dV^T += dO^T P, dK^T += Q^T dS with P / dS straight from the accumulators (key on the lane), dS
 // also stored transposed into the dS^T image (8 bytes per lane per 4 registers);  barrier;  phase B: wave w owns the
 // 32 x 32 tile (query sub-block w >> 1, dim block w & 1) of dQ = dS K over ALL 384 keys (both operands by
-// ds_read_b64_tr_b16 from the two images) and adds it to the fp32 dQ buffer: each accumulator register is two 128-byte
-// row segments, the shape the atomics run at full rate for.
+// ds_read_b64_tr_b16 from the two images) and adds it to the running sum of the pair's earlier key blocks (hand-off) or to the fp32
+// dQ buffer (atomics: each accumulator register is two 128-byte row segments, the shape the atomics run at full rate for).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -56,7 +57,9 @@ constexpr int FB_SMEM_TOTAL = FB_SMEM + FB_SUMS;
 //   A block only ever waits for a block with a SMALLER ticket: workgroups draw their (pair, block) from a per-XCD-group ticket
 //   counter (atomic add) in the order they start running, so the block waited for has started, whatever order the hardware
 //   dispatches workgroup ids in: no deadlock by construction; the spin is bounded all the same and a timeout is reported in
-//   status[0] (the sweep then finishes without waiting: wrong dQ, never a hang).
+//   status[0] (the sweep then finishes without waiting: wrong dQ, never a hang).  The tickets number the key blocks that EXIST
+//   (FbWork.slots, built by the prep kernel from the key counts), not the [pairs][static bound] rectangle the grid is sized by:
+//   the workgroups without a block start last (tools/fused_timeline.py: with them between the chains the CUs were 90 % busy).
 struct FbWork {
   float* part;            // hand-off: running sums [B H][nqt][4 quadrants][4 register groups][64 lanes] x 16 B; atomic form: dq32 [B Lq, H 64]
   unsigned* flags;        // [B H][nqt]
