@@ -91,6 +91,9 @@ constexpr size_t FB_DBG_BYTES = 16384;
 #ifndef FB_SDWA
 #define FB_SDWA 1
 #endif
+#ifndef FB_MASK_SKEW
+#define FB_MASK_SKEW 1      // (needs FB_SDWA; 0: the keep word of a chunk formed by three dependent instructions in its own group)
+#endif
 // Hand-off experiment, built and measured, NOT shipped (-DFB_HO_PREFETCH=1; needs FB_DMA): the predecessor's running sum of tile t+1
 // fetched by LDS-DMA into a 16 KB LDS region at the END of tile t (its flag checked one tile ahead), landing under phase A of tile t+1
 // and read back from LDS behind phase B - instead of four register loads issued ahead of the barrier, whose memory latency phase B
@@ -228,7 +231,7 @@ __device__ __forceinline__ void fb_g2(f32x16 (&dvacc)[FB_KB][2], f32x16 (&dkacc)
 // decoder rule - this lane's key is visible to the tile rows >= thr (thr = first visible row - row of register 0 of this lane;
 // register r is row (r & 3) + 8 (r >> 2) above it), so one compare + select per score
 template <int I, int M, bool EDGE, bool DROP>
-__device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], const int thr, uint32_t (&mw)[8], const uint32_t rkw, const uint32_t ck2,
+__device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], const int thr, uint32_t (&mw)[8], const uint32_t (&rkw)[8], const uint32_t ck2,
                                       const uint32_t th2) {
   constexpr int par = I & 1, r0 = 2 * M, r1 = 2 * M + 1;
   float p0 = fast_exp2(sacc[par][r0]), p1 = fast_exp2(sacc[par][r1]);
@@ -240,10 +243,24 @@ __device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], con
   sacc[par][r1] = p1;
   if (DROP) {                                          // registers (2m, 2m+1) are two consecutive queries of this lane's key: one packed mask word
 #if FB_SDWA
-    mw[M] = attn_drop_pair_kept(rkw, ck2, th2);        // 0xFFFF in every KEPT half (th2 = attn_drop_thresh2k)
+    // keep word of chunk M: 0xFFFF in every KEPT half (th2 = attn_drop_thresh2k).  Its three packed instructions (multiply, saturating
+    // subtract, shift) are SKEWED over the chunks of the block - chunk M + 2 is multiplied, M + 1 subtracted and M shifted in one group -
+    // so that no packed instruction stands right behind the one it depends on (each such pair costs an s_nop in an issue-bound gap)
+#if FB_MASK_SKEW
+    if constexpr (M == 0) {
+      mw[0] = attn_drop_kept_mul(rkw[0], ck2); mw[1] = attn_drop_kept_mul(rkw[1], ck2); mw[2] = attn_drop_kept_mul(rkw[2], ck2);
+      mw[0] = attn_drop_kept_sub(mw[0], th2); mw[1] = attn_drop_kept_sub(mw[1], th2);
+    } else {
+      if constexpr (M + 2 < 8) mw[M + 2] = attn_drop_kept_mul(rkw[M + 2], ck2);
+      if constexpr (M + 1 < 8) mw[M + 1] = attn_drop_kept_sub(mw[M + 1], th2);
+    }
+    mw[M] = attn_drop_kept_mask(mw[M]);
+#else
+    mw[M] = attn_drop_pair_kept(rkw[M], ck2, th2);
+#endif
     pfw[M] = fb_pack2(p0, p1) & mw[M];                 // dV uses the dropped one (scaled by 1/(1-p) at the end)
 #else
-    mw[M] = attn_drop_pair_dropped(rkw, ck2, th2);     // 0xFFFF in every dropped half
+    mw[M] = attn_drop_pair_dropped(rkw[M], ck2, th2);  // 0xFFFF in every dropped half
     pfw[M] = attn_drop_apply(fb_pack2(p0, p1), mw[M]);
 #endif
   } else {
@@ -691,7 +708,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   }
 #define FB_G1(i_, m_) fb_g1<i_, m_, DROP>(sacc, dpacc, qf, dof, kf, vf)
 #define FB_G2(i_, m_) fb_g2<i_, m_>(dvacc, dkacc, doT, qT, pfw, dsw)
-#define FB_E(i_, m_) fb_ve<i_, m_, EDGE, DROP>(sacc, pfw, thr[(i_) & 1], mw, rkw[m_], ck2[(i_) % 3], th2)
+#define FB_E(i_, m_) fb_ve<i_, m_, EDGE, DROP>(sacc, pfw, thr[(i_) & 1], mw, rkw, ck2[(i_) % 3], th2)
 #define FB_M(i_, m_) fb_vm<i_, m_, DROP>(sacc, dpacc, dsw, mw, dl[(m_) >> 1][2 * ((m_) & 1)], dl[(m_) >> 1][2 * ((m_) & 1) + 1], drop_inv)
         // slot "G1(n) + E(e)": eight groups of one MFMA of G1(b_n) and one chunk of E(b_e)
 #define FB_SLOT_G1E(n_, e_)                                                                         \

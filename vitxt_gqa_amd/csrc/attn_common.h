@@ -121,6 +121,20 @@ __device__ __forceinline__ uint32_t attn_drop_pair_kept(uint32_t a2, uint32_t b2
   const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, thresh2k), __builtin_bit_cast(s16x2, t));
   return __builtin_bit_cast(uint32_t, d >> 15);
 }
+// the three instructions of attn_drop_pair_kept one by one, for kernels that software-pipeline them over consecutive score pairs
+// (a dependent pair of packed 16-bit instructions back to back costs a wait state: cdna hazard "VALU write with op_sel -> VALU read")
+__device__ __forceinline__ uint32_t attn_drop_kept_mul(uint32_t a2, uint32_t b2) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a2) * __builtin_bit_cast(u16x2, b2));
+}
+__device__ __forceinline__ uint32_t attn_drop_kept_sub(uint32_t t2, uint32_t thresh2k) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, thresh2k), __builtin_bit_cast(s16x2, t2)));
+}
+__device__ __forceinline__ uint32_t attn_drop_kept_mask(uint32_t d2) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, d2) >> 15);
+}
 __device__ __forceinline__ float attn_drop_keep_lo(float x, uint32_t kword) {
   float r;
   asm("v_and_b32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(x), "v"(kword));
