@@ -131,6 +131,11 @@ __device__ __forceinline__ uint32_t attn_drop_kept_sub(uint32_t t2, uint32_t thr
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, thresh2k), __builtin_bit_cast(s16x2, t2)));
 }
+// (drop form of the middle stage: negative halves = dropped, thresh2s = attn_drop_thresh2s(thresh))
+__device__ __forceinline__ uint32_t attn_drop_dropped_sub(uint32_t t2, uint32_t thresh2s) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, t2), __builtin_bit_cast(s16x2, thresh2s)));
+}
 __device__ __forceinline__ uint32_t attn_drop_kept_mask(uint32_t d2) {
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, d2) >> 15);

@@ -60,6 +60,9 @@ __device__ __forceinline__ void fwd_dma16(fwd_u32x4 rs, uint32_t lds, uint32_t v
 #ifndef T2S_FWD_OCC
 #define T2S_FWD_OCC 2
 #endif
+#ifndef T2S_FWD_MASK_SKEW
+#define T2S_FWD_MASK_SKEW 1      // dropout mask words of a fragment formed stage by stage (0: word by word, the form of rounds 2-3)
+#endif
 template <bool USE_IDX, int QB, bool DROP, bool REPAIR>
 __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnParams p) {
   // [buf][K,V] double buffer, then one pre-scaled (32*QB)-row Q tile per wave
@@ -247,8 +250,16 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                   \
       u32x4 w_ = __builtin_bit_cast(u32x4, f_);                                                     \
       const uint32_t th2_ = attn_drop_thresh2s(p.drop_thresh);                                  \
+      if (T2S_FWD_MASK_SKEW) {   /* the four mask words stage by stage: no packed instruction right behind the one it depends on */ \
+        u32x4 m_;                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) m_[i] = attn_drop_kept_mul(rk2[qb_], ck_s[cbuf_][(kbk_) * 16 + 8 * (s_) + 4 * (i >> 1) + (i & 1) + 2 * lh]); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) m_[i] = attn_drop_dropped_sub(m_[i], th2_);   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) m_[i] = attn_drop_kept_mask(m_[i]);          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) w_[i] = attn_drop_apply(w_[i], m_[i]);        \
+      } else {                                                                                      \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
         w_[i] = attn_drop_apply(w_[i], attn_drop_pair_dropped(rk2[qb_], ck_s[cbuf_][(kbk_) * 16 + 8 * (s_) + 4 * (i >> 1) + (i & 1) + 2 * lh], th2_)); \
+      }                                                                                             \
       f_ = __builtin_bit_cast(bf16x8, w_);                                                          \
     }                                                                                               \
     pf[qb_][kbk_][s_] = f_;                                                                         \
