@@ -551,6 +551,40 @@ def test_attention_bwd_fused_five_products(B, L1, n_dec, keep, drop_p, dq_mode):
         assert (got[..., 768:].double() - two[..., 768:].double()).abs().max().item() < 2e-2 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("dq_mode", [1, 0])
+def test_attention_bwd_of_a_sample_without_keys(dq_mode):
+    """Empty input: one sample of the batch lists NO key (no visible prefix row, no decoder rows).  Its attention output is zero, so
+    every gradient of that sample is exactly zero - in the hand-off form too, where dQ is written by the last key block of a pair and
+    such a sample has none (the prep kernel writes its rows) - and the other sample comes out as when it runs alone."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    B, L = 2, 1100
+    g = torch.Generator().manual_seed(23)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    valid = torch.zeros(B, L, dtype=torch.bool)
+    valid[0, torch.randperm(L, generator=g)[:600]] = True
+    valid = valid.to(DEV)
+    keys = ops.compact_keys(valid)
+    assert keys.cnt.tolist() == [600, 0]
+    out, lse = ops.attn_fwd(x, keys)
+    assert out[1].abs().max().item() == 0
+    poison = torch.full((64 << 20,), float("nan"), device=DEV)        # recycle NaN-filled blocks through the caching allocator
+    del poison
+    got = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=dq_mode)
+    assert dq_mode == 0 or ops.fused_handoff_status() == 0
+    assert torch.isfinite(got.float()).all() and got[1].abs().max().item() == 0
+    two = ops.attn_bwd(x, out, dout, lse, keys, fused=False)
+    assert two[1].abs().max().item() == 0
+    k1 = ops.compact_keys(valid[:1])
+    o1, l1 = ops.attn_fwd(x[:1].contiguous(), k1)
+    alone = ops.attn_bwd(x[:1].contiguous(), o1, dout[:1].contiguous(), l1, k1, fused=True, dq_mode=dq_mode)
+    if dq_mode == 1:
+        assert torch.equal(got[:1], alone)
+    else:
+        assert (got[:1].float() - alone.float()).abs().max().item() <= 2.0 ** -6 * alone.float().abs().max().item()
+
+
 @pytest.mark.parametrize("B", [16, 3])
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
 def test_attention_bwd_fused_handoff_under_uneven_load(drop_p, B):

@@ -1144,7 +1144,8 @@ __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __re
                                                               const uint8_t* __restrict__ row_valid, int valid_len, int dec_q0, int n_dec, int B, int H, int Lq,
                                                               int64_t o_rs, int64_t o_bs, int64_t kv_rs, int64_t kv_bs,
                                                               unsigned* __restrict__ slots, int groups, const int32_t* __restrict__ kv_cnt, int dense_keys,
-                                                              int kblocks) {
+                                                              int kblocks, bf16_t* __restrict__ dq_empty /* hand-off: dq, to zero the rows of a sample WITHOUT keys */,
+                                                              int64_t q_rs, int64_t q_bs) {
   const int lane = threadIdx.x & 63;
   // the fused sweep's ticket table (FbWork.slots): per XCD group the first slot of each of its (sample, head) pairs = running count of
   // the key blocks that exist (the sample's key count, capped by the launch's static bound), then the group's total
@@ -1169,6 +1170,9 @@ __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __re
   const bf16_t* dp = dout + (int64_t)b * o_bs + (int64_t)q * o_rs;
   const int nchunk = H * 16;              // 4-element chunks per row
   float* zrow = dq32 ? dq32 + row * (int64_t)(H * 64) : nullptr;
+  // hand-off form: dQ is written by the LAST key block of a pair; a sample with an empty key list has no block, so its (exactly zero)
+  // dQ rows are written here (the atomic form zero-fills its sum buffer anyway)
+  const bool empty = dq_empty && ((kv_cnt ? kv_cnt[b] : dense_keys) + n_dec) <= 0;
   const bool fill = row_valid && (q < valid_len ? !row_valid[(int64_t)b * valid_len + q] : (q < dec_q0 || q >= dec_q0 + n_dec));
   for (int c0 = 0; c0 < nchunk; c0 += 64) {
     const int ci = c0 + lane;
@@ -1177,6 +1181,7 @@ __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __re
       const f32x4 a = Vec4<bf16_t>::load(op + ci * 4), d = Vec4<bf16_t>::load(dp + ci * 4);
       s = a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
       if (zrow) *reinterpret_cast<f32x4*>(zrow + ci * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (empty) *reinterpret_cast<bf16x4*>(dq_empty + (int64_t)b * q_bs + (int64_t)q * q_rs + ci * 4) = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
       if (fill) {
         const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
         *reinterpret_cast<bf16x4*>(dk + (int64_t)b * kv_bs + (int64_t)q * kv_rs + ci * 4) = z;
@@ -1288,7 +1293,8 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   hipLaunchKernelGGL(attn_delta_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)p.o, (const bf16_t*)p.dout, p.delta,
                      (const float*)p.lse, FB_DMA ? nl : nullptr, nd, (int)(nqt * FB_QROWS), handoff ? nullptr : dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs,
-                     p.kv_rs, p.kv_bs, handoff ? slots : nullptr, (int)groups, p.kv_idx ? p.kv_cnt : nullptr, p.idx_cap - p.n_dec, p.kblocks);
+                     p.kv_rs, p.kv_bs, handoff ? slots : nullptr, (int)groups, p.kv_idx ? p.kv_cnt : nullptr, p.idx_cap - p.n_dec, p.kblocks,
+                     handoff ? (bf16_t*)p.dq : nullptr, p.q_rs, p.q_bs);
   T2S_CHECK_LAUNCH("attn_bwd_fused (delta prep)");
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256), tail(attn_xcd_grid(1, p.H, p.B));
 #define FB_LAUNCH2(IDX_, MODE_, DROP_, grid_)                                                                            \
