@@ -110,7 +110,8 @@ int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, const void* o
  * dk / dv are deterministic either way.  workspace: t2s_attn_bwd_fused_workspace_bytes(B, H, Lq) bytes of device memory, contents
  * on entry irrelevant (the call clears what it needs); word 24 of it (uint32) is a status word: bit 0 set = a bounded spin of
  * the hand-off timed out (cannot happen unless a workgroup died; dq is then wrong but the launch ended).
- * row_valid as for t2s_attn_bwd_fill, or NULL (then the caller zero-fills dk / dv). */
+ * row_valid as for t2s_attn_bwd_fill, or NULL (then the caller zero-fills dk / dv).  A sample whose list is empty (kv_cnt = 0 and
+ * n_dec = 0) gets exactly zero dq rows in either form. */
 int64_t t2s_attn_bwd_fused_workspace_bytes(int B, int H, int Lq);
 int t2s_attn_bwd_fused(const void* q, const void* k, const void* v, const void* out, const void* dout,
                        const float* lse, float* delta, void* dq, void* dk, void* dv,
