@@ -91,9 +91,6 @@ constexpr size_t FB_DBG_BYTES = 16384;
 #ifndef FB_SDWA
 #define FB_SDWA 1
 #endif
-#ifndef FB_LDS_EARLY
-#define FB_LDS_EARLY 1      // row keys / row constants of a slot fetched one slot ahead (0: at the head of their own slot, rounds 2-3)
-#endif
 #ifndef FB_MASK_SKEW
 #define FB_MASK_SKEW 1      // (needs FB_SDWA; 0: the keep word of a chunk formed by three dependent instructions in its own group)
 #endif
@@ -715,13 +712,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #define FB_M(i_, m_) fb_vm<i_, m_, DROP>(sacc, dpacc, dsw, mw, dl[(m_) >> 1][2 * ((m_) & 1)], dl[(m_) >> 1][2 * ((m_) & 1) + 1], drop_inv)
         // slot "G1(n) + E(e)": eight groups of one MFMA of G1(b_n) and one chunk of E(b_e)
 #define FB_SLOT_G1E(n_, e_)                                                                         \
-  FB_THR(e_); FB_RK_HERE(e_); FB_DL_EARLY(e_);                                                      \
+  FB_THR(e_); FB_LD_RK(e_);                                                                         \
   FB_G1(n_, 0); FB_E(e_, 0); FB_FENCE(); FB_G1(n_, 1); FB_E(e_, 1); FB_FENCE(); FB_G1(n_, 2); FB_E(e_, 2); FB_FENCE();            \
   FB_G1(n_, 3); FB_E(e_, 3); FB_FENCE(); FB_G1(n_, 4); FB_E(e_, 4); FB_FENCE(); FB_G1(n_, 5); FB_E(e_, 5); FB_FENCE();            \
   FB_G1(n_, 6); FB_E(e_, 6); FB_FENCE(); FB_G1(n_, 7); FB_E(e_, 7); FB_FENCE();
         // slot "G2(i) + M(i)": dV^T MFMAs with two chunks of M each, then the dK^T MFMAs beside the dS^T stores
 #define FB_SLOT_G2M(i_)                                                                             \
-  FB_DL_HERE(i_);                                                                                   \
+  FB_LD_DL(i_);                                                                                     \
   FB_G2(i_, 0); FB_M(i_, 0); FB_M(i_, 1); FB_FENCE(); FB_G2(i_, 1); FB_M(i_, 2); FB_M(i_, 3); FB_FENCE();                        \
   FB_G2(i_, 2); FB_M(i_, 4); FB_FENCE(); FB_G2(i_, 3); FB_M(i_, 5); FB_FENCE();                                                   \
   FB_TICKS(2);                                                                                                                    \
@@ -729,26 +726,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   /* the s = 1 MFMAs that read them: the asm MFMAs get no hazard nops), the seeds of block i + 2 are fetched once the last chunk */     \
   /* has read this block's accumulators, the dS^T stores follow */                                                                   \
   FB_G2(i_, 4); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE(); \
-  FB_G2(i_, 6); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 7); FB_RK_EARLY((i_) + 1); FB_FENCE();
-        // FB_LDS_EARLY (round 4): the row keys of E(e) and the row constants of M(i) are fetched a slot AHEAD of their first use - the
-        // keys in the last (otherwise empty) group of the G2 + M slot before, the constants at the head of the G1 + E slot before -
-        // instead of at the head of their own slot, where the first chunk waited for them behind a queue of fragment loads (LDS
-        // returns in order: s_waitcnt lgkmcnt right in front of the first v_pk_mul / v_fma of the slot, seen in the ISA)
-#if FB_LDS_EARLY
-#define FB_RK_HERE(e_)
-#define FB_RK_EARLY(e_) if ((e_) <= 4) { FB_LD_RK(e_); }
-#define FB_DL_EARLY(e_) FB_LD_DL(e_)
-#define FB_DL_HERE(i_)
-#else
-#define FB_RK_HERE(e_) FB_LD_RK(e_)
-#define FB_RK_EARLY(e_)
-#define FB_DL_EARLY(e_)
-#define FB_DL_HERE(i_) FB_LD_DL(i_)
-#endif
+  FB_G2(i_, 6); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
         if (!PREF) { FB_LD_QF(qb_, dob_, 0); FB_LD_SEEDS(lse_s, del_s, 0); FB_LD_KF(0); }
         FB_FENCE();
         // slot 0: G1(b0), nothing to pair yet; the transposed fragments of sub-block 0 arrive meanwhile
-        FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_RK_EARLY(0); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
+        FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
         FB_TICKS(0);
         FB_LD_KF(1); FB_FENCE();
@@ -782,12 +764,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         FB_SLOT_G1E(5, 4);
         FB_TICKS(1);
         // slot "G2(b4) + M(b4) + E(b5)": E(b5) only behind the dV^T MFMAs of b4, which still read the operand words of P(b4)
-#if FB_LDS_EARLY
-        FB_LD_RK(5);                                         // (E(4) of the slot before was the last reader of the row-key words)
-#endif
         FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_FENCE();
         FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_FENCE();
-        FB_THR(5); FB_RK_HERE(5); FB_DL_EARLY(5);
+        FB_THR(5); FB_LD_RK(5);
         FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 0); FB_E(5, 1); FB_FENCE(); FB_G2(4, 5); FB_E(5, 2); FB_E(5, 3); FB_FENCE();
         FB_G2(4, 6); FB_E(5, 4); FB_E(5, 5); FB_FENCE(); FB_G2(4, 7); FB_E(5, 6); FB_E(5, 7); FB_FENCE();
         FB_TICKS(4);
@@ -796,10 +775,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_THR
 #undef FB_LD_RK
 #undef FB_LD_DL
-#undef FB_RK_HERE
-#undef FB_RK_EARLY
-#undef FB_DL_EARLY
-#undef FB_DL_HERE
 #undef FB_LD_QT
 #undef FB_ST_DS
 #undef FB_G1
