@@ -60,6 +60,9 @@ __device__ __forceinline__ void fwd_dma16(fwd_u32x4 rs, uint32_t lds, uint32_t v
 #ifndef T2S_FWD_OCC
 #define T2S_FWD_OCC 2
 #endif
+#ifdef T2S_FWD_TIMELINE   // diagnostic build only (tools/fwd_timeline.py): start / end of every workgroup on the 100 MHz real-time counter
+__device__ unsigned long long* t2s_fwd_tl = nullptr;
+#endif
 #ifndef T2S_FWD_MASK_SKEW
 #define T2S_FWD_MASK_SKEW 1      // dropout mask words of a fragment formed stage by stage (0: word by word, the form of rounds 2-3)
 #endif
@@ -71,6 +74,9 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
   constexpr int BQ = 128 * QB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   int qblk, h, b;
+#ifdef T2S_FWD_TIMELINE
+  const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (!attn_xcd_tile((p.Lq + BQ - 1) / BQ, p.H, p.B, qblk, h, b)) return;       // workgroup-uniform
   const int q0 = qblk * BQ + wave * (32 * QB);
   if (REPAIR) {   // only workgroups holding a poisoned row (LSE = NaN) do anything
@@ -473,6 +479,19 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
     }
     if (qb + 1 < QB) __syncthreads();
   }
+#ifdef T2S_FWD_TIMELINE
+  if (!REPAIR && t2s_fwd_tl && lane == 0 && blockIdx.x < 262144u) {
+    unsigned long long* tl = t2s_fwd_tl + (size_t)blockIdx.x * 4;
+    atomicMax(tl + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());      // the LAST wave's end
+    if (wave == 0) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+      tl[0] = tl_r0;
+      tl[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+      tl[3] = (unsigned long long)(unsigned)qblk | ((unsigned long long)(unsigned)b << 16) | ((unsigned long long)(unsigned)h << 32) | ((unsigned long long)(unsigned)nk << 40);
+    }
+  }
+#endif
 }
 
 template <bool DROP, bool REPAIR>
@@ -509,3 +528,10 @@ void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st) {
     else launch_fwd<false, true>(p, st);
   }
 }
+
+#ifdef T2S_FWD_TIMELINE
+extern "C" int t2s_dbg_fwd_timeline(void* buf) {
+  unsigned long long* b = reinterpret_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(t2s_fwd_tl), &b, sizeof(b)) == hipSuccess ? 0 : 1;
+}
+#endif
