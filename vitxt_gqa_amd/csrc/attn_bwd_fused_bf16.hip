@@ -91,14 +91,6 @@ constexpr size_t FB_DBG_BYTES = 16384;
 #ifndef FB_SDWA
 #define FB_SDWA 1
 #endif
-#ifndef FB_SLOT0
-#define FB_SLOT0 1          // fence behind the first MFMA of a tile (0: the compiler hoists 20 LDS loads above it and must drain six of them)
-#endif
-#if FB_SLOT0
-#define FB_SLOT0_FENCE() FB_FENCE()
-#else
-#define FB_SLOT0_FENCE()
-#endif
 #ifndef FB_MASK_SKEW
 #define FB_MASK_SKEW 1      // (needs FB_SDWA; 0: the keep word of a chunk formed by three dependent instructions in its own group)
 #endif
@@ -738,10 +730,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         if (!PREF) { FB_LD_QF(qb_, dob_, 0); FB_LD_SEEDS(lse_s, del_s, 0); FB_LD_KF(0); }
         FB_FENCE();
         // slot 0: G1(b0), nothing to pair yet; the transposed fragments of sub-block 0 arrive meanwhile
-        // (the fence behind the first MFMA: without it the compiler issues the 20 LDS loads below AHEAD of that MFMA, and with more than 15
-        // LDS operations outstanding - all the 4-bit lgkmcnt can count - the MFMA's own, long-arrived operands can only be waited for by
-        // draining the first six of the new loads: s_waitcnt lgkmcnt(14) at the top of every tile, seen in the ISA)
-        FB_G1(0, 0); FB_SLOT0_FENCE(); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
+        FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
         FB_TICKS(0);
         FB_LD_KF(1); FB_FENCE();
