@@ -234,7 +234,15 @@ template <int I, int M, bool EDGE, bool DROP>
 __device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], const int thr, uint32_t (&mw)[8], const uint32_t (&rkw)[8], const uint32_t ck2,
                                       const uint32_t th2) {
   constexpr int par = I & 1, r0 = 2 * M, r1 = 2 * M + 1;
+#if defined(FB_ABL) && (FB_ABL & 16)   // timing-only diagnostic build (results wrong): a plain multiply in place of each v_exp_f32 - what the exponentials cost
+  float p0 = sacc[par][r0] * 1.0001f, p1 = sacc[par][r1] * 1.0001f;
+#elif defined(FB_ABL) && (FB_ABL & 32) // timing-only: the two exponentials of a chunk kept apart by an empty asm (is a v_exp_f32 dearer right behind another one?)
+  float p0 = fast_exp2(sacc[par][r0]);
+  asm volatile("" : "+v"(p0));
+  float p1 = fast_exp2(sacc[par][r1]);
+#else
   float p0 = fast_exp2(sacc[par][r0]), p1 = fast_exp2(sacc[par][r1]);
+#endif
   if (EDGE) {
     p0 = ((r0 & 3) + 8 * (r0 >> 2)) >= thr ? p0 : 0.f;
     p1 = ((r1 & 3) + 8 * (r1 >> 2)) >= thr ? p1 : 0.f;
