@@ -219,8 +219,8 @@ def test_attn_bwd_fill_equals_zero_fill_path_full_length():
     # the fused five-product form: equal between its two fill paths BIT FOR BIT - dK / dV always were, dQ is since its sum across
     # the key blocks runs as the ordered hand-off (round 4) - and within bf16 rounding of the two-kernel form; the atomic dQ sum of
     # rounds 2-3 (dq_mode 0) equals the hand-off's to summation-order noise
-    fa = ops.attn_bwd(x, out, dout, lse, keys, fused=True)
-    fb = ops.attn_bwd(x, out, dout, lse, plain, fused=True)
+    fa = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1)
+    fb = ops.attn_bwd(x, out, dout, lse, plain, fused=True, dq_mode=1)
     assert ops.fused_handoff_status() == 0
     assert torch.equal(fa, fb)
     sc = a.float().abs().max().item()
