@@ -63,17 +63,6 @@ __device__ __forceinline__ void fwd_dma16(fwd_u32x4 rs, uint32_t lds, uint32_t v
 #ifdef T2S_FWD_TIMELINE   // diagnostic build only (tools/fwd_timeline.py): start / end of every workgroup on the 100 MHz real-time counter
 __device__ unsigned long long* t2s_fwd_tl = nullptr;
 #endif
-// dropout: which wave hashes the 32 column-key pairs of tile t (~190 cycles of quarter-rate 32-bit multiplies per tile).  Always wave 0
-// (rounds 2-3) put that work on SIMD 0 for BOTH workgroups of a CU - the one SIMD of a VALU-bound kernel with ~7 % more to issue; the
-// tiles' turn goes round the four waves instead (T2S_FWD_CK_ROT=0: wave 0 always)
-#ifndef T2S_FWD_CK_ROT
-#define T2S_FWD_CK_ROT 1
-#endif
-#if T2S_FWD_CK_ROT
-#define T2S_FWD_CK_WAVE(t_) ((t_) & 3)
-#else
-#define T2S_FWD_CK_WAVE(t_) 0
-#endif
 #ifndef T2S_FWD_MASK_SKEW
 #define T2S_FWD_MASK_SKEW 1      // dropout mask words of a fragment formed stage by stage (0: word by word, the form of rounds 2-3)
 #endif
@@ -162,12 +151,10 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
   const int sr = tid >> 3, sc = tid & 7;
   uint4 kr0, kr1, vr0, vr1;
   uint32_t ckreg = 0;
-  bool ck_mine = false;
   // dropout: column keys of key pair `tid` of tile t_ (threads 0..31), staged beside the K/V tile
 #define CK_LOAD(t_)                                                                                 \
-  ck_mine = DROP && T2S_FWD_CK_WAVE(t_) == wave && lane < 32;                                       \
-  if (ck_mine) {                                                                                    \
-    const int kp_ = (t_) * BK + 2 * lane;                                                           \
+  if (DROP && tid < 32) {                                                                           \
+    const int kp_ = (t_) * BK + 2 * tid;                                                            \
     ckreg = attn_drop_colkey16(salt, kp_, (qblk * BQ) / ATTN_DROP_QWIN) | (attn_drop_colkey16(salt, kp_ + 1, (qblk * BQ) / ATTN_DROP_QWIN) << 16); /* (BQ divides the window) */ \
   }
   // key-list lookups run one tile ahead of the row loads that depend on them (otherwise every tile waits out a full
@@ -225,7 +212,7 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
 #define STAGE_WRITE(buf_)      /* the pieces were aimed at dma_buf when they were issued: here they only have to have landed */  \
   {                                                                                                 \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
-    if (ck_mine) ck_s[buf_][lane] = ckreg;                                                          \
+    if (DROP && tid < 32) ck_s[buf_][tid] = ckreg;                                                  \
   }
 #else
 #define STAGE_WRITE(buf_)                                                                           \
@@ -235,7 +222,7 @@ __global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnPar
     *reinterpret_cast<uint4*>(kb_ + TILE_BYTES) = vr0;                                              \
     *reinterpret_cast<uint4*>(kb_ + 4096) = kr1;                                                    \
     *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + 4096) = vr1;                                       \
-    if (ck_mine) ck_s[buf_][lane] = ckreg;                                                          \
+    if (DROP && tid < 32) ck_s[buf_][tid] = ckreg;                                                  \
   }
 #endif
 
