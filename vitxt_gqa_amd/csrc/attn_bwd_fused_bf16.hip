@@ -91,9 +91,6 @@ constexpr size_t FB_DBG_BYTES = 16384;
 #ifndef FB_SDWA
 #define FB_SDWA 1
 #endif
-#ifndef FB_RK_AHEAD
-#define FB_RK_AHEAD 1       // pipelined sweep: a tile's dropout row keys hashed during phase B two tiles ahead (0: inside phase A, rounds 2-3)
-#endif
 #ifndef FB_MASK_SKEW
 #define FB_MASK_SKEW 1      // (needs FB_SDWA; 0: the keep word of a chunk formed by three dependent instructions in its own group)
 #endif
@@ -492,17 +489,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     const uint32_t st_lds = __builtin_amdgcn_readfirstlane(fb_lds_addr(stage));
     const int q_rs2 = __builtin_amdgcn_readfirstlane((int)p.q_rs * 2), o_rs2 = __builtin_amdgcn_readfirstlane((int)p.o_rs * 2);
     int st_buf = 0;               // stage buffer the next FB_STAGE_LOAD fills (uniform)
-    // dropout row keys of the 64-row tile starting at row0_: 32 lanes of wave 0, two keys each (eight quarter-rate 32-bit multiplies:
-    // ~190 cycles of ONE wave's issue time).  Inside phase A - where every wave's vector issue is the limit and the others then
-    // wait for wave 0 at the next barrier - that time is on the tile's critical path; the pipelined sweep computes the keys of tile
-    // t + 2 at the head of phase B of tile t instead (FB_RK_AHEAD), under that phase's LDS waits
-#define FB_RK_HASH(row0_)                                                                       \
-  if (DROP && tid < FB_QROWS / 2) {                                                             \
-    const int qa_ = (row0_) + 2 * tid, qb2_ = qa_ + 1;                                          \
-    rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kbw) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1, kbw) << 16); /* window = this key block */ \
-  }
-#define FB_STAGE_LOAD() FB_STAGE_LOAD_X(1)
-#define FB_STAGE_LOAD_X(hash_)                                                                  \
+#define FB_STAGE_LOAD()                                                                         \
   {                                                                                             \
     const uint32_t dst_ = st_lds + (uint32_t)(st_buf * FB_STAGE + wave_s * 1024);               \
     const int r0_ = ld_row0 + wave_s * 8;                                                       \
@@ -512,7 +499,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     fb_dma16(rs_o, dst_ + FB_TILE + 4096, voff_o, (r0_ + 32) * o_rs2);                          \
     if (wave_s == 0) fb_dma4(rs_nl, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE), lane * 4, ld_row0 * 4);                   \
     if (wave_s == 1) fb_dma4(rs_nd, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE + FB_QROWS * 4), lane * 4, ld_row0 * 4);    \
-    if (hash_) { FB_RK_HASH(ld_row0); }                                                         \
+    if (DROP && tid < FB_QROWS / 2) {                                                           \
+      const int qa_ = ld_row0 + 2 * tid, qb2_ = qa_ + 1;                                        \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kbw) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1, kbw) << 16); /* window = this key block */ \
+    }                                                                                           \
     ld_row0 += FB_QROWS;                                                                        \
   }
     // the DMA pieces of the tile must have landed before the barrier that publishes the buffer: every wave waits for its own
@@ -661,9 +651,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #else
 #define FB_TICKS(k_)
 #endif
-#if FB_DMA && FB_RK_AHEAD
-    if constexpr (FULL) { FB_RK_HASH(FB_QROWS); }            // tile 1's row keys (tile 0's were written with the first stage buffer)
-#endif
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
       if (DROP && (qt & (ATTN_DROP_QWIN / FB_QROWS - 1)) == 0) {      // a new 256-row window of query rows: re-hash this lane's three column keys
@@ -770,11 +757,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         FB_LD_QF(qb_, dob_, 1); FB_LD_KF(0); FB_FENCE();
         FB_SLOT_G2M(1);
         FB_TICKS(3);
-#if FB_DMA && FB_RK_AHEAD
-        FB_STAGE_LOAD_X(0); FB_FENCE();                      // (the row keys of that tile were hashed during phase B of the tile before)
-#else
         FB_STAGE_LOAD(); FB_FENCE();
-#endif
         FB_SLOT_G1E(3, 2);
         FB_TICKS(1);
         FB_LD_KF(1); FB_FENCE();
@@ -924,9 +907,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
           __hip_atomic_store(flags_pair + (qt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // ================= phase B: dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
-#if FB_DMA && FB_RK_AHEAD
-      if constexpr (FULL) { FB_RK_HASH((qt + 2) * FB_QROWS); }   // row keys of tile qt + 2, written with its stage buffer at the end of the next phase A
-#endif
       {
         f32x16 dqacc;
 #pragma unroll
@@ -1121,8 +1101,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     for (int kb = 0; kb < FB_KB; ++kb)
       asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dkacc[kb][0]), "+a"(dkacc[kb][1]), "+a"(dvacc[kb][0]), "+a"(dvacc[kb][1]));
 #undef FB_STAGE_LOAD
-#undef FB_STAGE_LOAD_X
-#undef FB_RK_HASH
 #undef FB_STAGE_WRITE
 #undef FB_SUM_DMA
 #undef FB_FLAG_WAIT
