@@ -178,3 +178,19 @@ def test_compact_key_list_is_clamped_to_its_buffer_when_the_bound_is_violated():
     k2 = KeyList(idx[:1], cnt[:1], n_dec, L1, cap_hint=40 + n_dec)
     k2c, f2, cap2 = k2.compact(L)
     assert cap2 == 64 and k2c.cnt.tolist() == [40] and f2[:52].tolist() == idx[0, :52].long().tolist()
+
+
+def test_backward_form_policy():
+    """ops._fused_policy (which attention-backward form a call takes when the caller does not say): with the ordered hand-off every
+    long sequence takes the fused five-product kernel whatever its key bound (profiles/r04_light_launches.txt); with fp32 atomics only
+    lists bounded at >= 2 048 keys do; short sequences (text_bert: 20 rows) and fp32 never; an explicit choice wins."""
+    import types
+    import torch
+    from vitxt_gqa_amd import ops
+    bf, f32 = torch.empty(1, dtype=torch.bfloat16), torch.empty(1, dtype=torch.float32)
+    k = lambda hint: types.SimpleNamespace(cap_hint=hint)
+    assert ops._fused_policy(None, bf, k(74), 10132, 1) and ops._fused_policy(None, bf, k(10132), 10132, 1)
+    assert not ops._fused_policy(None, bf, k(74), 10132, 0) and ops._fused_policy(None, bf, k(2048), 10132, 0)
+    assert not ops._fused_policy(None, bf, k(20), 20, 1) and not ops._fused_policy(None, bf, k(549), 1000, 1)
+    assert not ops._fused_policy(None, f32, k(10132), 10132, 1) and not ops._fused_policy(True, f32, k(10132), 10132, 1)
+    assert ops._fused_policy(True, bf, k(20), 20, 0) and not ops._fused_policy(False, bf, k(10132), 10132, 1)
