@@ -457,6 +457,52 @@ def test_pruned_kv_backward_takes_the_fused_form(drop_p):
     assert (gathered[live].float() - dkv_f[live].float()).abs().max().item() < 2e-2 * max(1.0, sk)
 
 
+def test_attention_entry_points_refuse_bad_arguments():
+    """Error behaviour of the attention entry points (return code + t2s_last_error, no launch): a fused-backward workspace smaller
+    than t2s_attn_bwd_fused_workspace_bytes says how many bytes are needed; K / V rows that would not fit the kernels' 32-bit
+    offsets (row stride or row count >= 2^24, span >= 4 GB) are refused before anything is launched; kv_idx without kv_cnt is."""
+    _need_gpu()
+    from vitxt_gqa_amd import hipext as X
+    from vitxt_gqa_amd import ops
+    B, L = 1, 256
+    x = torch.randn(B, L, 2304, device=DEV).to(torch.bfloat16)
+    valid = torch.ones(B, L, dtype=torch.bool, device=DEV)
+    keys = ops.compact_keys(valid)
+    out, lse = ops.attn_fwd(x, keys)
+    q, k, v = x[..., :768], x[..., 768:1536], x[..., 1536:]
+    dq = torch.empty_like(x)
+    delta = torch.empty_like(lse)
+    ws = torch.empty(1024, dtype=torch.float32, device=DEV)
+    need = int(X.lib().t2s_attn_bwd_fused_workspace_bytes(B, 12, L))
+    assert need > ws.numel() * 4
+    rc = X.lib().t2s_attn_bwd_fused(X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(out), X.ptr(out), X.ptr(lse), X.ptr(delta),
+                                    X.ptr(dq[..., :768]), X.ptr(dq[..., 768:1536]), X.ptr(dq[..., 1536:]), X.ptr(ws), ws.numel() * 4, 1,
+                                    X.ptr(keys.idx), X.ptr(keys.cnt), None, B, 12, L, keys.idx.shape[1], 0, 0, keys.cap_hint,
+                                    x.stride(1), x.stride(0), x.stride(1), x.stride(0), out.stride(1), out.stride(0),
+                                    0.125, X.dtype_code(x), 0.0, 0, X.stream())
+    assert rc != 0
+    with pytest.raises(RuntimeError, match="workspace of 4096 bytes, %d needed" % need):
+        X.check(rc, "t2s_attn_bwd_fused")
+
+    def fwd(kv_rs, idx=keys.idx, cnt=keys.cnt):
+        o2, l2 = torch.empty_like(out), torch.empty_like(lse)
+        return X.lib().t2s_attn_fwd(X.ptr(q), X.ptr(k), X.ptr(v), X.ptr(o2), X.ptr(l2), X.ptr(idx) if idx is not None else None,
+                                    X.ptr(cnt) if cnt is not None else None, B, 12, L, keys.idx.shape[1], 0, 0,
+                                    x.stride(1), x.stride(0), kv_rs, x.stride(0), out.stride(1), out.stride(0),
+                                    0.125, X.dtype_code(x), 0.0, 0, X.stream())
+    assert fwd(x.stride(1)) == 0
+    for bad in (1 << 24, 1 << 22):                       # stride too wide for a 24-bit multiply; 256 rows x 2^22 x 4 B = 4 GB
+        rc = fwd(bad)
+        assert rc != 0
+        with pytest.raises(RuntimeError, match="span < 4 GB"):
+            X.check(rc, "t2s_attn_fwd")
+    rc = fwd(x.stride(1), idx=keys.idx, cnt=None)
+    assert rc != 0
+    with pytest.raises(RuntimeError, match="kv_idx and kv_cnt"):
+        X.check(rc, "t2s_attn_fwd")
+    torch.cuda.synchronize()
+
+
 def test_c_abi_from_two_threads():
     """nn.DataParallel (the reference's shipped default, base_trainer.py:121-126) calls forward from one Python thread per
     replica: the C ABI keeps no global mutable state and its error string is thread-local.  Two threads hammer different
