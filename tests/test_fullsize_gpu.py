@@ -1,5 +1,7 @@
 """Parity at BASELINE.json's full sequence sizes (100 frames x 100 OCR tokens: L = 10 132 rows, 12 heads) through
-size-independent properties - the oracle cannot run these shapes in seconds.  Attention: probabilities sum to one
+size-independent properties (the comparison with the REFERENCE's own outputs at this length - B = 1, fixture full_b1_f100_p100 - is
+tests/test_fulllength_reference_gpu.py; the properties here cover what one sample cannot: B = 64, the 300 x 200 stress shape, ragged
+key lists).  Attention: probabilities sum to one
 (constant V), sampled rows against an fp64 restatement of those rows, masked keys are irrelevant, the dV checksum
 (sum over keys of dV == sum over queries of dO); whole model: the cached greedy decode equals the reference's
 recompute-everything loop, batch-order equivariance, losses against their formulas."""
@@ -133,7 +135,8 @@ def test_model_full_size_cached_decode_and_batch_equivariance():
 # A full TRAIN step at the metric's sequence shapes (BASELINE.json configs[2]: 100 x 100, and configs[4]: 300 x 200): forward
 # through 11 big BERT layers and the three MMT passes, both losses, the hand-written backward (batched wgrad, in-place
 # addmm chains, t2s_attn_bwd_fill inside the model), global-norm clip and Adam - base_trainer.py:251-278, t2s.py:288-354.
-# The oracle cannot run these shapes, so the checks are properties.
+# Reference parity of one sample at 100 x 100 is pinned in tests/test_fulllength_reference_gpu.py; here the checks are properties that hold
+# at any batch size and at the 300 x 200 stress shape (which neither the reference nor the oracle can run in a test's time).
 def _train_step_properties(Fn, Pn, B, V, seed, check_perm):
     from vitxt_gqa_amd import training_config
     from vitxt_gqa_amd.optim import build_optimizer, train_step
