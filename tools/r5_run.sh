@@ -1,0 +1,26 @@
+#!/bin/bash
+# round 5: ONE parametrised GPU-call script (replaces the per-call r4_run_*.sh files).
+#   gpurun --timeout 1200 -- 'bash tools/r5_run.sh <tag> <step> [<step> ...]'
+# steps: fulllen (reference-pinned tests at L = 10 132), suite (whole -m gpu suite), bench (bench line), benchq (bench without cpu baseline),
+#        gemm (own GEMM tests + probe), attn (attention tests + probe), smoke
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r5}; shift
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+set -e
+cd $REPO
+for STEP in "$@"; do
+  echo "=== step $STEP" | tee -a $OUT/steps.log
+  case $STEP in
+    fulllen) timeout -k 10 900 python3 -m pytest tests/test_fulllength_reference_gpu.py -m gpu -x -q -s > $OUT/pytest_fulllen.log 2>&1 || { tail -60 $OUT/pytest_fulllen.log; exit 1; }; tail -30 $OUT/pytest_fulllen.log ;;
+    suite)   timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_suite.log 2>&1 || { tail -60 $OUT/pytest_suite.log; exit 1; }; tail -3 $OUT/pytest_suite.log ;;
+    smoke)   timeout -k 10 300 python3 __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || { tail -30 $OUT/smoke.log; exit 1; }; tail -1 $OUT/smoke.log ;;
+    bench)   timeout -k 10 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -30 $OUT/bench.err; exit 1; }; tail -c 1500 $OUT/bench.json ;;
+    benchq)  timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-dropout0 > $OUT/benchq.json 2> $OUT/benchq.err || { tail -30 $OUT/benchq.err; exit 1; }; tail -c 1200 $OUT/benchq.json ;;
+    gemm)    timeout -k 10 600 python3 -m pytest tests/test_gemm_gpu.py -m gpu -x -q -s > $OUT/pytest_gemm.log 2>&1 || { tail -60 $OUT/pytest_gemm.log; exit 1; }; tail -5 $OUT/pytest_gemm.log
+             timeout -k 10 600 python3 tools/gemm_probe5.py > $OUT/gemm_probe.txt 2>&1 || { tail -40 $OUT/gemm_probe.txt; exit 1; }; cat $OUT/gemm_probe.txt ;;
+    attn)    timeout -k 10 900 python3 -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_dropout_gpu.py -m gpu -x -q > $OUT/pytest_attn.log 2>&1 || { tail -40 $OUT/pytest_attn.log; exit 1; }; tail -2 $OUT/pytest_attn.log
+             timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 0.1 > $OUT/attn_probe.txt 2>&1 || { tail -30 $OUT/attn_probe.txt; exit 1; }; cut -c1-200 $OUT/attn_probe.txt ;;
+    *) echo "unknown step $STEP"; exit 2 ;;
+  esac
+done
