@@ -457,8 +457,8 @@ def main():
     }
     if not args.forward_only:
         from vitxt_gqa_amd import ops as _ops
-        # how the fused attention backward sums dQ across key blocks, and the status word of its last call (0: no bounded spin of the
-        # hand-off ever timed out; read here, behind the timed region's synchronisation)
+        # how the fused attention backward sums dQ across key blocks, and the OR of the status words of EVERY call of the run (0: no
+        # bounded spin of the hand-off ever timed out; read here, behind the timed region's synchronisation)
         res["attn_bwd_dq"] = {"mode": "ordered hand-off (bit-reproducible)" if _ops.ATTN_BWD_DQ_MODE == 1 else "fp32 atomics",
                               "status": _ops.fused_handoff_status()}
         res["loss"] = float(last.detach())

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2S_ABI_VERSION 5
+#define T2S_ABI_VERSION 6
 #define T2S_F32 0
 #define T2S_BF16 1
 #define T2S_HEAD_DIM 64
@@ -109,7 +109,10 @@ int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, const void* o
  *   0  fp32 atomics into a [B, Lq, H*64] buffer + a cast pass (rounds 2-3): dq depends on arrival order in its last bits.
  * dk / dv are deterministic either way.  workspace: t2s_attn_bwd_fused_workspace_bytes(B, H, Lq) bytes of device memory, contents
  * on entry irrelevant (the call clears what it needs); word 24 of it (uint32) is a status word: bit 0 set = a bounded spin of
- * the hand-off timed out (cannot happen unless a workgroup died; dq is then wrong but the launch ended).
+ * the hand-off timed out (cannot happen unless a workgroup died).  The launch still ends, and the dq rows of that (sample, head)
+ * pair are NaN from the timed-out block on - never a silently wrong number; t2s_status_accumulate / t2s_status_gate below carry
+ * the word to the optimizer step.  dq_mode 0x101 (tests only): the hand-off with a dead predecessor - no block publishes, every
+ * successor's wait times out at once.
  * row_valid as for t2s_attn_bwd_fill, or NULL (then the caller zero-fills dk / dv).  A sample whose list is empty (kv_cnt = 0 and
  * n_dec = 0) gets exactly zero dq rows in either form. */
 int64_t t2s_attn_bwd_fused_workspace_bytes(int B, int H, int Lq);
@@ -306,11 +309,48 @@ int t2s_fasttext_rows(const float* table, int64_t table_rows, int dim, const int
  * HOST array of n_groups <= 8 learning rates; step: 1-based Adam step count (bias corrections); norm_coef may be NULL for
  * t2s_adam_step (no clipping); write_grad != 0 writes the clipped gradients back (the reference clips p.grad in place). */
 int t2s_optim_chunk_elems(void);
+/* Sticky status of a train step: t2s_status_accumulate ORs uint32 word `word` of a launch's workspace (T2S_FUSED_STATUS_WORD of the
+ * fused attention backward's) into sticky[0] and counts the launch in sticky[1] (sticky: 2+ uint32 of device memory the caller
+ * keeps and zeroes); t2s_status_gate, enqueued between t2s_clip_coef and t2s_adam_step, makes the step a no-op when sticky[0] != 0:
+ * norm_coef = (NaN, -1) and t2s_adam_step returns without touching parameters, moments or gradients. */
+#define T2S_FUSED_STATUS_WORD 24
+int t2s_status_accumulate(const void* workspace, int word, void* sticky, t2s_stream_t stream);
+int t2s_status_gate(const void* sticky, float* norm_coef, t2s_stream_t stream);
 int t2s_grad_sqnorm(const int64_t* desc, const int32_t* chunks, int n_chunks, float* partials, t2s_stream_t stream);
 int t2s_clip_coef(const float* partials, int n_chunks, float max_norm, float* norm_coef, t2s_stream_t stream);
 int t2s_adam_step(const int64_t* desc, const int32_t* chunks, int n_chunks, const int32_t* group_of,
                   const float* group_lr, int n_groups, float beta1, float beta2, float eps, int step,
                   const float* norm_coef, int write_grad, t2s_stream_t stream);
+
+/* ---- own bf16 MFMA GEMMs of the BERT block's linear layers (round 5, vitxt_gqa_amd/csrc/gemm_bf16.hip) -------------------
+ * Replace the torch.nn.Linear calls inside the third-party BertSelfOutput / BertIntermediate / BertOutput the reference runs at
+ * pythia/models/t2s.py:423-427, 538-542, 622-626 - and their autograd gradients, stepped by
+ * pythia/trainers/base_trainer.py:262-272 - where an epilogue a library GEMM cannot fuse pays: bf16 operands, fp32 accumulation,
+ * 256 x 256 x 64 tiles on the 8-phase LDS-DMA pipeline.
+ *
+ * t2s_gemm_nt:  C[M, N] = A[M, K] W[N, K]^T, row strides lda / ldw / ldc (elements; multiples of 8), K a multiple of 128, N of 8.
+ *   epilogue 0  C = bf16(acc + bias)                  (bias [N] bf16 or NULL)                       nn.Linear forward / dgrad
+ *            1  C = bf16(C + bf16(acc))               (the residual branch a LayerNorm backward left in C)
+ *            2  C = bf16(acc * gelu'(u[m, n])), colsum_part[2 * ceil(M / 256)][N] fp32 = column sums of C per 128-row group
+ *               (u [M, N] bf16 row stride ldc = the FFN pre-activation; table = fp32 gelu'(x) of every bf16 bit pattern from
+ *               t2s_gelu_tables): BertIntermediate's GELU backward + the FFN bias gradient folded into the dgrad of BertOutput.dense
+ *            3  C = u = bf16(acc + bias) and g[m, n] = gelu(u) (table = bf16 gelu(x) of every bf16 bit pattern): BertIntermediate
+ *               forward with both the pre-activation (kept for backward) and the activation written by the GEMM
+ * t2s_gemm_nt_colsum_rows(M): rows of colsum_part for epilogue 2.
+ * t2s_gelu_tables: fills fwd_bf16 [65536] bf16 and / or grad_f32 [65536] fp32 with gelu / gelu' (exact erf form, the arithmetic
+ *   of t2s_gelu_fwd / t2s_gelu_bwd) of the bf16 value whose bit pattern is the index. */
+int t2s_gelu_tables(void* fwd_bf16, void* grad_f32, t2s_stream_t stream);
+int t2s_gemm_nt_colsum_rows(int64_t M);
+int t2s_gemm_nt(const void* a, const void* w, const void* bias, void* c, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                int64_t ldc, int epilogue, const void* u, void* g, const void* table, float* colsum_part, t2s_stream_t stream);
+/* t2s_gemm_wgrad:  dw[n_out, n_in] (fp32; += when accumulate) = dy[rows, n_out]^T x[rows, n_in]  (bf16 operands, row strides
+ * ld_dy / ld_x): the weight gradient of a linear layer over all token rows.  The rows are cut into `splits` groups (one
+ * 256 x 256 tile x one group per workgroup), each writes an fp32 slab, a second kernel sums the slabs in group order:
+ * bit-reproducible.  slabs: splits * n_out * n_in floats of workspace.  n_out, n_in multiples of 256.
+ * t2s_gemm_wgrad_splits: the group count that fills the card's CUs once (0: shape not supported). */
+int t2s_gemm_wgrad_splits(int64_t rows, int n_out, int n_in);
+int t2s_gemm_wgrad(const void* dy, const void* x, float* dw, float* slabs, int64_t rows, int n_out, int n_in, int64_t ld_dy,
+                   int64_t ld_x, int splits, int accumulate, t2s_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,34 @@
+"""Host logic of the own GEMM family that needs no GPU: the weight-gradient kernel's workgroup -> (row split, tile) map
+(vitxt_gqa_amd/csrc/gemm_bf16.hip tn_item, mirrored in vitxt_gqa_amd/gemm.py) takes every item exactly once."""
+import itertools
+
+from vitxt_gqa_amd import gemm as G
+
+
+def test_wgrad_workgroup_map_is_a_bijection_onto_the_items():
+    shapes = [1, 2, 3, 4, 9, 12, 27, 31, 32, 33, 36, 48, 64, 100, 144]
+    for T, cus in itertools.product(shapes, (256, 304, 64)):
+        for S in sorted({1, 2, 3, 5, 7, 8, 9, 28, max(1, cus // T), max(1, cus // T) + 3}):
+            c = G.wgrad_grid(T, S, cus)
+            seen = {}
+            for wg in range(8 * c):
+                it = G.wgrad_item(wg, c, T, S)
+                if it is None:
+                    continue
+                assert 0 <= it[0] < S and 0 <= it[1] < T, (T, S, cus, wg, it)
+                assert it not in seen, "item %s taken by workgroups %d and %d (T=%d S=%d c=%d)" % (it, seen[it], wg, T, S, c)
+                seen[it] = wg
+            assert len(seen) == T * S, "T=%d S=%d cus=%d c=%d: %d of %d items taken" % (T, S, cus, c, len(seen), T * S)
+
+
+def test_wgrad_map_keeps_a_row_split_on_one_xcd_for_the_step_shapes():
+    """The point of the map: the workgroups of one XCD (ids equal mod 8) read the same rows.  FFN weights (36 tiles, 7 splits on 256 CUs):
+    XCDs 0..6 hold 32 tiles of ONE split each; QKV (27 tiles, 9 splits): every XCD hosts one whole split."""
+    c = G.wgrad_grid(36, 7)
+    assert c == 32
+    for x in range(7):
+        assert {G.wgrad_item(x + 8 * j, c, 36, 7)[0] for j in range(32)} == {x}
+    c = G.wgrad_grid(27, 9)
+    for x in range(8):
+        hosted = [G.wgrad_item(x + 8 * j, c, 27, 9) for j in range(27)]
+        assert {h[0] for h in hosted} == {x} and sorted(h[1] for h in hosted) == list(range(27))

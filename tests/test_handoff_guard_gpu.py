@@ -1,0 +1,109 @@
+"""Round 5: a timed-out dQ hand-off must be LOUD, and the fused backward's LDS-DMA staging must not depend on
+how the hardware range-checks a scalar buffer offset.
+
+* dq_mode 0x101 is the hand-off with a dead predecessor (no block publishes its flags, spin limit 0): every successor's wait times
+  out at once.  Asserted: the launch ends; the status word is set; the dQ rows of every pair with more than one key block are NaN
+  (never a silently wrong number) while dK / dV stay finite; FusedClipAdam's step on such gradients is a no-op on the device and the
+  NEXT step raises ops.HandoffTimeout; optim.raise_if_handoff_failed() raises at a synchronisation point and clears the word.
+* Lq % 64 != 0 with q / out / dout as views of larger buffers whose bytes right behind the last sample's rows are NaN: the staged rows
+  behind Lq must read as zeros (the tile's row offset rides in the range-checked vector offset): finite gradients, equal to the
+  two-kernel form's."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _case(B=2, L1=1500, n_dec=12, seed=5, frac=0.9):
+    from vitxt_gqa_amd import ops
+    L = L1 + n_dec
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    valid = (torch.rand(B, L1, generator=g) < frac).to(DEV)
+    valid[:, 0] = True
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
+    out, lse = ops.attn_fwd(x, keys)
+    return x, dout, keys, out, lse
+
+
+def test_a_timed_out_handoff_poisons_dq_and_sets_the_sticky_status():
+    from vitxt_gqa_amd import ops, optim
+    ops.reset_fused_status()
+    x, dout, keys, out, lse = _case()
+    good = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1)
+    assert ops.fused_handoff_status() == 0 and torch.isfinite(good.float()).all()
+    bad = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=0x101)
+    torch.cuda.synchronize()
+    assert ops.fused_handoff_status() & 1, "the timeout must reach the sticky status word"
+    dq = bad[..., :768].float()
+    assert torch.isnan(dq).any(), "a chain whose hand-off failed must not hand back numbers"
+    # every pair here has 4 key blocks (1 350 + 12 keys / 384): all of its dQ rows come from the poisoned chain
+    assert torch.isnan(dq).all()
+    assert torch.isfinite(bad[..., 768:].float()).all() and torch.equal(bad[..., 768:], good[..., 768:]), "dK / dV do not depend on the hand-off"
+    with pytest.raises(ops.HandoffTimeout):
+        optim.raise_if_handoff_failed()
+    assert ops.fused_handoff_status() == 0, "raising clears the word"
+    again = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1)
+    assert ops.fused_handoff_status() == 0 and torch.equal(again, good)
+
+
+def test_the_optimizer_step_behind_a_timed_out_handoff_is_a_noop_and_the_next_one_raises():
+    from vitxt_gqa_amd import ops, optim
+    ops.reset_fused_status()
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(300, 768, device=DEV))
+    opt = optim.FusedClipAdam([w], lr=1e-2)
+    w.grad = torch.randn_like(w)
+    opt.step_clipped(0.25)                                   # a clean step moves the parameter
+    torch.cuda.synchronize()
+    w1 = w.detach().clone()
+    m1 = opt.state[w]["exp_avg"].clone()
+    x, dout, keys, out, lse = _case(B=1, L1=1100)
+    ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=0x101)
+    w.grad = torch.full_like(w, float("nan"))               # what such a backward leaves in the gradients
+    norm = opt.step_clipped(0.25)
+    torch.cuda.synchronize()
+    assert torch.isnan(norm), "the reported norm of a gated step is NaN"
+    assert torch.equal(w.detach(), w1) and torch.equal(opt.state[w]["exp_avg"], m1), "the gated step must not touch parameters or moments"
+    assert torch.isnan(w.grad).all()
+    w.grad = torch.randn_like(w)
+    with pytest.raises(ops.HandoffTimeout):
+        opt.step_clipped(0.25)                               # the previous step's status word has reached the host
+    assert ops.fused_handoff_status() == 0
+    opt.step_clipped(0.25)                                   # training could go on (from a checkpoint) once the cause is gone
+    torch.cuda.synchronize()
+    assert not torch.equal(w.detach(), w1) and torch.isfinite(w).all()
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_rows_behind_the_last_sample_are_never_staged(drop_p):
+    from vitxt_gqa_amd import ops
+    ops.reset_fused_status()
+    B, L1, n_dec = 2, 1100 + 37, 12                           # L = 1149: the last query tile holds 61 rows, 3 are behind Lq
+    L = L1 + n_dec
+    assert L % 64 != 0
+    g = torch.Generator().manual_seed(9)
+    pad = 256                                                 # NaN rows right behind each buffer's last sample
+    xb = torch.full((B * L + pad, 2304), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ob = torch.full((B * L + pad, 768), float("nan"), dtype=torch.bfloat16, device=DEV)
+    db = torch.full((B * L + pad, 768), float("nan"), dtype=torch.bfloat16, device=DEV)
+    xb[:B * L] = (torch.randn(B * L, 2304, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    db[:B * L] = torch.randn(B * L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    x, dout = xb[:B * L].view(B, L, 2304), db[:B * L].view(B, L, 768)
+    valid = (torch.rand(B, L1, generator=g) < 0.8).to(DEV)
+    valid[:, 0] = True
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
+    kw = dict(drop_p=drop_p, drop_seed=77) if drop_p else {}
+    o, lse = ops.attn_fwd(x, keys, **kw)
+    ob[:B * L] = o.view(B * L, 768)
+    out = ob[:B * L].view(B, L, 768)
+    assert torch.isnan(xb[B * L:].float()).all() and torch.isnan(ob[B * L:].float()).all()
+    got = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw)
+    torch.cuda.synchronize()
+    assert ops.fused_handoff_status() == 0
+    assert torch.isfinite(got.float()).all(), "a NaN behind the tensors reached the gradients: the rows behind Lq were read"
+    two = ops.attn_bwd(x, out, dout, lse, keys, fused=False, **kw)
+    scale = two.float().abs().max().item()
+    assert (got.float() - two.float()).abs().max().item() < 3e-2 * max(1.0, scale)

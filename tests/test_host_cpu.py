@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(lib):
     raw = ctypes.CDLL(hipext.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.t2s_abi_version() == 5
+    assert lib.t2s_abi_version() == 6
 
 
 def test_argument_validation_reports_errors(lib):

@@ -742,33 +742,6 @@ def test_ocr_encoding_tail_matches_the_framework_ops(dtype, tol, drop_p):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("drop_p", [0.0, 0.1])
-@pytest.mark.parametrize("B,L1,n_dec,keep", [(1, 515, 12, 1.0), (2, 1400, 12, 0.7), (1, 300, 0, 0.9)])
-def test_attention_fwd_one_wave_per_simd_variant(B, L1, n_dec, keep, drop_p, monkeypatch):
-    """The opt-in forward kernel of csrc/attn_fwd_pw_bf16.hip (T2S_ATTN_FWD_PW=1; slower than the shipped one, kept for A/B
-    runs) computes the same attention: the two outputs differ by bf16 roundings only.  (Since round 4 it declines launches with
-    attention dropout - the row key of the mask changes per 384-key window, which its pipeline does not do - and the shipped kernel
-    runs instead: the dropout cases then compare the shipped kernel with itself.)"""
-    _need_gpu()
-    from vitxt_gqa_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(77 + L1)
-    L = L1 + n_dec
-    x = (torch.randn(B, L, 2304, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
-    valid = (torch.rand(B, L1, generator=g) < keep).to(DEV)
-    valid[:, 0] = True
-    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
-    monkeypatch.delenv("T2S_ATTN_FWD_PW", raising=False)
-    out0, lse0 = ops.attn_fwd(x, keys, drop_p=drop_p, drop_seed=4242)
-    monkeypatch.setenv("T2S_ATTN_FWD_PW", "1")
-    out1, lse1 = ops.attn_fwd(x, keys, drop_p=drop_p, drop_seed=4242)
-    torch.cuda.synchronize()
-    assert torch.isfinite(out1).all() and torch.isfinite(lse1).all()
-    # two bf16 ulps of the larger of (|out|, 1): the two kernels sum the same products in different orders
-    assert ((out1.float() - out0.float()).abs() <= 2.0 ** -6 * out0.float().abs().clamp(min=1.0)).all()
-    assert (lse1 - lse0).abs().max().item() < 2e-2
-
-
-@pytest.mark.gpu
 def test_recorded_gemm_selections_load_and_change_no_result_beyond_rounding():
     """vitxt_gqa_amd/gemm_tuning.py: the recorded hipBLASLt selections load on this card (torch's validators accept the file) and a
     GEMM of a recorded shape gives the library default's result up to the rounding of a different summation order."""

@@ -1,3 +1,7 @@
+// DIAGNOSTIC VARIANT of vitxt_gqa_amd/csrc/attn_bwd_fused_bf16.hip (the round-4 source with every switch: -DFB_STAMP / FB_STAMP_SLOTS cycle
+// stamps, -DFB_TIMELINE workgroup records, -DFB_ABL / FB_HO_ABL timing-only ablations (RESULTS WRONG), -DFB_DMA=0, -DFB_SDWA=0,
+// -DFB_MASK_SKEW=0, -DFB_HO_PREFETCH=1).  Never part of the product library: tools/ablate/fb_variants.sh links it in place of the
+// product source into tools/ablate/_build/libt2s_fb_<name>.so for tools/fused_stamps.py / fused_timeline.py and same-box A/B runs.
 // Fused bf16 flash-attention backward for gfx950, head_dim 64: FIVE matrix products per (query, key) pair.
 //
 // The two-kernel form (attn_dkdv_bf16.hip + attn_dq_bf16_kernel) needs no cross-workgroup sum but computes S = Q K^T and
@@ -24,7 +28,7 @@
 
 #include <type_traits>
 
-#include "attn_common.h"
+#include "../../vitxt_gqa_amd/csrc/attn_common.h"
 
 namespace {
 
@@ -38,6 +42,8 @@ constexpr int FB_TILE = FB_QROWS * 128;           // bytes of a 64-row bf16 tile
 constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + (FB_QROWS / 2) * 4;   // Q | dO | -lse*log2e | -delta | dropout row keys (pairs)
 constexpr int FB_KIMG = FB_KEYS * 128;
 constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
+constexpr int FB_SUMS = FB_QROWS * 64 * 4;        // hand-off: the predecessor's running sum of one query tile, prefetched into LDS (16 KB)
+constexpr int FB_SMEM_TOTAL = FB_SMEM + FB_SUMS;
 
 // ---- dQ across the key blocks of a (sample, head): two forms, chosen per launch (FbWork::handoff).
 // ATOMIC (rounds 2-3): every key block adds its [64 x 64] tile to an fp32 [B Lq, H 64] buffer with float atomics (memory-side,
@@ -67,18 +73,41 @@ struct FbWork {
   const float* nd;        // [B H][nqt * 64]: -delta per query row, 0 behind Lq
   const unsigned* slots;  // [8 XCD groups][groups + 1]: first ticket of each (sample, head) pair of the group, then the group's total (prep kernel)
   int groups;             // (sample, head) pairs per XCD group = ceil(B H / 8)
+  unsigned long long* dbg; // the workspace's tail: diagnostic builds only (-DFB_STAMP: cycle stamps; -DFB_TIMELINE: one record per workgroup)
   int handoff;
-  unsigned spin_limit;    // polls a hand-off wait may take before it gives up (FB_SPIN_LIMIT; 0 in the diagnostic mode of the tests)
-  int never_publish;      // diagnostic mode (dq_mode bit 8): no block publishes its flags - every successor's wait times out
 };
+// tail of the workspace for the diagnostic builds (tools/fused_stamps.py, tools/fused_timeline.py); a product build never writes it
+#ifdef FB_TIMELINE
+constexpr size_t FB_DBG_BYTES = 16384 + (size_t)131072 * 32;      // stamps of 256 workgroups + 32 B per workgroup of a launch
+#else
+constexpr size_t FB_DBG_BYTES = 16384;
+#endif
 // Staging of the Q / dO tiles and their row constants by LDS-DMA (buffer_load ... lds: 1 KB per wave-instruction = 8 rows x 128 B
 // straight into the swizzled tile image - the chunk swizzle is a permutation INSIDE a row, so it goes on the per-lane source address;
-// rows behind Lq fall outside the descriptor's records and read as zeros - the tile's row offset is part of the VECTOR offset, which the
-// hardware range-checks (a scalar offset is not: ADVICE r4); the row constants arrive pre-scaled from the prep kernel).  VERDICT r3 #3;
-// cdna_hip_programming.md rule 21.  Dropout masks of the pipelined sweep are KEEP words applied to the fp32 dP values by one
-// v_and_b32_sdwa per score, their three packed instructions skewed over the chunks of a block (round 4).  The diagnostic / timing-only
-// variants of this kernel (cycle stamps, workgroup timeline, register-staged Q / dO, drop-word masks, the LDS-prefetched hand-off, the
-// "results wrong" ablation switches) live in tools/ablate/attn_bwd_fused_bf16_diag.hip, not in the product library.
+// rows behind Lq are out-of-range records and read as zeros; the row constants arrive pre-scaled from the prep kernel).  Replaces
+// global -> 16 VGPRs -> 4 ds_write_b128 per lane and tile (cdna_hip_programming.md rule 21).  -DFB_DMA=0: the
+// register-staged form of rounds 2-3 (tools/ablate/fb_variants.sh builds it for same-box A/B runs).
+#ifndef FB_DMA
+#define FB_DMA 1
+#endif
+// Dropout masks of the pipelined sweep as KEEP words applied to the fp32 dP values by one v_and_b32_sdwa per score (round 4; 0: the
+// drop words + v_bfe_i32 / v_ashrrev_i32 + v_bfi_b32 of rounds 2-3, kept for same-box A/B builds)
+#ifndef FB_SDWA
+#define FB_SDWA 1
+#endif
+#ifndef FB_MASK_SKEW
+#define FB_MASK_SKEW 1      // (needs FB_SDWA; 0: the keep word of a chunk formed by three dependent instructions in its own group)
+#endif
+// Hand-off experiment, built and measured, NOT shipped (-DFB_HO_PREFETCH=1; needs FB_DMA): the predecessor's running sum of tile t+1
+// fetched by LDS-DMA into a 16 KB LDS region at the END of tile t (its flag checked one tile ahead), landing under phase A of tile t+1
+// and read back from LDS behind phase B - instead of four register loads issued ahead of the barrier, whose memory latency phase B
+// alone does not quite cover (profiles/r04_handoff_ablation.txt: ~2.5 % of the kernel).  Correct (all fused tests green), and 2.5 - 4 %
+// SLOWER than the register loads (profiles/r04_handoff_prefetch_ab.txt: 23.72 vs 23.13 ms with dropout, 20.22 vs 19.46 without, B = 32):
+// four more DMA pieces per wave and tile cost more issue time than the latency they hide (MI355X_MICROARCH.md prices a piece at 60 - 185
+// cycles inside a busy phase), and the look-ahead poll needs the predecessor 2.3 instead of 1.3 tiles ahead.
+#ifndef FB_HO_PREFETCH
+#define FB_HO_PREFETCH 0
+#endif
 // The DMA is issued through inline asm: told about an LDS-DMA builtin, the compiler orders every later LDS read whose address it cannot
 // prove disjoint (the stage buffer index is a run-time value) behind it with an s_waitcnt vmcnt(0) - in the middle of phase A, a
 // full memory round trip per tile (seen in the ISA).  The waits are placed by hand instead: every wave waits for its own pieces
@@ -209,7 +238,15 @@ template <int I, int M, bool EDGE, bool DROP>
 __device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], const int thr, uint32_t (&mw)[8], const uint32_t (&rkw)[8], const uint32_t ck2,
                                       const uint32_t th2) {
   constexpr int par = I & 1, r0 = 2 * M, r1 = 2 * M + 1;
+#if defined(FB_ABL) && (FB_ABL & 16)   // timing-only diagnostic build (results wrong): a plain multiply in place of each v_exp_f32 - what the exponentials cost
+  float p0 = sacc[par][r0] * 1.0001f, p1 = sacc[par][r1] * 1.0001f;
+#elif defined(FB_ABL) && (FB_ABL & 32) // timing-only: the two exponentials of a chunk kept apart by an empty asm (is a v_exp_f32 dearer right behind another one?)
+  float p0 = fast_exp2(sacc[par][r0]);
+  asm volatile("" : "+v"(p0));
+  float p1 = fast_exp2(sacc[par][r1]);
+#else
   float p0 = fast_exp2(sacc[par][r0]), p1 = fast_exp2(sacc[par][r1]);
+#endif
   if (EDGE) {
     p0 = ((r0 & 3) + 8 * (r0 >> 2)) >= thr ? p0 : 0.f;
     p1 = ((r1 & 3) + 8 * (r1 >> 2)) >= thr ? p1 : 0.f;
@@ -217,9 +254,11 @@ __device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], con
   sacc[par][r0] = p0;                                  // dS uses the UNdropped probability
   sacc[par][r1] = p1;
   if (DROP) {                                          // registers (2m, 2m+1) are two consecutive queries of this lane's key: one packed mask word
+#if FB_SDWA
     // keep word of chunk M: 0xFFFF in every KEPT half (th2 = attn_drop_thresh2k).  Its three packed instructions (multiply, saturating
     // subtract, shift) are SKEWED over the chunks of the block - chunk M + 2 is multiplied, M + 1 subtracted and M shifted in one group -
     // so that no packed instruction stands right behind the one it depends on (each such pair costs an s_nop in an issue-bound gap)
+#if FB_MASK_SKEW
     if constexpr (M == 0) {
       mw[0] = attn_drop_kept_mul(rkw[0], ck2); mw[1] = attn_drop_kept_mul(rkw[1], ck2); mw[2] = attn_drop_kept_mul(rkw[2], ck2);
       mw[0] = attn_drop_kept_sub(mw[0], th2); mw[1] = attn_drop_kept_sub(mw[1], th2);
@@ -228,7 +267,14 @@ __device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], con
       if constexpr (M + 1 < 8) mw[M + 1] = attn_drop_kept_sub(mw[M + 1], th2);
     }
     mw[M] = attn_drop_kept_mask(mw[M]);
+#else
+    mw[M] = attn_drop_pair_kept(rkw[M], ck2, th2);
+#endif
     pfw[M] = fb_pack2(p0, p1) & mw[M];                 // dV uses the dropped one (scaled by 1/(1-p) at the end)
+#else
+    mw[M] = attn_drop_pair_dropped(rkw[M], ck2, th2);  // 0xFFFF in every dropped half
+    pfw[M] = attn_drop_apply(fb_pack2(p0, p1), mw[M]);
+#endif
   } else {
     pfw[M] = fb_pack2(p0, p1);
   }
@@ -239,8 +285,12 @@ __device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dp
                                       const float nd1, const float inv) {
   constexpr int par = I & 1;
   if (DROP) {
+#if FB_SDWA
     // (one v_and_b32_sdwa per score: the kept-half word, sign-extended by the operand selector, is the fp32 mask)
     const float d0 = attn_drop_keep_lo(dpacc[par][2 * M], mw[M]), d1 = attn_drop_keep_hi(dpacc[par][2 * M + 1], mw[M]);
+#else
+    const float d0 = attn_drop_zero_lo(dpacc[par][2 * M], mw[M]), d1 = attn_drop_zero_hi(dpacc[par][2 * M + 1], mw[M]);
+#endif
     dsw[M] = fb_pack2(sacc[par][2 * M] * __builtin_fmaf(d0, inv, nd0), sacc[par][2 * M + 1] * __builtin_fmaf(d1, inv, nd1));
   } else {
     dsw[M] = fb_pack2(sacc[par][2 * M] * dpacc[par][2 * M], sacc[par][2 * M + 1] * dpacc[par][2 * M + 1]);
@@ -265,6 +315,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   char* const dsimg = kimg + FB_KIMG;              // [384 keys][64 q] bf16, same layout
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   float* __restrict__ const dq32 = w.part;         // (atomic form)
+#ifdef FB_TIMELINE   // diagnostic build only: when and where every workgroup ran (100 MHz real-time counter, HW_ID / XCC_ID)
+  const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
+#define FB_TL_DUMMY()                                                                                                        \
+  if (tid == 0 && blockIdx.x < 131072u) {                                                                                    \
+    unsigned hw_, xcc_;                                                                                                      \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); \
+    unsigned long long* tl_ = w.dbg + 2048 + (size_t)blockIdx.x * 4;                                                         \
+    tl_[0] = tl_r0;                                                                                                          \
+    tl_[1] = __builtin_amdgcn_s_memrealtime();                                                                               \
+    tl_[2] = (unsigned long long)hw_ | ((unsigned long long)xcc_ << 32);                                                     \
+    tl_[3] = 1ull << 63;                                                                                                     \
+  }
+#else
+#define FB_TL_DUMMY()
+#endif
   int kblk, h, b;
   if constexpr (HO && !TAIL) {
     // ticket: this workgroup is the slot-th one of its XCD group to START (not the slot-th by id), see FbWork
@@ -284,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     __syncthreads();
     const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)sl[0]);
     __syncthreads();                               // (the stage buffer is written below)
-    if (slot >= tab[w.groups]) return;
+    if (slot >= tab[w.groups]) { FB_TL_DUMMY(); return; }
     int g = 0;                                     // the pair whose slot range holds this ticket: count the first-slots <= slot
     for (int base = 0; base < w.groups; base += 64) {
       const int gi = base + lane;
@@ -304,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   const int n_prefix = USE_IDX ? p.kv_cnt[b] : (p.idx_cap - p.n_dec);
   const int nk = n_prefix + p.n_dec;
   int kbw = TAIL ? p.kblocks : kblk;
-  if (kbw * FB_KEYS >= nk) return;     // uniform per workgroup
+  if (kbw * FB_KEYS >= nk) { FB_TL_DUMMY(); return; }     // uniform per workgroup
   const int32_t* __restrict__ idx = USE_IDX ? p.kv_idx + (int64_t)b * p.idx_cap : nullptr;
   const bf16_t* __restrict__ Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.q_bs + h * 64;
   const bf16_t* __restrict__ DO = reinterpret_cast<const bf16_t*>(p.dout) + (int64_t)b * p.o_bs + h * 64;
@@ -351,11 +416,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     // hand-off chain position (workgroup-uniform): block 0 has no predecessor, the block that holds the end of the list finishes dQ
     const bool ho_last = HO && (MODE != 0) && (kp0 + FB_KEYS >= nk);              // (a last block is an edge block: never in the FULL, non-EDGE sweep)
     int ho_wait = (HO && !TAIL) ? kbw : 0;                                         // flags[t] must reach this before tile t's sum is read
-    float ho_ln2 = 0.6931471805599453f;                                            // dQ = ln 2 * acc (K is pre-scaled by log2 e); NaN once a wait has timed out
     // running sums of this pair through a buffer descriptor: block 0 gets ZERO records - its loads return 0.0 without touching
     // memory, so the sweep needs no branch around them
-    const __amdgpu_buffer_rsrc_t rs_ld = fb_rsrc(part_pair, (HO && kbw > 0) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
+#ifndef FB_HO_ABL
+#define FB_HO_ABL 0      // timing-only switches of diagnostic builds (results wrong): 1 = every block's sum loads read zeros (no memory access), 2 = no
+                         // flag load / poll, 4 = plain instead of write-through stores, 8 = no stores of the sum; 0 in every product build
+#endif
+    const __amdgpu_buffer_rsrc_t rs_ld = fb_rsrc(part_pair, (HO && kbw > 0 && !(FB_HO_ABL & 1)) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
     const __amdgpu_buffer_rsrc_t rs_st = fb_rsrc(part_pair, HO ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
+    constexpr bool HP = HO && !TAIL && FB_HO_PREFETCH;                              // sum prefetched through LDS (block 0 has none: uniform branch)
+    const bool ho_first = kbw == 0;
     // ---- K image of the workgroup's keys, pre-scaled by scale*log2e (one bf16 rounding per element, as the dK/dV kernel's
     // register fragments); rows past the list repeat its last key (their P is forced to 0 below)
 #pragma unroll
@@ -400,10 +470,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     uint32_t ck2[FB_KB];
 #pragma unroll
     for (int kb = 0; kb < FB_KB; ++kb) ck2[kb] = 0u;         // (set per 256-row window of query rows at the top of every fourth tile)
+#if FB_SDWA
     const uint32_t th2 = attn_drop_thresh2k(p.drop_thresh);      // (the pipelined sweep's masks are KEEP words)
+#else
+    const uint32_t th2 = attn_drop_thresh2s(p.drop_thresh);
+#endif
     const float drop_inv = p.drop_inv;
     uint32_t rkreg = 0;
     int ld_row0 = 0;              // first query row of the tile being loaded (uniform)
+#if FB_DMA
     // ---- staging of the Q / dO tiles by LDS-DMA.  A tile is 8 pieces of 8 rows; wave w issues pieces w and w + 4 of Q and of dO.
     // Lane: row 8 piece + lane / 8, chunk POSITION lane % 8, which holds the logical chunk (lane % 8) ^ tile_f(row); tile_f depends on
     // bits 1..3 of the row, i.e. on lane / 8 and on the parity of the piece - the same for pieces w and w + 4: ONE offset per operand
@@ -422,11 +497,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   {                                                                                             \
     const uint32_t dst_ = st_lds + (uint32_t)(st_buf * FB_STAGE + wave_s * 1024);               \
     const int r0_ = ld_row0 + wave_s * 8;                                                       \
-    /* the tile's row offset rides in the VECTOR offset: that one is range-checked against the descriptor (rows behind Lq read 0) */ \
-    fb_dma16(rs_q, dst_, voff_q + r0_ * q_rs2, 0);                                              \
-    fb_dma16(rs_o, dst_ + FB_TILE, voff_o + r0_ * o_rs2, 0);                                    \
-    fb_dma16(rs_q, dst_ + 4096, voff_q + (r0_ + 32) * q_rs2, 0);                                \
-    fb_dma16(rs_o, dst_ + FB_TILE + 4096, voff_o + (r0_ + 32) * o_rs2, 0);                      \
+    fb_dma16(rs_q, dst_, voff_q, r0_ * q_rs2);                                                  \
+    fb_dma16(rs_o, dst_ + FB_TILE, voff_o, r0_ * o_rs2);                                        \
+    fb_dma16(rs_q, dst_ + 4096, voff_q, (r0_ + 32) * q_rs2);                                    \
+    fb_dma16(rs_o, dst_ + FB_TILE + 4096, voff_o, (r0_ + 32) * o_rs2);                          \
     if (wave_s == 0) fb_dma4(rs_nl, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE), lane * 4, ld_row0 * 4);                   \
     if (wave_s == 1) fb_dma4(rs_nd, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE + FB_QROWS * 4), lane * 4, ld_row0 * 4);    \
     if (DROP && tid < FB_QROWS / 2) {                                                           \
@@ -442,22 +516,83 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     if (DROP && tid < FB_QROWS / 2) reinterpret_cast<uint32_t*>(stage + (buf_) * FB_STAGE + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
     st_buf ^= 1;                                                                                \
   }
+#else
+    // ---- staging of the Q / dO tiles through registers (as attn_dkdv_bf16.hip: uniform 64-bit base + advancing 32-bit offsets, rows
+    // past Lq clamp to the last row and get P = 0 through lse = -inf)
+    uint4 q0r, q1r, d0r, d1r;
+    float lreg, dreg;
+    const char* __restrict__ Qb = reinterpret_cast<const char*>(Q);
+    const char* __restrict__ DOb = reinterpret_cast<const char*>(DO);
+    const uint32_t q_step = (uint32_t)(FB_QROWS * p.q_rs * 2), o_step = (uint32_t)(FB_QROWS * p.o_rs * 2);
+    const uint32_t q_max = (uint32_t)((p.Lq - 1) * p.q_rs * 2) + (uint32_t)sc * 16u, o_max = (uint32_t)((p.Lq - 1) * p.o_rs * 2) + (uint32_t)sc * 16u;
+    uint32_t qo0 = (uint32_t)(sr * p.q_rs * 2) + (uint32_t)sc * 16u, oo0 = (uint32_t)(sr * p.o_rs * 2) + (uint32_t)sc * 16u;
+    uint32_t qo1 = qo0 + (uint32_t)(32 * p.q_rs * 2), oo1 = oo0 + (uint32_t)(32 * p.o_rs * 2);
+    int ld_row = tid & 63;
+#define FB_STAGE_LOAD()                                                                         \
+  {                                                                                             \
+    const uint32_t a0_ = qo0 < q_max ? qo0 : q_max, b0_ = oo0 < o_max ? oo0 : o_max;            \
+    const uint32_t a1_ = qo1 < q_max ? qo1 : q_max, b1_ = oo1 < o_max ? oo1 : o_max;            \
+    q0r = *reinterpret_cast<const uint4*>(Qb + a0_);                                            \
+    d0r = *reinterpret_cast<const uint4*>(DOb + b0_);                                           \
+    q1r = *reinterpret_cast<const uint4*>(Qb + a1_);                                            \
+    d1r = *reinterpret_cast<const uint4*>(DOb + b1_);                                           \
+    const int r2c_ = ld_row < p.Lq ? ld_row : p.Lq - 1;                                         \
+    lreg = LSE[r2c_]; dreg = DELTA[r2c_];       /* raw: arithmetic on them HERE would make the wave wait for the loads here */  \
+    if (DROP && tid < FB_QROWS / 2) {                                                           \
+      const int qa_ = ld_row0 + 2 * tid, qb2_ = qa_ + 1;                                        \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kbw) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1, kbw) << 16); /* window = this key block */ \
+    }                                                                                           \
+    qo0 += q_step; oo0 += o_step; qo1 += q_step; oo1 += o_step;                                 \
+    ld_row += FB_QROWS; ld_row0 += FB_QROWS;                                                    \
+  }
+#define FB_STAGE_WRITE(buf_)                                                                    \
+  {                                                                                             \
+    char* base_ = stage + (buf_) * FB_STAGE;                                                    \
+    *reinterpret_cast<uint4*>(base_ + tile_off(sr, sc)) = q0r;                                  \
+    *reinterpret_cast<uint4*>(base_ + FB_TILE + tile_off(sr, sc)) = d0r;                        \
+    *reinterpret_cast<uint4*>(base_ + tile_off(sr + 32, sc)) = q1r;                             \
+    *reinterpret_cast<uint4*>(base_ + FB_TILE + tile_off(sr + 32, sc)) = d1r;                   \
+    if (tid < FB_QROWS) {        /* (ld_row was advanced past the staged tile by the load) */  \
+      const bool in_ = ld_row - FB_QROWS < p.Lq;                                                \
+      reinterpret_cast<float*>(base_ + 2 * FB_TILE)[tid] = in_ ? -(lreg * LOG2E) : -INFINITY;   \
+      reinterpret_cast<float*>(base_ + 2 * FB_TILE + FB_QROWS * 4)[tid] = in_ ? -dreg : 0.f;    \
+    }                                                                                           \
+    if (DROP && tid < FB_QROWS / 2) reinterpret_cast<uint32_t*>(base_ + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
+  }
+#endif
+    // hand-off with prefetch: tile 0's sum must be published before its DMA goes out (later tiles: checked one tile ahead, inside the sweep)
+    const u32x4 rs_sum = HP ? fb_rsrc_s(part_pair, (unsigned)(nqt * FB_SUMS)) : u32x4{0u, 0u, 0u, 0u};
+    const uint32_t hp_lds = HP ? __builtin_amdgcn_readfirstlane(fb_lds_addr(smem + FB_SMEM)) + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 4096u : 0u;
+#define FB_SUM_DMA(qt_)                                                                         \
+  {                                                                                             \
+    const int so_ = ((qt_) * 4 + __builtin_amdgcn_readfirstlane(wave)) * 4096;                  \
+    fb_dma16_sc1(rs_sum, hp_lds, lane * 16, so_);                                               \
+    fb_dma16_sc1(rs_sum, hp_lds + 1024, lane * 16, so_ + 1024);                                 \
+    fb_dma16_sc1(rs_sum, hp_lds + 2048, lane * 16, so_ + 2048);                                 \
+    fb_dma16_sc1(rs_sum, hp_lds + 3072, lane * 16, so_ + 3072);                                 \
+  }
 #define FB_FLAG_WAIT(addr_, fv_)      /* bounded spin until *addr_ >= ho_wait (fv_: a value already read from it) */  \
   {                                                                                             \
     int fvs_ = __builtin_amdgcn_readfirstlane((int)(fv_));                                      \
-    if (fvs_ < ho_wait) {                                                   \
+    if (!(FB_HO_ABL & 2) && fvs_ < ho_wait) {                                                   \
       unsigned spins_ = 0;                                                                      \
       do {                                                                                      \
         __builtin_amdgcn_s_sleep(16);                                                           \
         fvs_ = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load((addr_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); \
-        if (++spins_ > w.spin_limit) {      /* never in a correct run: report, stop waiting and POISON what this block hands on - */ \
-          if (lane == 0) atomicOr(w.status, 1u);      /* its sums, hence the pair's dQ rows, become NaN: no hang, no silent error */   \
+        if (++spins_ > FB_SPIN_LIMIT) {     /* never in a correct run: report, stop waiting (wrong dQ, no hang) */          \
+          if (lane == 0) atomicOr(w.status, 1u);                                                \
           ho_wait = 0;                                                                          \
-          ho_ln2 = __builtin_nanf("");                                                          \
         }                                                                                       \
       } while (fvs_ < ho_wait);                                                                 \
     }                                                                                           \
   }
+    if constexpr (HP) {
+      if (!ho_first) {
+        const unsigned f0_ = __hip_atomic_load(flags_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FB_FLAG_WAIT(flags_pair, f0_);
+        FB_SUM_DMA(0);
+      }
+    }
     FB_STAGE_LOAD();
     FB_STAGE_WRITE(0);
     __syncthreads();
@@ -501,6 +636,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       FB_LD_SEEDS(reinterpret_cast<const float*>(stage + 2 * FB_TILE), reinterpret_cast<const float*>(stage + 2 * FB_TILE) + FB_QROWS, 0);
       FB_LD_KF(0);
     }
+#ifdef FB_STAMP   // diagnostic build only (tools/ablate): where a tile's cycles go; never defined in a product build
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_t0 = 0, st_t1 = 0;
+#define FB_TICK(k_) { FB_FENCE(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1) :: "memory"); st_sum[k_] += st_t1 - st_t0; st_t0 = st_t1; FB_FENCE(); }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0) :: "memory");
+    const unsigned long long st_c0 = st_t0, st_r0 = __builtin_amdgcn_s_memrealtime();      // the clock: shader cycles per 100 MHz tick over the sweep
+#else
+#define FB_TICK(k_)
+#endif
+    // FB_STAMP_SLOTS (diagnostic build): the six counters are re-used for the slot classes of phase A instead of the tile's segments:
+    // 0 = slot G1(b0), 1 = the five G1+E slots, 2 / 3 = first (dV^T + M) / second (dK^T + LDS) halves of the G2+M slots of b0..b3 (and 2 also
+    // the first half of G2+M(b5)), 4 = the G2(b4)+M(b4)+E(b5) slot and the second half of G2+M(b5),
+    // 5 = everything behind phase A
+#if defined(FB_STAMP) && defined(FB_STAMP_SLOTS)
+#undef FB_TICK
+#define FB_TICK(k_) { if ((k_) == 5) { FB_FENCE(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1) :: "memory"); st_sum[5] += st_t1 - st_t0; st_t0 = st_t1; FB_FENCE(); } }
+#define FB_TICKS(k_) { FB_FENCE(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1) :: "memory"); st_sum[k_] += st_t1 - st_t0; st_t0 = st_t1; FB_FENCE(); }
+#else
+#define FB_TICKS(k_)
+#endif
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
       if (DROP && (qt & (ATTN_DROP_QWIN / FB_QROWS - 1)) == 0) {      // a new 256-row window of query rows: re-hash this lane's three column keys
@@ -510,7 +664,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       }
       // hand-off: how far the predecessor has published this tile's running sum - asked now, looked at at the end of phase A
       unsigned fv = 0;
-      if constexpr (HO && !TAIL) fv = __hip_atomic_load(flags_pair + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (prefetch form: the flag of the NEXT tile, whose sum is fetched at the end of this one)
+      const int fq = HP ? (qt + 1 < nqt ? qt + 1 : qt) : qt;
+      if constexpr (HO && !TAIL && !(FB_HO_ABL & 2)) fv = __hip_atomic_load(flags_pair + fq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // global loads of the next tile in sequence (past the end: clamped rows, harmless).  Pipelined form: issued a third of the way
       // into phase A instead of here - at the top of the tile the memory pipeline is still draining the 16 atomics per lane of the
       // previous tile, and the loads are not needed before the end of the phase
@@ -577,6 +733,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   FB_LD_DL(i_);                                                                                     \
   FB_G2(i_, 0); FB_M(i_, 0); FB_M(i_, 1); FB_FENCE(); FB_G2(i_, 1); FB_M(i_, 2); FB_M(i_, 3); FB_FENCE();                        \
   FB_G2(i_, 2); FB_M(i_, 4); FB_FENCE(); FB_G2(i_, 3); FB_M(i_, 5); FB_FENCE();                                                   \
+  FB_TICKS(2);                                                                                                                    \
   /* the dK^T MFMAs of s = 0 need chunks 0..3 only: chunks 6, 7 of dS are formed beside the first of them (an MFMA group ahead of */   \
   /* the s = 1 MFMAs that read them: the asm MFMAs get no hazard nops), the seeds of block i + 2 are fetched once the last chunk */     \
   /* has read this block's accumulators, the dS^T stores follow */                                                                   \
@@ -587,8 +744,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // slot 0: G1(b0), nothing to pair yet; the transposed fragments of sub-block 0 arrive meanwhile
         FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
+        FB_TICKS(0);
         FB_LD_KF(1); FB_FENCE();
         FB_SLOT_G1E(1, 0);
+        FB_TICKS(1);
         // the barrier that ends the PREVIOUS tile (every wave is done reading its dS^T image) stands here, ahead of the first dS^T
         // store of this tile, instead of behind the atomics: a wave that got its atomics out early starts the next tile.  A bare
         // s_barrier: it orders later LDS writes behind earlier LDS reads whose data has long been consumed by MFMAs - nothing
@@ -596,25 +755,35 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         asm volatile("s_barrier" ::: "memory");
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(0);
+        FB_TICKS(3);
         FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
+        FB_TICKS(1);
         FB_LD_QF(qb_, dob_, 1); FB_LD_KF(0); FB_FENCE();
         FB_SLOT_G2M(1);
+        FB_TICKS(3);
         FB_STAGE_LOAD(); FB_FENCE();
         FB_SLOT_G1E(3, 2);
+        FB_TICKS(1);
         FB_LD_KF(1); FB_FENCE();
         FB_SLOT_G2M(2);                                      // last use of sub-block 0's transposed fragments
+        FB_TICKS(3);
         FB_LD_QT(1); FB_FENCE();
         FB_SLOT_G1E(4, 3);
+        FB_TICKS(1);
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(3);
+        FB_TICKS(3);
         FB_SLOT_G1E(5, 4);
+        FB_TICKS(1);
         // slot "G2(b4) + M(b4) + E(b5)": E(b5) only behind the dV^T MFMAs of b4, which still read the operand words of P(b4)
         FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_FENCE();
         FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_FENCE();
         FB_THR(5); FB_LD_RK(5);
         FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 0); FB_E(5, 1); FB_FENCE(); FB_G2(4, 5); FB_E(5, 2); FB_E(5, 3); FB_FENCE();
         FB_G2(4, 6); FB_E(5, 4); FB_E(5, 5); FB_FENCE(); FB_G2(4, 7); FB_E(5, 6); FB_E(5, 7); FB_FENCE();
+        FB_TICKS(4);
         FB_SLOT_G2M(5);
+        FB_TICKS(4);
 #undef FB_THR
 #undef FB_LD_RK
 #undef FB_LD_DL
@@ -708,6 +877,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       // LDS writes wait on vmcnt, which retires in order - behind the 16 atomics of phase B that wait would last their
       // ~3000-cycle round trip), the buffer was last read in phase A of the previous tile, and the barrier below publishes it,
       // so that phase B can already fetch the next tile's first operands.
+      FB_TICK(0);                                            // phase A
       // K^T fragments of the first two groups of the dQ product: they do not depend on this tile, so they are fetched ahead of
       // the barrier (their registers were the transposed Q / dO fragments until a moment ago)
       bf16x8 afA[4], bfA[4], afB[4], bfB[4];
@@ -722,20 +892,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // every wave: its running-sum stores of the PREVIOUS tile have landed (the flag below is stored behind this wait and the
         // barrier: Guideline 16 R1); the stage loads of this tile are younger and are needed right below anyway
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (!TAIL) FB_FLAG_WAIT(flags_pair + qt, fv);          // the predecessor has not published that tile yet: bounded spin
+        if constexpr (!TAIL) FB_FLAG_WAIT(flags_pair + fq, fv);          // the predecessor has not published that tile yet: bounded spin
       }
       FB_STAGE_WRITE(buf ^ 1);
-      if constexpr (HO) {
+      if constexpr (HO && !HP) {
         // this wave's own poll has matched: its loads of the sum may go out now (every load of handed-off bytes is an sc1 load issued
         // by a wave behind its own matching poll) - ahead of the barrier, behind the staging wait (which would wait for them too),
         // so that they have the barrier and all of phase B to come back
 #pragma unroll
         for (int g = 0; g < 4; ++g) pin[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ho_off + g * 1024, 0, 16 /* sc1 */);
       }
+      FB_TICK(1);                                            // stage write
       __syncthreads();                                       // the dS^T image of this query tile is complete
+      FB_TICK(2);                                            // barrier 1
       if constexpr (HO && !TAIL) {
         // publish the previous tile's running sum: every wave drained its stores before the barrier above
-        if ((!CAN_LAST || !ho_last) && tid == 0 && qt > 0 && !w.never_publish)
+        if ((!CAN_LAST || !ho_last) && tid == 0 && qt > 0)
           __hip_atomic_store(flags_pair + (qt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // ================= phase B: dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
@@ -745,9 +917,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         for (int i = 0; i < 16; ++i) dqacc[i] = 0.f;
         // steps of 16 keys in groups of 4; full key blocks: 24 steps with the transposed reads of group g+1 in flight under the
         // MFMAs of group g, otherwise the steps that hold valid keys (rows past them may never have been written)
+#ifndef FB_ABL
+#define FB_ABL 0      // timing-only ablation switches of the diagnostic build (results are then wrong; 1 / 2: no dQ operand reads / MFMAs,
+                      // 4: no atomics, 8: plain stores in their place); 0 in every product build
+#endif
+#if FB_ABL & 1
+#define FB_DQ_LOAD_A(af_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(af_[u]));
+#define FB_DQ_LOAD_B(bf_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bf_[u]));
+#else
 #define FB_DQ_LOAD_A(af_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) af_[u] = fb_tr(dsimg + (16 * (4 * (g_) + u)) * 128, vaq);
 #define FB_DQ_LOAD_B(bf_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) bf_[u] = fb_tr(kimg + (16 * (4 * (g_) + u)) * 128, vad);
+#endif
 #define FB_DQ_LOAD(af_, bf_, g_) FB_DQ_LOAD_A(af_, g_) FB_DQ_LOAD_B(bf_, g_)
+#if FB_ABL & 2
+#define FB_DQ_MFMA(af_, bf_) _Pragma("unroll") for (int u = 0; u < 4; ++u) asm volatile("" :: "v"(af_[u]), "v"(bf_[u]));
+#else
 #define FB_DQ_MFMA(af_, bf_)                                                                        \
   asm("s_nop 1\n\t"                                                                                \
       "v_mfma_f32_32x32x16_bf16 %0, %1, %5, %0\n\t"                                                \
@@ -757,10 +941,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       : "+v"(dqacc)                                                                                 \
       : "v"(FB_U4(af_[0])), "v"(FB_U4(af_[1])), "v"(FB_U4(af_[2])), "v"(FB_U4(af_[3])), "v"(FB_U4(bf_[0])), "v"(FB_U4(bf_[1])),  \
         "v"(FB_U4(bf_[2])), "v"(FB_U4(bf_[3])));
+#endif
         if constexpr (PREF) {
           // 24 steps of 16 keys, eight steps of operands in flight: step k's MFMA is followed in the stream by the four transposed
           // reads of step k + 8 (into the registers it just released), so the reads run under the MFMAs instead of between them
-          // (reads and MFMAs of this phase measured ADDITIVE in the grouped form: tools/fused_stamps.py)
+          // (reads and MFMAs of this phase measured ADDITIVE in the grouped form: tools/fused_stamps.py, FB_ABL)
           // afA/bfA hold steps k with (k & 7) < 4, afB/bfB those with (k & 7) >= 4; the K^T fragments of steps 0..7 were fetched
           // ahead of the barrier
 #pragma unroll
@@ -780,10 +965,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             const bool hiHalf = (k & 7) >= 4;
             bf16x8& a_ = hiHalf ? afB[k & 3] : afA[k & 3];
             bf16x8& b_ = hiHalf ? bfB[k & 3] : bfA[k & 3];
+#if !(FB_ABL & 2)
             asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(a_)), "v"(FB_U4(b_)));
+#else
+            asm volatile("" :: "v"(a_), "v"(b_));
+#endif
             if (k + 8 < FB_KEYS / 16) {
+#if !(FB_ABL & 1)
               a_ = fb_tr(dsimg + (16 * (k + 8)) * 128, vaq);
               b_ = fb_tr(kimg + (16 * (k + 8)) * 128, vad);
+#else
+              asm volatile("" : "+v"(a_), "+v"(b_));
+#endif
             }
             FB_FENCE();
           }
@@ -805,17 +998,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_DQ_LOAD_B
 #undef FB_DQ_MFMA
         asm volatile("s_nop 11" : "+v"(dqacc));              // MFMA result -> VALU read
+        FB_TICK(3);                                          // phase B MFMAs
         // dS (K c) = c dS K;  dQ = scale dS K = acc * ln 2.  Register r = query row acc_row(r, lh), 32 consecutive dims per
         // half wave: two 128-byte segments per wave instruction
         const int q0 = qt * FB_QROWS + dq_qb * 32;
         if constexpr (HO) {
+          if constexpr (HP) {          // the sum arrived by DMA under phase A (waited for in FB_STAGE_WRITE); block 0 has none
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              pin[g] = ho_first ? u32x4{0u, 0u, 0u, 0u}
+                                : *reinterpret_cast<const u32x4*>(smem + FB_SMEM + wave_u * 4096 + g * 1024 + lane * 16);
+          }
           f32x16 tot;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             // (bit_cast of the WHOLE vector, then the element: bit_cast(float, pin[g][j]) is narrowed by this clang to a one-dword load
             // whose value stands in for all four elements - seen in the ISA)
             const f32x4 pf = __builtin_bit_cast(f32x4, pin[r >> 2]);
-            tot[r] = __builtin_fmaf(dqacc[r], ho_ln2, pf[r & 3]);
+            tot[r] = __builtin_fmaf(dqacc[r], 0.6931471805599453f, pf[r & 3]);
           }
           if (CAN_LAST && ho_last) {
             // the last block of the pair: dQ rows in bf16.  Lanes 2i / 2i+1 hold columns 2i / 2i+1 of the same rows: the even lane
@@ -835,14 +1035,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const f32x4 t4 = {tot[4 * g], tot[4 * g + 1], tot[4 * g + 2], tot[4 * g + 3]};
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 16 /* sc1: write-through */);
+              if (!(FB_HO_ABL & 8))
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, (FB_HO_ABL & 4) ? 0 : 16 /* sc1: write-through */);
+              else
+                asm volatile("" ::"v"(t4));
             }
+          }
+          if constexpr (HP) {          // next tile's sum: its flag was checked at the end of this tile's phase A; the LDS region was read just above
+            if (!ho_first && qt + 1 < nqt) FB_SUM_DMA(qt + 1);
           }
         } else {
         const int rstep = p.H * 64;
         float* rowp = DQ + (int64_t)q0 * rstep + dq_db * 32;          // wave-uniform (dq_qb / dq_db come from readfirstlane)
         const int loff = lr + 4 * lh * rstep;                          // this lane's element offset
+#if FB_ABL & 4        // timing-only: no atomics (the accumulator is kept alive)
+#define FB_DQ_OUT(ptr_, v_) asm volatile("" :: "v"(v_))
+#elif FB_ABL & 8      // timing-only: plain stores in their place (same addresses, same bytes)
+#define FB_DQ_OUT(ptr_, v_) *(ptr_) = (v_)
+#else
 #define FB_DQ_OUT(ptr_, v_) unsafeAtomicAdd(ptr_, v_)
+#endif
         if (q0 + 32 <= p.Lq) {                               // whole sub-block inside the sequence
 #pragma unroll
           for (int r = 0; r < 16; ++r) FB_DQ_OUT(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
@@ -854,17 +1066,30 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_DQ_OUT
         }
       }
+      FB_TICK(4);                                            // atomics
       if constexpr (!FULL) __syncthreads();                  // every wave is done reading the dS^T image (pipelined form: see phase A)
+      FB_TICK(5);                                            // barrier 2
     }
     if constexpr (HO) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last tile's stores (the tail launch reads them back in its next key block)
       if constexpr (!TAIL) {
         if (!CAN_LAST || !ho_last) {                         // workgroup-uniform
           __syncthreads();
-          if (tid == 0 && !w.never_publish) __hip_atomic_store(flags_pair + (nqt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (tid == 0) __hip_atomic_store(flags_pair + (nqt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
+#ifdef FB_STAMP
+#ifndef FB_STAMP_MODE
+#define FB_STAMP_MODE 0      // which kernel of the launch records its stamps (0: full key blocks, 1: the edge blocks)
+#endif
+    if ((MODE == FB_STAMP_MODE || (MODE == 3 && FB_STAMP_MODE == (EDGE ? 1 : 0))) && lane == 0 && wave == 0) {
+      unsigned long long* dbg = w.dbg + (int64_t)(blockIdx.x & 255) * 8;
+      for (int k = 0; k < 6; ++k) dbg[k] = st_sum[k];
+      dbg[6] = (unsigned long long)nqt;
+      dbg[7] = ((st_t0 - st_c0) * 1000ull) / (__builtin_amdgcn_s_memrealtime() - st_r0 + 1);       // MHz / 100 * 1000
+    }
+#endif
     };
     if constexpr (MODE == 3) {
       if (edge_wg) sweep(std::true_type{}, std::true_type{});
@@ -881,6 +1106,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dkacc[kb][0]), "+a"(dkacc[kb][1]), "+a"(dvacc[kb][0]), "+a"(dvacc[kb][1]));
 #undef FB_STAGE_LOAD
 #undef FB_STAGE_WRITE
+#undef FB_SUM_DMA
 #undef FB_FLAG_WAIT
 
     // ---- dK / dV of this wave's keys
@@ -903,6 +1129,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             *reinterpret_cast<bf16x4*>(dvp + d) = v4;
           }
       }
+#ifdef FB_TIMELINE
+    if (!TAIL && lane == 0 && wave != 0 && blockIdx.x < 131072u)      // the LAST wave's end (the CU is free for the next workgroup only then)
+      atomicMax(w.dbg + 2048 + (size_t)blockIdx.x * 4 + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (!TAIL && tid == 0 && blockIdx.x < 131072u) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+      unsigned long long* tl = w.dbg + 2048 + (size_t)blockIdx.x * 4;
+      tl[0] = tl_r0;
+      atomicMax(tl + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+      tl[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+      tl[3] = (unsigned long long)(unsigned)kbw | ((unsigned long long)(unsigned)b << 8) | ((unsigned long long)(unsigned)h << 24) |
+              ((unsigned long long)(unsigned)nkeys_wg << 32) | ((unsigned long long)(edge_wg ? 1u : 0u) << 48);
+    }
+#endif
     if (TAIL) __syncthreads();                               // the next key block rewrites the K image
   } while (TAIL && (++kbw) * FB_KEYS < nk);
 }
@@ -970,10 +1210,6 @@ __global__ __launch_bounds__(256) void attn_delta_prep_kernel(const bf16_t* __re
       if (nl) {          // the row constants as the fused sweep seeds its accumulators with them (LDS-DMA copies them raw)
         nl[bh * nq_pad + q] = -(lse[bh * Lq + q] * LOG2E);
         nd[bh * nq_pad + q] = -s;
-        // rows behind Lq of the padded arrays (< 64 per pair): P = exp2(-inf) = 0 there, and -delta must not be a NaN left in the
-        // workspace by an earlier use (0 * NaN) - written by the wave that holds the sample's last row
-        if (q == Lq - 1)
-          for (int pq = Lq; pq < nq_pad; ++pq) { nl[bh * nq_pad + pq] = -INFINITY; nd[bh * nq_pad + pq] = 0.f; }
       }
     }
   }
@@ -1003,15 +1239,13 @@ size_t attn_bwd_fused_workspace_bytes(int B, int H, int Lq) {
   const size_t ctrl = ((size_t)FB_CTRL_WORDS * 4 + (size_t)B * H * nqt * 4 + T2S_XCDS * (groups + 1) * 4 + 255) / 256 * 256;
   const size_t rowc = 2 * (size_t)B * H * nqt * FB_QROWS * 4;            // -lse log2e and -delta per padded query row (LDS-DMA sources)
   const size_t sums = (size_t)B * H * nqt * (FB_QROWS * 64 * 4);        // >= B * Lq * H * 64 * 4, the atomic form's buffer
-  return ctrl + rowc + sums;
+  return ctrl + rowc + sums + FB_DBG_BYTES;                              // + room for the diagnostic builds' stamps
 }
 
 // Fused backward (bf16): delta + housekeeping, the 5-product kernel (+ its tail launch, see attn_dkdv_bf16.hip); dQ across key
 // blocks by the ordered hand-off (handoff != 0: no zero fill, no cast pass, bit-reproducible) or by fp32 atomics + the cast.
-int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* workspace, size_t workspace_bytes, int dq_mode, hipStream_t st) {
+int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* workspace, size_t workspace_bytes, int handoff, hipStream_t st) {
   AttnParams p = p_in;
-  const int handoff = dq_mode & 0xff;
-  const bool diag_dead = handoff && (dq_mode & 0x100);      // tests: the hand-off with a dead predecessor (spin limit 0, flags never published)
   if (workspace_bytes < attn_bwd_fused_workspace_bytes(p.B, p.H, p.Lq)) {
     t2s_set_error("attn_bwd_fused: workspace of %zu bytes, %zu needed (t2s_attn_bwd_fused_workspace_bytes)", workspace_bytes,
                   attn_bwd_fused_workspace_bytes(p.B, p.H, p.Lq));
@@ -1034,26 +1268,22 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   w.nd = nd;
   w.part = nd + rowc_n;
   w.handoff = handoff;
-  w.spin_limit = diag_dead ? 0u : FB_SPIN_LIMIT;
-  w.never_publish = diag_dead ? 1 : 0;
+  w.dbg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + attn_bwd_fused_workspace_bytes(p.B, p.H, p.Lq) - FB_DBG_BYTES);
+#if defined(FB_TIMELINE) || defined(FB_STAMP)
+  if (hipMemsetAsync(w.dbg, 0, FB_DBG_BYTES, st) != hipSuccess) return 3;
+#endif
   float* const dq32 = w.part;
-  // > 64 KB of LDS per workgroup needs the opt-in: once per device (a flag per device ordinal is the only state kept)
-  static bool lds_reserved[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-  if (dev < 0 || !lds_reserved[dev]) {
+  // > 64 KB of LDS per workgroup needs the opt-in; set on every call (idempotent, per device, no state of ours is kept)
 #define FB_K(I_, M_, D_) reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, true>)
   const void* kernels[] = {FB_K(true, 0, false), FB_K(true, 1, false), FB_K(true, 2, false), FB_K(false, 0, false), FB_K(false, 1, false),
                            FB_K(true, 0, true),  FB_K(true, 1, true),  FB_K(true, 2, true),  FB_K(false, 0, true),  FB_K(false, 1, true),
                            FB_K(true, 3, false), FB_K(false, 3, false), FB_K(true, 3, true), FB_K(false, 3, true)};
 #undef FB_K
   for (const void* k : kernels)
-    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
-      t2s_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS per workgroup", FB_SMEM);
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM_TOTAL) != hipSuccess) {
+      t2s_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS per workgroup", FB_SMEM_TOTAL);
       return 3;
     }
-  if (dev >= 0) lds_reserved[dev] = true;
-  }
   {
     // tickets, status and flags: zeroed on every call (a replayed or repeated launch starts from a clean protocol state); the
     // atomic form only needs a clean status word
@@ -1063,16 +1293,25 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
     }
   }
   const int64_t rows = (int64_t)p.B * p.Lq;
+#if FB_DMA
+  // rows behind Lq of the padded row-constant arrays: P = exp2(-inf) = 0 there, and -delta must not be a NaN from an earlier use of
+  // the workspace (0 * NaN); the prep kernel overwrites the rows that exist
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(nl), (int)0xFF800000u, rowc_n, st) != hipSuccess ||
+      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(nd), 0, rowc_n, st) != hipSuccess) {
+    t2s_set_error("attn_bwd_fused: cannot initialise the row-constant arrays");
+    return 3;
+  }
+#endif
   p.kblocks = (max_keys + FB_KEYS - 1) / FB_KEYS;
   hipLaunchKernelGGL(attn_delta_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)p.o, (const bf16_t*)p.dout, p.delta,
-                     (const float*)p.lse, nl, nd, (int)(nqt * FB_QROWS), handoff ? nullptr : dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs,
+                     (const float*)p.lse, FB_DMA ? nl : nullptr, nd, (int)(nqt * FB_QROWS), handoff ? nullptr : dq32, (bf16_t*)p.dk, (bf16_t*)p.dv, p.row_valid, p.valid_len, p.dec_q0, p.n_dec, p.B, p.H, p.Lq, p.o_rs, p.o_bs,
                      p.kv_rs, p.kv_bs, handoff ? slots : nullptr, (int)groups, p.kv_idx ? p.kv_cnt : nullptr, p.idx_cap - p.n_dec, p.kblocks,
                      handoff ? (bf16_t*)p.dq : nullptr, p.q_rs, p.q_bs);
   T2S_CHECK_LAUNCH("attn_bwd_fused (delta prep)");
   dim3 grid(attn_xcd_grid(p.kblocks, p.H, p.B)), block(256), tail(attn_xcd_grid(1, p.H, p.B));
 #define FB_LAUNCH2(IDX_, MODE_, DROP_, grid_)                                                                            \
-  if (handoff) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, true>), grid_, block, FB_SMEM, st, p, w);   \
-  else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, false>), grid_, block, FB_SMEM, st, p, w);
+  if (handoff) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, true>), grid_, block, FB_SMEM_TOTAL, st, p, w);   \
+  else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, false>), grid_, block, FB_SMEM_TOTAL, st, p, w);
 #define FB_LAUNCH(IDX_, MODE_, grid_)                                                                                  \
   if (p.drop_thresh) { FB_LAUNCH2(IDX_, MODE_, true, grid_) } else { FB_LAUNCH2(IDX_, MODE_, false, grid_) }            \
   T2S_CHECK_LAUNCH("attn_bwd_fused (five-product kernel)");

@@ -1,3 +1,5 @@
+// DIAGNOSTIC VARIANT of vitxt_gqa_amd/csrc/attn_fwd_bf16.hip (round-4 source with its experiment switches: -DT2S_FWD_TIMELINE, -DT2S_FWD_DMA=1,
+// -DT2S_FWD_QREG, -DT2S_FWD_OCC=1, -DT2S_FWD_MASK_SKEW=0, T2S_ATTN_FWD_PW=1 -> tools/ablate/attn_fwd_pw_bf16.hip).  Not part of the product library.
 // bf16 flash-attention forward kernel for gfx950 (see attn_fwd.hip for the design notes and the reference call sites:
 // the BERT self-attention of t2s.py:384-432 / 556-633).  Templated on QB = number of 32-row query blocks per wave:
 //   QB = 2: a wave owns 64 query rows (256 per workgroup); every K row fragment and V^T fragment read from LDS feeds
@@ -27,6 +29,7 @@
 #include <stdlib.h>
 
 #include "attn_common.h"
+int launch_attn_fwd_pw_bf16(const AttnParams& p, hipStream_t st);      // tools/ablate/attn_fwd_pw_bf16.hip (link it in for T2S_ATTN_FWD_PW=1)
 
 namespace {
 
@@ -34,16 +37,49 @@ constexpr int BK = 64;                     // keys per tile
 constexpr int TILE_BYTES = BK * 128;       // one 64-row bf16 tile image
 constexpr float BIG = 1.2089258e24f;       // 2^80
 
-// (the experiment forms of this kernel - K / V tiles by LDS-DMA, Q fragments kept in registers, one wave per SIMD, the workgroup
-// timeline, word-by-word dropout masks - live in tools/ablate/attn_fwd_bf16_diag.hip, all measured as nulls or losses: tools/ablate/README.md)
+// -DT2S_FWD_DMA=1 (experiment; default 0): the K / V tiles gathered by LDS-DMA (buffer_load ... lds with a per-lane SOURCE
+// address = the key-list row, the chunk swizzle on that address, one 1 KB piece = 8 rows per wave-instruction) instead of global -> VGPR ->
+// ds_write_b128.  Issued through inline asm for the reason given in attn_bwd_fused_bf16.hip (the compiler would drain the DMA before the
+// next LDS read it cannot prove disjoint); every wave waits for its own pieces ahead of the barrier that publishes the buffer.
+#ifndef T2S_FWD_DMA
+#define T2S_FWD_DMA 0
+#endif
+typedef uint32_t fwd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fwd_u32x4 fwd_rsrc_s(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  fwd_u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) & 0xffffu;
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void fwd_dma16(fwd_u32x4 rs, uint32_t lds, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rs) : "memory", "m0");
+}
+
+// experiment switches (tools/ablate/README.md): T2S_FWD_OCC = waves per SIMD the register budget is sized for,
+// T2S_FWD_QREG = keep the pre-scaled Q fragments in registers instead of re-reading them from LDS every tile
+#ifndef T2S_FWD_OCC
+#define T2S_FWD_OCC 2
+#endif
+#ifdef T2S_FWD_TIMELINE   // diagnostic build only (tools/fwd_timeline.py): start / end of every workgroup on the 100 MHz real-time counter
+__device__ unsigned long long* t2s_fwd_tl = nullptr;
+#endif
+#ifndef T2S_FWD_MASK_SKEW
+#define T2S_FWD_MASK_SKEW 1      // dropout mask words of a fragment formed stage by stage (0: word by word, the form of rounds 2-3)
+#endif
 template <bool USE_IDX, int QB, bool DROP, bool REPAIR>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, T2S_FWD_OCC) void attn_fwd_bf16_kernel(AttnParams p) {
   // [buf][K,V] double buffer, then one pre-scaled (32*QB)-row Q tile per wave
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES + 4 * QB * 32 * 128];
   __shared__ uint32_t ck_s[2][32];                  // dropout: column keys of the tile's 32 key pairs (packed 16-bit halves)
   constexpr int BQ = 128 * QB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   int qblk, h, b;
+#ifdef T2S_FWD_TIMELINE
+  const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (!attn_xcd_tile((p.Lq + BQ - 1) / BQ, p.H, p.B, qblk, h, b)) return;       // workgroup-uniform
   const int q0 = qblk * BQ + wave * (32 * QB);
   if (REPAIR) {   // only workgroups holding a poisoned row (LSE = NaN) do anything
@@ -135,6 +171,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     ri0 = USE_IDX ? (uint32_t)idx[p0_] : (uint32_t)p0_;                                             \
     ri1 = USE_IDX ? (uint32_t)idx[p1_] : (uint32_t)p1_;                                             \
   }
+#if T2S_FWD_DMA
+  // lane (sr, sc) of wave w = row 8 w + lane / 8, chunk POSITION lane % 8 of pieces w and w + 4 of the K and of the V tile: the position holds
+  // the logical chunk sc ^ tile_f(row) (tile_f is the same 32 rows further down), fetched from the lane's key-list row
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t dma_chunk = (uint32_t)((sc ^ tile_f(sr)) * 8);
+  const fwd_u32x4 rs_k = fwd_rsrc_s(K, (uint32_t)(((int64_t)(p.idx_cap > p.Lq ? p.idx_cap : p.Lq) * p.kv_rs) * 2)), rs_v = fwd_rsrc_s(V, (uint32_t)(((int64_t)(p.idx_cap > p.Lq ? p.idx_cap : p.Lq) * p.kv_rs) * 2));
+  const uint32_t smem_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+  int dma_buf = 0;                     // the buffer the next STAGE_LOAD_ROWS fills (uniform)
+#define STAGE_LOAD_ROWS()                                                                           \
+  {                                                                                                 \
+    const uint32_t o0_ = (ri0 * (uint32_t)p.kv_rs + dma_chunk) * 2u;                                \
+    const uint32_t o1_ = (ri1 * (uint32_t)p.kv_rs + dma_chunk) * 2u;                                \
+    const uint32_t d_ = smem_lds + (uint32_t)(dma_buf * 2 * TILE_BYTES + wave_s * 1024);            \
+    fwd_dma16(rs_k, d_, o0_);                                                                       \
+    fwd_dma16(rs_v, d_ + TILE_BYTES, o0_);                                                          \
+    fwd_dma16(rs_k, d_ + 4096, o1_);                                                                \
+    fwd_dma16(rs_v, d_ + TILE_BYTES + 4096, o1_);                                                   \
+  }
+#else
 #define STAGE_LOAD_ROWS()                                                                           \
   {                                                                                                 \
     /* (24-bit multiply: full rate where v_mul_lo_u32 runs at a quarter; rows < 2^24 and the row stride < 2^24 are checked at launch) */ \
@@ -145,11 +200,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     kr1 = *reinterpret_cast<const uint4*>(K + o1_);                                                 \
     vr1 = *reinterpret_cast<const uint4*>(V + o1_);                                                 \
   }
+#endif
+#if T2S_FWD_DMA
+#define DMA_BUF(x_) dma_buf = (x_);
+#else
+#define DMA_BUF(x_)
+#endif
 #define STAGE_LOAD(t_)                                                                              \
   {                                                                                                 \
     IDX_LOAD(t_);                                                                                   \
     STAGE_LOAD_ROWS();                                                                              \
   }
+#if T2S_FWD_DMA
+#define STAGE_WRITE(buf_)      /* the pieces were aimed at dma_buf when they were issued: here they only have to have landed */  \
+  {                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+    if (DROP && tid < 32) ck_s[buf_][tid] = ckreg;                                                  \
+  }
+#else
 #define STAGE_WRITE(buf_)                                                                           \
   {                                                                                                 \
     char* kb_ = smem + (buf_) * 2 * TILE_BYTES + tile_off(sr, sc);                                  \
@@ -159,8 +227,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     *reinterpret_cast<uint4*>(kb_ + TILE_BYTES + 4096) = vr1;                                       \
     if (DROP && tid < 32) ck_s[buf_][tid] = ckreg;                                                  \
   }
+#endif
 
+#ifdef T2S_FWD_QREG
+  bf16x8 qreg[QB][4];
+  __syncthreads();
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qreg[qb][s] = ROW_FRAG(qoff, qb, s);
+#define Q_FRAG(qb_, s_) qreg[qb_][s_]
+#else
 #define Q_FRAG(qb_, s_) ROW_FRAG(qoff, qb_, s_)
+#endif
   f32x16 oacc[QB][2], sacc[QB][2], negm[QB];
   bf16x8 pf[QB][2][2];
   float m_run[QB], l_run[QB];
@@ -181,12 +260,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                   \
       u32x4 w_ = __builtin_bit_cast(u32x4, f_);                                                     \
       const uint32_t th2_ = attn_drop_thresh2s(p.drop_thresh);                                  \
-      {   /* the four mask words stage by stage: no packed instruction right behind the one it depends on */ \
+      if (T2S_FWD_MASK_SKEW) {   /* the four mask words stage by stage: no packed instruction right behind the one it depends on */ \
         u32x4 m_;                                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) m_[i] = attn_drop_kept_mul(rk2[qb_], ck_s[cbuf_][(kbk_) * 16 + 8 * (s_) + 4 * (i >> 1) + (i & 1) + 2 * lh]); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) m_[i] = attn_drop_dropped_sub(m_[i], th2_);   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) m_[i] = attn_drop_kept_mask(m_[i]);          \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) w_[i] = attn_drop_apply(w_[i], m_[i]);        \
+      } else {                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+        w_[i] = attn_drop_apply(w_[i], attn_drop_pair_dropped(rk2[qb_], ck_s[cbuf_][(kbk_) * 16 + 8 * (s_) + 4 * (i >> 1) + (i & 1) + 2 * lh], th2_)); \
       }                                                                                             \
       f_ = __builtin_bit_cast(bf16x8, w_);                                                          \
     }                                                                                               \
@@ -211,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       for (int qb = 0; qb < QB; ++qb) rk2[qb] = attn_drop_rowkey16w(rh[qb], (t * BK) / ATTN_DROP_KWIN) * 0x10001u;
     }
     __syncthreads();
+    DMA_BUF(0);
     STAGE_LOAD(t);
     CK_LOAD(t);
     STAGE_WRITE(0);
@@ -277,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   // ---- steady state: tiles [1, nfast), K/V double-buffered in LDS
   if (nfast > 1) {
     __syncthreads();
+    DMA_BUF(1);
     STAGE_LOAD(1);
     CK_LOAD(1);
     STAGE_WRITE(1);
@@ -295,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   }
     for (int t = 1; t < nfast; ++t) {
       const int buf = t & 1;
+      DMA_BUF(buf ^ 1);
       STAGE_LOAD_ROWS();                                 // tile t+1 (after the last fast tile: an unused, harmless load)
       IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
       CK_LOAD(t + 1);
@@ -361,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #undef IDX_LOAD
 #undef CK_LOAD
 #undef STAGE_WRITE
+#undef DMA_BUF
 
   // ---- epilogue: normalise, stage O through LDS (per-wave 32 x 64 tile, 144-B rows), store whole rows
   __syncthreads();
@@ -397,6 +483,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     }
     if (qb + 1 < QB) __syncthreads();
   }
+#ifdef T2S_FWD_TIMELINE
+  if (!REPAIR && t2s_fwd_tl && lane == 0 && blockIdx.x < 262144u) {
+    unsigned long long* tl = t2s_fwd_tl + (size_t)blockIdx.x * 4;
+    atomicMax(tl + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());      // the LAST wave's end
+    if (wave == 0) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+      tl[0] = tl_r0;
+      tl[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+      tl[3] = (unsigned long long)(unsigned)qblk | ((unsigned long long)(unsigned)b << 16) | ((unsigned long long)(unsigned)h << 32) | ((unsigned long long)(unsigned)nk << 40);
+    }
+  }
+#endif
 }
 
 template <bool DROP, bool REPAIR>
@@ -417,8 +516,14 @@ void launch_fwd(const AttnParams& p, hipStream_t st) {
 }  // namespace
 
 void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st) {
-  // main pass (the one-wave-per-SIMD experiment of round 3, 5-12 % slower on the benchmark shape, is tools/ablate/attn_fwd_pw_bf16.hip)
-  if (p.drop_thresh) launch_fwd<true, false>(p, st);
+  // main pass: this file's two-waves-per-SIMD kernel.  T2S_ATTN_FWD_PW=1 (read per launch, so that one process can run both) sends
+  // sequences longer than one 256-row workgroup to the one-wave-per-SIMD kernel of attn_fwd_pw_bf16.hip instead: an experiment that
+  // is correct (the kernel tests run both) and 5-12 % SLOWER on the benchmark shape - opt-in, for A/B runs.
+  // The repair launch below is this file's either way.
+  const char* pw_env = getenv("T2S_ATTN_FWD_PW");
+  const bool use_pw = pw_env && pw_env[0] == '1';
+  if (use_pw && p.Lq > 256 && !p.drop_thresh && launch_attn_fwd_pw_bf16(p, st) == 0) {      // (without dropout only: round 4's windowed row keys are not in that pipeline)
+  } else if (p.drop_thresh) launch_fwd<true, false>(p, st);
   else launch_fwd<false, false>(p, st);
   // The steady-state loop exists only when some sample can have more than one whole tile of prefix keys; only then can
   // a wave have poisoned its rows.  The repair launch reads the LSE of its rows and returns unless one is NaN.
@@ -428,3 +533,9 @@ void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st) {
   }
 }
 
+#ifdef T2S_FWD_TIMELINE
+extern "C" int t2s_dbg_fwd_timeline(void* buf) {
+  unsigned long long* b = reinterpret_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(t2s_fwd_tl), &b, sizeof(b)) == hipSuccess ? 0 : 1;
+}
+#endif

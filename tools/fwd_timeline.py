@@ -15,7 +15,9 @@ os.makedirs(out, exist_ok=True)
 lib = os.path.join(out, "libt2s_fwd_timeline.so")
 from vitxt_gqa_amd import build as Bld  # noqa: E402
 if not os.path.exists(lib) or os.environ.get("FB_REBUILD", "0") == "1":
-    subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-w", "-DT2S_FWD_TIMELINE"] + ["-o", lib] + Bld.sources())
+    # the product forward source carries no diagnostics: the timeline build links tools/ablate/attn_fwd_bf16_diag.hip in its place
+    srcs = [s_ for s_ in Bld.sources() if not s_.endswith("attn_fwd_bf16.hip")] + [os.path.join(ROOT, "tools", "ablate", "attn_fwd_bf16_diag.hip")]
+    subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-w", "-DT2S_FWD_TIMELINE", "-I" + os.path.join(ROOT, "vitxt_gqa_amd", "csrc")] + ["-o", lib] + srcs)
 os.environ["T2S_HIP_LIB"] = lib
 import torch  # noqa: E402
 from vitxt_gqa_amd import hipext as X  # noqa: E402

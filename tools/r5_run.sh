@@ -21,6 +21,7 @@ for STEP in "$@"; do
              timeout -k 10 600 python3 tools/gemm_probe5.py > $OUT/gemm_probe.txt 2>&1 || { tail -40 $OUT/gemm_probe.txt; exit 1; }; cat $OUT/gemm_probe.txt ;;
     attn)    timeout -k 10 900 python3 -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_dropout_gpu.py -m gpu -x -q > $OUT/pytest_attn.log 2>&1 || { tail -40 $OUT/pytest_attn.log; exit 1; }; tail -2 $OUT/pytest_attn.log
              timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 0.1 > $OUT/attn_probe.txt 2>&1 || { tail -30 $OUT/attn_probe.txt; exit 1; }; cut -c1-200 $OUT/attn_probe.txt ;;
+    guard)   timeout -k 10 600 python3 -m pytest tests/test_handoff_guard_gpu.py -m gpu -x -q > $OUT/pytest_guard.log 2>&1 || { tail -60 $OUT/pytest_guard.log; exit 1; }; tail -3 $OUT/pytest_guard.log ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
 done

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[4] (300 frames x 200 OCR: L = 60 332 rows per question, attention = 93 % of the FLOPs): the attention kernels
 alone at that length, every geometry the build has, interleaved in ONE process:
-  forward   the shipped two-waves-per-SIMD kernel (64-key tiles) vs the one-wave-per-SIMD kernel with 128-key tiles (T2S_ATTN_FWD_PW=1,
-            csrc/attn_fwd_pw_bf16.hip: built in round 3, slower at L = 10 132)
+  forward   the shipped two-waves-per-SIMD kernel (64-key tiles); (round 3-4 also ran the one-wave-per-SIMD kernel with 128-key tiles here:
+            tools/ablate/attn_fwd_pw_bf16.hip, slower, no longer in the product library)
   backward  two-kernel (128-key blocks, 7 products) vs fused 384-key blocks with the dQ hand-off vs fused with fp32 atomics
 over B in {1, 2, 4}, dropout 0.1 and 0.  usage: stress_sweep.py [L1 keep]"""
 import os
@@ -36,8 +36,6 @@ for B in (1, 2, 4):
     for dp in (0.1, 0.0):
         kw = dict(drop_p=dp, drop_seed=7) if dp else {}
         fw = {"fwd shipped (64-key tiles, 2 waves/SIMD)": "0"}
-        if not dp:                                      # (the one-wave-per-SIMD kernel declines dropout launches since the windowed row keys)
-            fw["fwd pw (128-key tiles, 1 wave/SIMD)"] = "1"
         bw = {"bwd two-kernel (128-key blocks)": dict(fused=False), "bwd fused 384 keys, hand-off": dict(fused=True, dq_mode=1),
               "bwd fused 384 keys, atomics": dict(fused=True, dq_mode=0)}
         t = {k: [] for k in list(fw) + list(bw)}

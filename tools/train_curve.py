@@ -26,17 +26,8 @@ opt = build_optimizer(model, cfg)
 sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda it: lr_lambda_update(it, cfg))
 batch = to_device(make_batch(B, F, P, V=V, seed=100), dev)
 batch.grounding_noise = tuple(t.to(dev) for t in make_noise(B, F, P, seed=100))
-# every fused-backward launch leaves a status word (bit 0: a bounded hand-off spin timed out): collect them all
+# every fused-backward launch ORs its status word (bit 0: a bounded hand-off spin timed out) into the device's sticky word and counts itself
 from vitxt_gqa_amd import ops  # noqa: E402
-_ctrl, _orig_fused = [], ops._call_fused
-
-
-def _watched(*a, **k):
-    _orig_fused(*a, **k)
-    _ctrl.append(ops._LAST_FUSED_WS)
-
-
-ops._call_fused = _watched
 launches = timeouts = 0
 print("step  loss          grad_norm     lr            ms")
 for i in range(steps):
@@ -46,7 +37,6 @@ for i in range(steps):
     torch.cuda.synchronize()
     print("%4d  %-12.4f  %-12.4f  %-12.3e  %.1f" % (i, loss.item(), norm.item(), opt.param_groups[0]["lr"], 1e3 * (time.perf_counter() - t0)), flush=True)
     assert torch.isfinite(loss) and torch.isfinite(norm)
-    launches += len(_ctrl)
-    timeouts += sum(int(w.view(torch.int32)[ops.FUSED_CTRL_STATUS_WORD].item()) & 1 for w in _ctrl)
-    _ctrl.clear()
+    launches = ops.fused_launches_seen(dev)
+    timeouts += ops.fused_handoff_status(dev) & 1
 print("fused attention-backward launches: %d (dQ %s), hand-off spins that timed out: %d" % (launches, "hand-off" if ops.ATTN_BWD_DQ_MODE == 1 else "atomics", timeouts))

@@ -61,11 +61,6 @@ __device__ __forceinline__ uint32_t attn_hash32(uint32_t x) {
 __device__ __forceinline__ uint32_t attn_drop_salt(uint32_t seed_lo, uint32_t seed_hi, uint32_t bh) {
   return attn_hash32(seed_lo ^ attn_hash32(seed_hi ^ (bh * 0x9E3779B1u)));
 }
-#ifdef T2S_ABL_NOHASH   // timing-only ablation (tools/ablate): key generation without its cost; never defined in a product build
-__device__ __forceinline__ uint32_t attn_drop_rowhash(uint32_t salt, int q) { return salt + (uint32_t)q; }
-__device__ __forceinline__ uint32_t attn_drop_rowkey16w(uint32_t rowhash, int kwin) { return ((rowhash + (uint32_t)kwin) & 0xFFFFu) | 1u; }
-__device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos, int qwin) { return ((salt ^ (uint32_t)(kpos + qwin)) & 0xFFFFu) | 1u; }
-#else
 __device__ __forceinline__ uint32_t attn_drop_rowhash(uint32_t salt, int q) { return attn_hash32(salt + (uint32_t)q * 0x85EBCA6Bu); }
 // (the window multiplier is itself a HASH of the window index, a wave-uniform scalar computation: with small odd multiples
 //  (2 w + 1) c of one constant, two rows whose hashes differ by d with d c mod 2^32 small collided in EVERY window at once - 4 identical
@@ -81,7 +76,6 @@ __device__ __forceinline__ uint32_t attn_drop_colkey16(uint32_t salt, int kpos, 
   const uint32_t ch = attn_hash32((salt ^ 0xC2B2AE35u) + (uint32_t)kpos * 0x27D4EB2Fu);
   return ((ch * (attn_hash32((uint32_t)qwin * 0x85EBCA6Bu + 0x1b873593u) | 1u)) >> 16) | 1u;
 }
-#endif
 constexpr int ATTN_DROP_KWIN = 384;          // key-list positions per row-key window (the fused backward's key block)
 constexpr int ATTN_DROP_QWIN = 256;          // query rows per column-key window (the forward's workgroup)
 __device__ __forceinline__ uint32_t attn_drop_rowkey16(uint32_t salt, int q, int kwin) { return attn_drop_rowkey16w(attn_drop_rowhash(salt, q), kwin); }
@@ -259,8 +253,6 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 
 // bf16 forward kernel lives in attn_fwd_bf16.hip
 void launch_attn_fwd_bf16(const AttnParams& p, hipStream_t st);
-// one-wave-per-SIMD, hand-placed main pass for long sequences (attn_fwd_pw_bf16.hip); 0 or an error code
-int launch_attn_fwd_pw_bf16(const AttnParams& p, hipStream_t st);
 // bf16 dK/dV kernel lives in attn_dkdv_bf16.hip
 void launch_attn_dkdv_bf16(const AttnParams& p, int max_keys, hipStream_t st);
 // fused 5-product bf16 backward (delta + housekeeping, main kernel, dQ cast) lives in attn_bwd_fused_bf16.hip

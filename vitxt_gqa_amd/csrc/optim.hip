@@ -65,6 +65,22 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
   }
 }
 
+// ---- the sticky status of a train step (a hand-off wait of the fused attention backward timed out: its dQ rows are NaN by
+// construction).  status_accumulate ORs the status word of a launch's workspace into a word that outlives the workspace; status_gate
+// turns the step into a no-op (clip coefficient -1: adam_step_kernel returns at once, parameters, moments and gradients untouched)
+// and the reported norm into NaN; the host raises when it reads the word (optim.py).
+__global__ void status_accumulate_kernel(const unsigned* __restrict__ word, unsigned* __restrict__ sticky) {
+  const unsigned v = *word;
+  if (v) atomicOr(sticky, v);
+  atomicAdd(sticky + 1, 1u);          // launches seen
+}
+__global__ void status_gate_kernel(const unsigned* __restrict__ sticky, float* __restrict__ norm_coef) {
+  if (sticky[0] != 0u) {
+    norm_coef[0] = __builtin_nanf("");
+    norm_coef[1] = -1.f;
+  }
+}
+
 __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, float coef, float lr, const AdamArgs& a) {
   g *= coef;
   m = m + (g - m) * (1.f - a.beta1);                        // exp_avg.lerp_(grad, 1 - beta1)
@@ -83,6 +99,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const int64_t* __restric
   const int64_t n = desc[5 * t + 4];
   const float lr = a.lr[group_of[t]];
   const float coef = coef_p ? coef_p[1] : 1.f;
+  if (coef < 0.f) return;          // the step was gated off (status_gate_kernel): nothing is touched
   const int64_t lo = (int64_t)c * OPT_CHUNK, hi = lo + OPT_CHUNK < n ? lo + OPT_CHUNK : n;
   const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
   if (vec) {
@@ -121,6 +138,21 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const int64_t* __restric
 }  // namespace
 
 extern "C" int t2s_optim_chunk_elems(void) { return OPT_CHUNK; }
+
+extern "C" int t2s_status_accumulate(const void* workspace, int word, void* sticky, t2s_stream_t stream) {
+  T2S_CHECK_ARG(workspace && sticky && word >= 0, "status_accumulate: bad arguments");
+  hipLaunchKernelGGL(status_accumulate_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(workspace) + word,
+                     reinterpret_cast<unsigned*>(sticky));
+  T2S_CHECK_LAUNCH("status_accumulate");
+  return 0;
+}
+
+extern "C" int t2s_status_gate(const void* sticky, float* norm_coef, t2s_stream_t stream) {
+  T2S_CHECK_ARG(sticky && norm_coef, "status_gate: null pointer");
+  hipLaunchKernelGGL(status_gate_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(sticky), norm_coef);
+  T2S_CHECK_LAUNCH("status_gate");
+  return 0;
+}
 
 extern "C" int t2s_grad_sqnorm(const int64_t* desc, const int32_t* chunks, int n_chunks, float* partials, t2s_stream_t stream) {
   T2S_CHECK_ARG(desc && chunks && partials && n_chunks > 0, "grad_sqnorm: null pointer / no chunks");

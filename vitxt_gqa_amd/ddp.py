@@ -173,6 +173,12 @@ class GradBuckets:
             raise RuntimeError("GradBuckets.finish(): %d of %d gradient buckets were never all-reduced: %d parameter(s) of them "
                                "produced no gradient this iteration (candidates: %s)" % (len(missing), len(self.buckets),
                                                                                          sum(self._pending), ", ".join(names[:8])))
+        # a hand-off wait that timed out on ONE rank puts NaN rows into the summed gradients of EVERY rank: the sticky status word
+        # (ops.fused_status_tensor) is exchanged too (MAX), so that every rank's optimizer gates the step off and raises
+        flat0 = self.buckets[0][0] if self.buckets else None
+        if self.collective and flat0 is not None and flat0.is_cuda and self.world > 1:
+            from . import ops
+            self._handles.append(dist.all_reduce(ops.fused_status_tensor(flat0.device), op=dist.ReduceOp.MAX, group=self.group, async_op=True))
         for h in self._handles:
             h.wait()
         self._handles = []

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2S_HIP_LIB") or os.path.join(_HERE, "libt2s_hip.so")      # override: kernel build experiments only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 T2S_F32, T2S_BF16 = 0, 1
 
@@ -52,10 +52,17 @@ _SIGS = {
     "t2s_infonce_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_void_p]),
     "t2s_fasttext_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "t2s_optim_chunk_elems": (c_int, []),
+    "t2s_status_accumulate": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "t2s_status_gate": (c_int, [c_void_p, c_void_p, c_void_p]),
     "t2s_grad_sqnorm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "t2s_clip_coef": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "t2s_adam_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_int, c_void_p, c_int, c_void_p]),
     "t2s_phoc": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "t2s_gelu_tables": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "t2s_gemm_nt_colsum_rows": (c_int, [c_int64]),
+    "t2s_gemm_nt": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int] + [c_void_p] * 5),
+    "t2s_gemm_wgrad_splits": (c_int, [c_int64, c_int, c_int]),
+    "t2s_gemm_wgrad": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -129,16 +129,42 @@ ATTN_BWD_FUSED_MIN_ROWS = 1024
 ATTN_BWD_DQ_MODE = 0 if os.environ.get("T2S_ATTN_BWD_DQ", "handoff") == "atomic" else 1
 _KEEP_DQ32 = os.environ.get("T2S_KEEP_DQ32", "0") == "1"     # tools/fused_stamps.py: keep the workspace, whose tail holds the diagnostic
 _LAST_DQ32 = None                                             # build's cycle stamps (otherwise it is freed with the call: 2 GB at B=64)
-_LAST_FUSED_WS = None                                         # the most recent workspace (its status word: fused_handoff_status())
 FUSED_CTRL_STATUS_WORD = 24                                   # include/t2s_hip.h: uint32 word of the workspace, bit 0 = a hand-off spin timed out
+_STICKY = {}                                                  # device index -> int32 [4]: (OR of every fused launch's status word, launches seen, -, -)
 
 
-def fused_handoff_status():
-    """Status word of the most recent fused-backward call (synchronises): 0 = clean, bit 0 = a bounded spin of the dQ hand-off timed
-    out (dQ of that call is wrong).  Tests and bench.py read it; a timeout cannot happen unless a workgroup died."""
-    if _LAST_FUSED_WS is None:
+class HandoffTimeout(RuntimeError):
+    """A bounded wait of the fused attention backward's dQ hand-off timed out (a workgroup died or the card is oversubscribed): the dQ
+    rows behind it are NaN and the optimizer step that follows is gated off on the device - the gradients of this step are not usable."""
+
+
+def fused_status_tensor(device):
+    """The sticky status words of ``device`` (created on first use).  Every fused-backward call ORs its workspace's status word into
+    word 0 (one 1-thread kernel behind the launch - no copy, no allocation per call); ``FusedClipAdam`` gates its step on it and raises."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _STICKY:
+        _STICKY[key] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return _STICKY[key]
+
+
+def fused_handoff_status(device=None):
+    """OR of the status words of every fused-backward call since the last ``reset_fused_status`` (synchronises): 0 = clean, bit 0 = a
+    bounded spin of the dQ hand-off timed out (the dQ rows behind it are NaN).  A timeout cannot happen unless a workgroup died."""
+    if not _STICKY:
         return 0
-    return int(_LAST_FUSED_WS.view(torch.int32)[FUSED_CTRL_STATUS_WORD].item())
+    if device is None:
+        return int(sum(int(t[0].item()) for t in _STICKY.values()))
+    return int(fused_status_tensor(device)[0].item())
+
+
+def fused_launches_seen(device):
+    return int(fused_status_tensor(device)[1].item())
+
+
+def reset_fused_status():
+    for t in _STICKY.values():
+        t.zero_()
 
 
 def _fused_policy(fused, qkv, keys, L, mode):
@@ -154,14 +180,14 @@ def _fused_policy(fused, qkv, keys, L, mode):
 
 def _call_fused(head, klist3, tail, B, L, mode, device):
     # workspace: control words, hand-off flags and the fp32 dQ sums (either form); cleared as needed inside the call
-    global _LAST_FUSED_WS, _LAST_DQ32
+    global _LAST_DQ32
     nbytes = int(X.lib().t2s_attn_bwd_fused_workspace_bytes(B, HEADS, L))
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
     if _KEEP_DQ32:
         _LAST_DQ32 = ws
     X.check(X.lib().t2s_attn_bwd_fused(*head, X.ptr(ws), nbytes, mode, *klist3, *tail), "t2s_attn_bwd_fused")
-    # keep the 256-byte control block only (a copy enqueued behind the kernels), not the 2 GB workspace
-    _LAST_FUSED_WS = ws[:64].clone()
+    # the launch's status word goes into the device's sticky word (the 2 GB workspace dies with this call)
+    X.check(X.lib().t2s_status_accumulate(X.ptr(ws), FUSED_CTRL_STATUS_WORD, X.ptr(fused_status_tensor(device)), X.stream()), "t2s_status_accumulate")
 
 
 def attn_bwd(qkv, out, dout, lse, keys, scale=1.0 / 8.0, drop_p=0.0, drop_seed=0, fused=None, kv=None, dq_mode=None):

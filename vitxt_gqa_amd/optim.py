@@ -49,6 +49,7 @@ class FusedClipAdam(torch.optim.Adam):
             raise ValueError("FusedClipAdam covers the reference's recipe only: weight_decay 0, no amsgrad")
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
         self._tables = None
+        self._status_probe = None          # (pinned host copy of the device's sticky status words, event): checked at the next step
 
     def _build_tables(self, live):
         from . import hipext as X
@@ -63,7 +64,8 @@ class FusedClipAdam(torch.optim.Adam):
         key = tuple(tuple(d) for d in desc)
         tb = dict(key=key, desc=torch.tensor(desc, dtype=torch.int64, device=dev), group_of=torch.tensor(group_of, dtype=torch.int32, device=dev),
                   chunks=torch.tensor(chunks, dtype=torch.int32, device=dev), n_chunks=len(chunks),
-                  partials=torch.empty(len(chunks), dtype=torch.float32, device=dev), norm_coef=torch.zeros(2, dtype=torch.float32, device=dev))
+                  partials=torch.empty(len(chunks), dtype=torch.float32, device=dev), norm_coef=torch.zeros(2, dtype=torch.float32, device=dev),
+                  unit=torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev))
         self._tables = tb
         return tb
 
@@ -102,18 +104,20 @@ class FusedClipAdam(torch.optim.Adam):
                 import warnings
                 warnings.warn("FusedClipAdam: per-parameter step counts differ (%d distinct values, e.g. after loading a checkpoint whose "
                               "parameters were updated unevenly): taking torch.optim.Adam's foreach path with clip_grad_norm_ instead of "
-                              "the fused clip + Adam kernels on this and every later step" % len(steps))
+                              "the fused clip + Adam kernels while the counts stay uneven (decided anew on every step)" % len(steps))
                 self._warned_uneven = True
+            raise_if_handoff_failed(live[0][1].device)          # (this path has no device-side gate: look before the update)
             norm = None
             if max_norm is not None:
                 norm = torch.nn.utils.clip_grad_norm_([p for _, p in live], max_norm, foreach=True)
+            saved = [g.get("foreach") for g in self.param_groups]
             for g in self.param_groups:
                 g["foreach"] = True
             try:
                 super().step()
             finally:
-                for g in self.param_groups:
-                    g["foreach"] = False
+                for g, v in zip(self.param_groups, saved):
+                    g["foreach"] = v
             return norm
         step = steps.pop() + 1
         tb = self._tables
@@ -128,16 +132,46 @@ class FusedClipAdam(torch.optim.Adam):
                 raise RuntimeError("FusedClipAdam: betas / eps must agree across param groups")
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
         L, st = X.lib(), X.stream()
+        from . import ops
+        dev = live[0][1].device
+        # a hand-off wait of the fused attention backward that timed out in the PREVIOUS step gated that step off on the device
+        # (below); its sticky word was copied to the host behind the step without a synchronisation: look at it now and raise
+        self._check_status_probe()
         nc = None
         if max_norm is not None:
             X.check(L.t2s_grad_sqnorm(X.ptr(tb["desc"]), X.ptr(tb["chunks"]), tb["n_chunks"], X.ptr(tb["partials"]), st), "t2s_grad_sqnorm")
             X.check(L.t2s_clip_coef(X.ptr(tb["partials"]), tb["n_chunks"], float(max_norm), X.ptr(tb["norm_coef"]), st), "t2s_clip_coef")
             nc = tb["norm_coef"]
+        else:
+            nc = tb["norm_coef"]
+            nc.copy_(tb["unit"])          # (norm 0, coefficient 1: no clipping)
+        # the gate: with the sticky status word set (this step's gradients hold NaN rows) the clip coefficient becomes -1 and
+        # t2s_adam_step returns without touching parameters, moments or gradients
+        sticky = ops.fused_status_tensor(dev)
+        X.check(L.t2s_status_gate(X.ptr(sticky), X.ptr(nc), st), "t2s_status_gate")
         X.check(L.t2s_adam_step(X.ptr(tb["desc"]), X.ptr(tb["chunks"]), tb["n_chunks"], X.ptr(tb["group_of"]), lrs, len(self.param_groups),
-                                float(b1), float(b2), float(eps), step, X.ptr(nc), 1 if nc is not None else 0, st), "t2s_adam_step")
+                                float(b1), float(b2), float(eps), step, X.ptr(nc), 1 if max_norm is not None else 0, st), "t2s_adam_step")
         for _, p in live:
             self.state[p]["step"] = torch.tensor(float(step), dtype=torch.float32)
-        return nc[0].clone() if nc is not None else None
+        # the sticky word travels to a pinned host buffer behind the step (asynchronously); the next step - or
+        # raise_if_handoff_failed() at a logging / checkpoint synchronisation point - reads it
+        if self._status_probe is None:
+            self._status_probe = [torch.zeros(4, dtype=torch.int32).pin_memory(), torch.cuda.Event(), dev, False]
+        host, ev, _, _ = self._status_probe
+        host.copy_(sticky, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        self._status_probe[3] = True
+        return nc[0].clone() if max_norm is not None else None
+
+    def _check_status_probe(self):
+        pr = self._status_probe
+        if pr is None or not pr[3]:
+            return
+        host, ev, dev, _ = pr
+        ev.synchronize()          # recorded a whole step ago: complete unless the host runs more than a step ahead
+        pr[3] = False
+        if int(host[0]) != 0:
+            raise_if_handoff_failed(dev)
 
     def step(self, closure=None):
         self.step_clipped(None, closure)
@@ -161,6 +195,19 @@ def build_optimizer(model, config):
     return getattr(torch.optim, oc.type)(groups, **params, **kw)
 
 
+def raise_if_handoff_failed(device=None):
+    """Synchronising check of the sticky status of the fused attention backward (ops.fused_handoff_status): raises
+    ``ops.HandoffTimeout`` when a bounded wait of the dQ hand-off has timed out since the last reset, and clears the word.  Call it
+    where the trainer synchronises anyway (loss logging, checkpoints); ``FusedClipAdam`` also checks the previous step's word at
+    every step without synchronising, and the step in which the timeout happened was gated off on the device."""
+    from . import ops
+    st = ops.fused_handoff_status(device)
+    if st != 0:
+        ops.reset_fused_status()
+        raise ops.HandoffTimeout("fused attention backward: a hand-off wait timed out (status word %d) - the dQ rows behind it are NaN and the "
+                                 "optimizer step of that iteration was skipped on the device; a workgroup died or the card is oversubscribed" % st)
+
+
 def clip_and_step(model, optimizer, config):
     """``clip_gradients`` + ``optimizer.step()`` of BaseTrainer._backward (base_trainer.py:268-270); one fused pass when the
     optimizer is ``FusedClipAdam``.  Returns the gradient norm before clipping (or None)."""
@@ -169,6 +216,8 @@ def clip_and_step(model, optimizer, config):
         if tp["clip_norm_mode"] != "all":
             raise NotImplementedError("Clip norm mode %s not implemented" % tp["clip_norm_mode"])
         return optimizer.step_clipped(tp["max_grad_l2_norm"])
+    if any(p.is_cuda for g in optimizer.param_groups for p in g["params"]):
+        raise_if_handoff_failed()          # an optimizer without the device-side gate: look (and synchronise) before the update
     norm = clip_gradients(model, config) if tp["clip_gradients"] else None
     optimizer.step()
     return norm
