@@ -46,6 +46,7 @@ def test_gemm_nt_store_and_bias(M, N, K):
 def test_gemm_nt_strided_operands_and_accumulate():
     from vitxt_gqa_amd import gemm as G
     M, N, K = 1300, 768, 768
+    torch.manual_seed(11)
     big = (torch.rand(M, 2304, device="cuda") * 2 - 1).to(torch.bfloat16)
     a = big[:, 768:1536]                                   # row stride 2304
     w = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.1).to(torch.bfloat16)
@@ -54,9 +55,12 @@ def test_gemm_nt_strided_operands_and_accumulate():
     G.gemm_nt(a, w, out=c, accumulate=True)
     prod = _ref(a, w).to(torch.bfloat16).double()          # the product is rounded to bf16, then added in fp32 and rounded again
     want = (c0.double() + prod).to(torch.bfloat16)
+    # (the kernel's fp32 sum may round the product one bf16 step away from the fp64 product's rounding: one ulp of the product, and
+    # the second rounding may then flip too: one ulp of the sum)
     diff = (c.double() - want.double()).abs()
-    ulp = want.double().abs() * 2.0 ** -7 + 1e-2
+    ulp = (want.double().abs() + prod.abs()) * 2.0 ** -7 + 1e-2
     assert (diff <= ulp).all(), diff.max().item()
+    assert (diff == 0).double().mean().item() > 0.97
 
 
 @pytest.mark.parametrize("M", [512, 1300])

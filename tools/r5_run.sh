@@ -22,6 +22,19 @@ for STEP in "$@"; do
     attn)    timeout -k 10 900 python3 -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_dropout_gpu.py -m gpu -x -q > $OUT/pytest_attn.log 2>&1 || { tail -40 $OUT/pytest_attn.log; exit 1; }; tail -2 $OUT/pytest_attn.log
              timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 0.1 > $OUT/attn_probe.txt 2>&1 || { tail -30 $OUT/attn_probe.txt; exit 1; }; cut -c1-200 $OUT/attn_probe.txt ;;
     guard)   timeout -k 10 600 python3 -m pytest tests/test_handoff_guard_gpu.py -m gpu -x -q > $OUT/pytest_guard.log 2>&1 || { tail -60 $OUT/pytest_guard.log; exit 1; }; tail -3 $OUT/pytest_guard.log ;;
+    benchab) # same box, back to back: the step with the library GEMMs everywhere, then with the own GEMM family (default)
+             T2S_OWN_GEMM=none timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-dropout0 > $OUT/bench_lib.json 2> $OUT/bench_lib.err || { tail -30 $OUT/bench_lib.err; exit 1; }
+             timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-dropout0 > $OUT/bench_own.json 2> $OUT/bench_own.err || { tail -30 $OUT/bench_own.err; exit 1; }
+             T2S_OWN_GEMM=none timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-dropout0 > $OUT/bench_lib2.json 2> $OUT/bench_lib2.err || { tail -30 $OUT/bench_lib2.err; exit 1; }
+             timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-dropout0 > $OUT/bench_own2.json 2> $OUT/bench_own2.err || { tail -30 $OUT/bench_own2.err; exit 1; }
+             python3 - <<PYEOF
+import json
+for n in ("bench_lib", "bench_own", "bench_lib2", "bench_own2"):
+    d = json.loads(open("$OUT/" + n + ".json").read().strip().splitlines()[-1])
+    print("%-11s %8.2f ms/step  %7.2f samples/s  bwd-group frac %.3f  loss_step0 %s" % (n, d["ms_per_step"], d["value"], d["roofline"]["frac"], d.get("loss_step0")))
+PYEOF
+             ;;
+    dropdyn) timeout -k 10 1100 python3 tools/dropout_dynamics.py ${DD_SEEDS:-5} ${DD_STEPS:-200} > $OUT/dropout_dynamics.txt 2> $OUT/dropout_dynamics.err || { tail -30 $OUT/dropout_dynamics.err; exit 1; }; cat $OUT/dropout_dynamics.txt ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
 done

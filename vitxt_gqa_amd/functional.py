@@ -18,6 +18,7 @@ import threading
 
 import torch
 
+from . import gemm as own
 from . import ops
 
 HID = ops.HID
@@ -32,6 +33,20 @@ RECOMPUTE_ACTIVATIONS = False
 PRUNE_KV_MAX_KEYS = int(os.environ.get("T2S_PRUNE_KV_MAX_KEYS", "2047"))      # (below ops.ATTN_BWD_FUSED_MIN_KEYS: pruned launches take the two-kernel backward)
 
 
+# Which GEMMs of the BERT block run on this build's own MFMA kernels (vitxt_gqa_amd/gemm.py, csrc/gemm_bf16.hip) instead of the library,
+# bf16 operand mode only - the forms measured faster in the step (profiles/r05_gemm_probe.txt):
+#   wgrad     the four weight gradients of a layer: ONE deterministic split-K kernel over all token rows (library: batched GEMM over row
+#             groups + an fp32 sum)
+#   gelu_bwd  dgrad of BertOutput.dense with gelu'(u) and the FFN bias gradient in its epilogue (library GEMM + standalone gelu_bwd pass)
+#   gelu_fwd  BertIntermediate: u and gelu(u) both written by the GEMM (library GEMM + standalone gelu_fwd pass)
+# T2S_OWN_GEMM=none (or a comma list) for same-box A/B runs.
+OWN_GEMM = frozenset(t for t in os.environ.get("T2S_OWN_GEMM", "wgrad,gelu_bwd,gelu_fwd").split(",") if t and t != "none")
+
+
+def _own(kind, *mats):
+    return kind in OWN_GEMM and all(m.dtype == torch.bfloat16 and m.dim() == 2 and m.stride(1) == 1 and m.stride(0) % 8 == 0 for m in mats)
+
+
 def _mm_bias(x2, w, b):
     """x2 [rows, in] @ w[out, in]^T + b  (library GEMM with bias epilogue)."""
     return torch.addmm(b, x2, w.t())
@@ -43,6 +58,8 @@ def _wgrad(dy2, x2, B):
     sample (contraction L) followed by an fp32 sum over the B partial products it runs at 0.8-1.1 PFLOP/s
     (tools/wgrad_probe.py), and the partials are summed in fp32 instead of inside a bf16-output GEMM.  Returns fp32."""
     rows = dy2.size(0)
+    if _own("wgrad", dy2, x2) and own.wgrad_supported(rows, dy2.size(1), x2.size(1)):
+        return own.gemm_wgrad(dy2, x2)
     if B < 2 or rows // B < 1024 or dy2.dtype == F32:
         return (dy2.t() @ x2).float()
     # number of row groups: one per sample, except for the two FFN weights (3072 x 768 / 768 x 3072), where 16 larger groups run 2-3 %
@@ -85,8 +102,11 @@ def _layer_forward(x2, xl, keys, B, L, W, drop_p, seeds, attn_drop_p, recompute,
     del a
     y1_op = y1_lo if lo else y1
     res1 = ops.NormRes(z1, st1, g1, be1) if lo else y1
-    u = _mm_bias(y1_op, w_i, b_i)
-    gact = ops.gelu_fwd(u)
+    if _own("gelu_fwd", y1_op, w_i):
+        u, gact = own.gemm_nt_gelu_dual(y1_op, w_i, b_i)
+    else:
+        u = _mm_bias(y1_op, w_i, b_i)
+        gact = ops.gelu_fwd(u)
     o = _mm_bias(gact, w_o, b_o)
     keep_y2 = materialise or not lo
     y2, y2_lo, z2, st2 = ops.add_layernorm_fwd(o, res1, g2, be2, stream_dtype=F32, want_lo=lo, want_y=keep_y2, drop_p=drop_p, drop_seed=seeds[1])
@@ -114,10 +134,15 @@ def _layer_backward(saved, keys, dy, drop_p, seeds, attn_drop_p, stop_at_qkv=Fal
     if gact is None:
         gact = ops.gelu_fwd(u)
     dw_o = _wgrad(dz2x, gact, B)
-    dgact = dz2x @ w_o_t.t()
-    del gact, dz2x
-    du, db_i = ops.gelu_bwd(dgact, u)
-    del dgact
+    del gact
+    if _own("gelu_bwd", dz2x, w_o_t, u):
+        du, db_i = own.gemm_nt_gelu_grad(dz2x, w_o_t, u)
+        del dz2x
+    else:
+        dgact = dz2x @ w_o_t.t()
+        del dz2x
+        du, db_i = ops.gelu_bwd(dgact, u)
+        del dgact
     if y1_op is None:                                                    # recompute the LN1 output
         y1, y1_lo, _, _ = ops.add_layernorm_fwd(z1, None, g1, be1, save=False, stream_dtype=F32, want_lo=lo, want_y=not lo)
         y1_op = y1_lo if lo else y1
