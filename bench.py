@@ -101,7 +101,7 @@ class _Budget(Exception):
     pass
 
 
-def cpu_baseline(V, seed=0, budget_s=240, full=(100, 100), guard_s=150):
+def cpu_baseline(V, seed=0, budget_s=330, full=(100, 100), guard_s=230):
     """Reference semantics (CPU oracle) timed on the host cores: ONE REAL full train step (forward, both losses, backward, clip,
     Adam; fp32; B=1) at the metric's own shape, 100 frames x 100 OCR tokens (L = 10 132), with the oracle's attention evaluated by
     torch's fused CPU attention on the same additive masks (oracle.ATTENTION_IMPL = "sdpa": BASELINE.md section 3 allows it; the

@@ -131,3 +131,46 @@ def test_gemm_wgrad_rows_behind_the_operands_are_never_read():
         dw = G.gemm_wgrad(dy, x, splits=splits)
         assert torch.isfinite(dw).all()
         assert torch.equal(dw.double(), dy.double().t() @ x.double())
+
+
+def test_bert_layer_with_own_gemms_equals_the_library_form(monkeypatch):
+    """The fused BertLayer function (vitxt_gqa_amd/functional.py) with the own GEMM family (weight gradients, gelu' epilogue, gelu dual
+    epilogue: the default) against the same function with every GEMM on the library (T2S_OWN_GEMM=none): output, input gradient and all
+    16 parameter gradients agree to bf16 noise; the own form is bit-reproducible."""
+    from vitxt_gqa_amd import functional as FN, ops
+    from vitxt_gqa_amd.t2s import BertLayerParams
+    torch.manual_seed(0)
+    lp = BertLayerParams()
+    for p in lp.parameters():
+        p.data.normal_(0, 0.05)
+    lp.attention.output.LayerNorm.weight.data.add_(1.0)
+    lp.output.LayerNorm.weight.data.add_(1.0)
+    lp = lp.to("cuda")
+    B, L1, n_dec = 2, 700, 12
+    L = L1 + n_dec
+    x = torch.randn(B, L, 768, device="cuda").to(torch.bfloat16).float()
+    valid = (torch.rand(B, L1, device="cuda") < 0.6)
+    valid[:, 0] = True
+    dy = torch.randn(B, L, 768, device="cuda").to(torch.bfloat16).float()
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
+
+    def run(own):
+        monkeypatch.setattr(FN, "OWN_GEMM", frozenset(own))
+        for p in lp.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        y, _ = FN.bert_layer(xg, None, keys, lp, torch.bfloat16)
+        y.backward(dy)
+        return y.detach(), xg.grad.clone(), {n: p.grad.clone() for n, p in lp.named_parameters()}
+
+    y0, dx0, g0 = run(())
+    y1, dx1, g1 = run(("wgrad", "gelu_bwd", "gelu_fwd"))
+    y2, dx2, g2 = run(("wgrad", "gelu_bwd", "gelu_fwd"))
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2) and all(torch.equal(g1[n], g2[n]) for n in g1)
+    assert (y1 - y0).abs().max().item() < 3e-2
+    assert (dx1 - dx0).abs().max().item() < 3e-2 * max(1.0, dx0.abs().max().item())
+    for n in g0:
+        rel = (g1[n] - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-6 * g0[n].numel() ** 0.5)
+        if "key.bias" in n:
+            continue
+        assert rel < 2e-2, "%s: own vs library GEMMs rel %.3e" % (n, rel)
