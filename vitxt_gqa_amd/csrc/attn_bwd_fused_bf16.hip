@@ -29,13 +29,16 @@
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int FB_KB = 3;                          // 32-key blocks per wave
-constexpr int FB_WKEYS = 32 * FB_KB;              // 96 keys per wave
-constexpr int FB_KEYS = 4 * FB_WKEYS;             // 384 keys per workgroup
-static_assert(FB_KEYS == ATTN_DROP_KWIN, "a fused key block is one row-key window of the dropout mask");
+constexpr int FB_KB = 2;                          // 32-key blocks per wave
+constexpr int FB_NB = 2 * FB_KB;                  // (query sub-block, key block) blocks of a tile per wave
+constexpr int FB_WKEYS = 32 * FB_KB;              // 64 keys per wave
+constexpr int FB_KEYS = 4 * FB_WKEYS;             // 256 keys per workgroup
+// the dropout mask's row key changes per window of ATTN_DROP_KWIN = 384 key-list positions: a 256-key block lies in one window or
+// straddles two, and then the boundary falls between two WAVES (64 | 384): every wave's keys have ONE window, a block at most two
+static_assert(ATTN_DROP_KWIN % FB_WKEYS == 0 && FB_KEYS <= ATTN_DROP_KWIN, "a wave's keys must lie in one row-key window of the dropout mask");
 constexpr int FB_QROWS = 64;
 constexpr int FB_TILE = FB_QROWS * 128;           // bytes of a 64-row bf16 tile
-constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + (FB_QROWS / 2) * 4;   // Q | dO | -lse*log2e | -delta | dropout row keys (pairs)
+constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + 2 * (FB_QROWS / 2) * 4;   // Q | dO | -lse*log2e | -delta | dropout row keys (pairs) of the block's two windows
 constexpr int FB_KIMG = FB_KEYS * 128;
 constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
 
@@ -184,7 +187,7 @@ __device__ __forceinline__ uint32_t fb_pack2(float a, float b) {
 template <int I, int M, bool DROP>
 __device__ __forceinline__ void fb_g1(f32x16 (&sacc)[2], f32x16 (&dpacc)[2], const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], const bf16x8 (&kf)[4],
                                       const u32x4 (&vf)[FB_KB][4]) {
-  constexpr int s = M / 2, kb = I % 3, par = I & 1;
+  constexpr int s = M / 2, kb = I % FB_KB, par = I & 1;
   if constexpr (M % 2 == 0) FB_MFMA_V(sacc[par], qf[s], kf[s]);
   else if constexpr (DROP && s == 0) FB_MFMA_VAZ(dpacc[par], dof[0], vf[kb][0]);      // dropout: dP from zero, delta subtracted behind the mask
   else FB_MFMA_VA(dpacc[par], dof[s], vf[kb][s]);
@@ -193,7 +196,7 @@ __device__ __forceinline__ void fb_g1(f32x16 (&sacc)[2], f32x16 (&dpacc)[2], con
 template <int I, int M>
 __device__ __forceinline__ void fb_g2(f32x16 (&dvacc)[FB_KB][2], f32x16 (&dkacc)[FB_KB][2], const bf16x8 (&doT)[2][2], const bf16x8 (&qT)[2][2],
                                       const uint32_t (&pfw)[8], const uint32_t (&dsw)[8]) {
-  constexpr int kb = I % 3, s = (M & 3) >> 1, db = M & 1;
+  constexpr int kb = I % FB_KB, s = (M & 3) >> 1, db = M & 1;
   if constexpr (M < 4) {
     const u32x4 b = {pfw[4 * s], pfw[4 * s + 1], pfw[4 * s + 2], pfw[4 * s + 3]};
     FB_MFMA_A(dvacc[kb][db], doT[s][db], b);
@@ -397,6 +400,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     // attention-probability dropout (attn_common.h): this lane's column key of each key block in both 16-bit halves; the row keys of
     // the tile's 32 query pairs are hashed by threads 0..31 while the tile is staged (dkdv kernel's scheme: the same mask function)
     const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
+    // row-key windows of this block's keys (first / last) and of this wave's 64 keys; the tile's row keys are staged for both
+    const int kwin_a = kp0 / ATTN_DROP_KWIN, kwin_b = (kp0 + FB_KEYS - 1) / ATTN_DROP_KWIN;
+    const int kwin_w = __builtin_amdgcn_readfirstlane((kp0 + wave * FB_WKEYS) / ATTN_DROP_KWIN);
+    const int rk_woff = kwin_w != kwin_a ? FB_QROWS / 2 : 0;           // word offset of this wave's row-key set in the stage buffer
     uint32_t ck2[FB_KB];
 #pragma unroll
     for (int kb = 0; kb < FB_KB; ++kb) ck2[kb] = 0u;         // (set per 256-row window of query rows at the top of every fourth tile)
@@ -429,9 +436,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     fb_dma16(rs_o, dst_ + FB_TILE + 4096, voff_o + (r0_ + 32) * o_rs2, 0);                      \
     if (wave_s == 0) fb_dma4(rs_nl, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE), lane * 4, ld_row0 * 4);                   \
     if (wave_s == 1) fb_dma4(rs_nd, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE + FB_QROWS * 4), lane * 4, ld_row0 * 4);    \
-    if (DROP && tid < FB_QROWS / 2) {                                                           \
-      const int qa_ = ld_row0 + 2 * tid, qb2_ = qa_ + 1;                                        \
-      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kbw) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1, kbw) << 16); /* window = this key block */ \
+    if (DROP && tid < FB_QROWS) {        /* threads 0..31: the row pairs under the block's first window, 32..63: under its last */ \
+      const int qa_ = ld_row0 + 2 * (tid & 31), qb2_ = qa_ + 1, kw2_ = tid < 32 ? kwin_a : kwin_b;                                \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kw2_) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1, kw2_) << 16); \
     }                                                                                           \
     ld_row0 += FB_QROWS;                                                                        \
   }
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #define FB_STAGE_WRITE(buf_)                                                                    \
   {                                                                                             \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
-    if (DROP && tid < FB_QROWS / 2) reinterpret_cast<uint32_t*>(stage + (buf_) * FB_STAGE + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
+    if (DROP && tid < FB_QROWS) reinterpret_cast<uint32_t*>(stage + (buf_) * FB_STAGE + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
     st_buf ^= 1;                                                                                \
   }
 #define FB_FLAG_WAIT(addr_, fv_)      /* bounded spin until *addr_ >= ho_wait (fv_: a value already read from it) */  \
@@ -487,10 +494,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   }
 #define FB_LD_SEEDS(lse_, del_, i_)  /* accumulators of block i start from the row constants of this lane's rows (broadcast reads) */  \
   _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
-    const f32x4 l4 = *reinterpret_cast<const f32x4*>((lse_) + ((i_) / 3) * 32 + 8 * g + 4 * lh);    \
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>((lse_) + ((i_) / FB_KB) * 32 + 8 * g + 4 * lh);    \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) sacc[(i_) & 1][4 * g + j] = l4[j];                \
     if (!DROP) {      /* dropout: the dP chain starts from zero, delta is subtracted behind the mask (FB_M) */  \
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>((del_) + ((i_) / 3) * 32 + 8 * g + 4 * lh); \
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>((del_) + ((i_) / FB_KB) * 32 + 8 * g + 4 * lh); \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) dpacc[(i_) & 1][4 * g + j] = d4[j];             \
     }                                                                                               \
   }
@@ -524,10 +531,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         {   // (EDGE: a wave whose 96 keys all lie past the list runs the phase as well - its P is forced to 0; a branch around the
             // phase costs the edge kernel ~100 spilled registers, whose scratch reloads queue behind the atomics, for no gain: the
             // workgroup waits for its busiest wave at the barrier anyway)
-        // Software pipeline over the tile's six blocks b_i = (query sub-block i / 3, key block i % 3).  One wave per SIMD issues in
+        // Software pipeline over the tile's four blocks b_i = (query sub-block i / 2, key block i % 2).  One wave per SIMD issues in
         // order, so an MFMA only overlaps VALU / LDS work that stands BETWEEN it and the next MFMA in the instruction stream.
         // Slots of 8 MFMAs each, fenced into one-MFMA groups:
-        //   G1(b0) | G1(b1) + E(b0) | G2(b0) + M(b0) | G1(b2) + E(b1) | G2(b1) + M(b1) | ... | G1(b5) + E(b4) | G2(b4) + M(b4), E(b5) | G2(b5) + M(b5)
+        //   G1(b0) | G1(b1) + E(b0) | G2(b0) + M(b0) | G1(b2) + E(b1) | G2(b1) + M(b1) | G1(b3) + E(b2) | G2(b2) + M(b2), E(b3) | G2(b3) + M(b3)
         // G1 = S, dP chains (row constants through the C operand of the first MFMA); E = P = exp2(S') and its bf16 operand
         // words (2 v_exp + 1 cvt per group); G2 = 4 dV^T MFMAs (need P) then 4 dK^T MFMAs (need dS); M = dS = P dP' (4 mul + 2 cvt
         // per group, in the dV^T half).  Every consumer stands at least one MFMA group behind the MFMA that produces its input
@@ -536,16 +543,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         bf16x8 qT[2][2], doT[2][2];
         uint32_t mw[8], rkw[8];       // dropout: mask words of the block in its softmax, row-key words of the next one
         f32x4 dl[4];                  // dropout: -delta of the rows of the block whose dS is formed
-        const uint32_t* rk_s = reinterpret_cast<const uint32_t*>(del_s + FB_QROWS);
+        const uint32_t* rk_s = reinterpret_cast<const uint32_t*>(del_s + FB_QROWS) + rk_woff;
 #define FB_LD_RK(i_)     /* row-key words of block i: registers (2m, 2m+1) = rows 8g + 4lh + {0,1} / {2,3}: word (sb*32 + 8g + 4lh)/2 + (m & 1) */ \
   if (DROP) { _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                       \
-    const uint2 w2 = *reinterpret_cast<const uint2*>(rk_s + ((i_) / 3) * 16 + 4 * g + 2 * lh);      \
+    const uint2 w2 = *reinterpret_cast<const uint2*>(rk_s + ((i_) / FB_KB) * 16 + 4 * g + 2 * lh);      \
     rkw[2 * g] = w2.x; rkw[2 * g + 1] = w2.y; } }
 #define FB_LD_DL(i_)                                                                                \
-  if (DROP) { _Pragma("unroll") for (int g = 0; g < 4; ++g) dl[g] = *reinterpret_cast<const f32x4*>(del_s + ((i_) / 3) * 32 + 8 * g + 4 * lh); }
+  if (DROP) { _Pragma("unroll") for (int g = 0; g < 4; ++g) dl[g] = *reinterpret_cast<const f32x4*>(del_s + ((i_) / FB_KB) * 32 + 8 * g + 4 * lh); }
         int thr[2] = {0, 0};          // EDGE: visibility threshold of the block whose softmax runs (by block parity)
         const int rowb = qt * FB_QROWS + 4 * lh;
-#define FB_THR(i_) if (EDGE) thr[(i_) & 1] = qmin[(i_) % 3] - rowb - ((i_) / 3) * 32;
+#define FB_THR(i_) if (EDGE) thr[(i_) & 1] = qmin[(i_) % FB_KB] - rowb - ((i_) / FB_KB) * 32;
         uint32_t pfw[8], dsw[8];
         // 8-byte stores of rows lr and lr + 1 would hit the same LDS banks (the chunk swizzle ignores bit 0 of the row, and an
         // 8-byte store spans half a chunk): odd rows take the other half of the chunk - 10 % of this kernel's LDS cycles were
@@ -559,12 +566,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   }
 #define FB_ST_DS(i_)     /* dS^T image rows of block i: queries sb*32 + 16s + {0..3, 8..11} + 4lh of this lane's key */  \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
-    *reinterpret_cast<uint2*>(dsw_ + ((i_) % 3) * 4096 + (wrow + (((4 * ((i_) / 3) + 2 * s) << 4) ^ wxor))) = make_uint2(dsw[4 * s], dsw[4 * s + 1]);          \
-    *reinterpret_cast<uint2*>(dsw_ + ((i_) % 3) * 4096 + (wrow + (((4 * ((i_) / 3) + 2 * s + 1) << 4) ^ wxor))) = make_uint2(dsw[4 * s + 2], dsw[4 * s + 3]);  \
+    *reinterpret_cast<uint2*>(dsw_ + ((i_) % FB_KB) * 4096 + (wrow + (((4 * ((i_) / FB_KB) + 2 * s) << 4) ^ wxor))) = make_uint2(dsw[4 * s], dsw[4 * s + 1]);          \
+    *reinterpret_cast<uint2*>(dsw_ + ((i_) % FB_KB) * 4096 + (wrow + (((4 * ((i_) / FB_KB) + 2 * s + 1) << 4) ^ wxor))) = make_uint2(dsw[4 * s + 2], dsw[4 * s + 3]);  \
   }
 #define FB_G1(i_, m_) fb_g1<i_, m_, DROP>(sacc, dpacc, qf, dof, kf, vf)
 #define FB_G2(i_, m_) fb_g2<i_, m_>(dvacc, dkacc, doT, qT, pfw, dsw)
-#define FB_E(i_, m_) fb_ve<i_, m_, EDGE, DROP>(sacc, pfw, thr[(i_) & 1], mw, rkw, ck2[(i_) % 3], th2)
+#define FB_E(i_, m_) fb_ve<i_, m_, EDGE, DROP>(sacc, pfw, thr[(i_) & 1], mw, rkw, ck2[(i_) % FB_KB], th2)
 #define FB_M(i_, m_) fb_vm<i_, m_, DROP>(sacc, dpacc, dsw, mw, dl[(m_) >> 1][2 * ((m_) & 1)], dl[(m_) >> 1][2 * ((m_) & 1) + 1], drop_inv)
         // slot "G1(n) + E(e)": eight groups of one MFMA of G1(b_n) and one chunk of E(b_e)
 #define FB_SLOT_G1E(n_, e_)                                                                         \
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   /* the dK^T MFMAs of s = 0 need chunks 0..3 only: chunks 6, 7 of dS are formed beside the first of them (an MFMA group ahead of */   \
   /* the s = 1 MFMAs that read them: the asm MFMAs get no hazard nops), the seeds of block i + 2 are fetched once the last chunk */     \
   /* has read this block's accumulators, the dS^T stores follow */                                                                   \
-  FB_G2(i_, 4); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE(); \
+  FB_G2(i_, 4); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < FB_NB) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE(); \
   FB_G2(i_, 6); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
         if (!PREF) { FB_LD_QF(qb_, dob_, 0); FB_LD_SEEDS(lse_s, del_s, 0); FB_LD_KF(0); }
         FB_FENCE();
@@ -588,33 +595,27 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
         FB_LD_KF(1); FB_FENCE();
-        FB_SLOT_G1E(1, 0);
+        FB_SLOT_G1E(1, 0);                                   // last use of sub-block 0's row fragments and row constants
         // the barrier that ends the PREVIOUS tile (every wave is done reading its dS^T image) stands here, ahead of the first dS^T
         // store of this tile, instead of behind the atomics: a wave that got its atomics out early starts the next tile.  A bare
         // s_barrier: it orders later LDS writes behind earlier LDS reads whose data has long been consumed by MFMAs - nothing
         // to wait for (__syncthreads would drain the LDS loads in flight here)
         asm volatile("s_barrier" ::: "memory");
-        FB_LD_KF(2); FB_FENCE();
-        FB_SLOT_G2M(0);
-        FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
         FB_LD_QF(qb_, dob_, 1); FB_LD_KF(0); FB_FENCE();
-        FB_SLOT_G2M(1);
+        FB_SLOT_G2M(0);
         FB_STAGE_LOAD(); FB_FENCE();
-        FB_SLOT_G1E(3, 2);
+        FB_SLOT_G1E(2, 1);
         FB_LD_KF(1); FB_FENCE();
-        FB_SLOT_G2M(2);                                      // last use of sub-block 0's transposed fragments
+        FB_SLOT_G2M(1);                                      // last use of sub-block 0's transposed fragments
         FB_LD_QT(1); FB_FENCE();
-        FB_SLOT_G1E(4, 3);
-        FB_LD_KF(2); FB_FENCE();
+        FB_SLOT_G1E(3, 2);
+        // slot "G2(b2) + M(b2) + E(b3)": E(b3) only behind the dV^T MFMAs of b2, which still read the operand words of P(b2)
+        FB_G2(2, 0); FB_M(2, 0); FB_M(2, 1); FB_FENCE(); FB_G2(2, 1); FB_M(2, 2); FB_M(2, 3); FB_FENCE();
+        FB_G2(2, 2); FB_M(2, 4); FB_M(2, 5); FB_FENCE(); FB_G2(2, 3); FB_M(2, 6); FB_M(2, 7); FB_FENCE();
+        FB_THR(3); FB_LD_RK(3);
+        FB_G2(2, 4); FB_ST_DS(2); FB_E(3, 0); FB_E(3, 1); FB_FENCE(); FB_G2(2, 5); FB_E(3, 2); FB_E(3, 3); FB_FENCE();
+        FB_G2(2, 6); FB_E(3, 4); FB_E(3, 5); FB_FENCE(); FB_G2(2, 7); FB_E(3, 6); FB_E(3, 7); FB_FENCE();
         FB_SLOT_G2M(3);
-        FB_SLOT_G1E(5, 4);
-        // slot "G2(b4) + M(b4) + E(b5)": E(b5) only behind the dV^T MFMAs of b4, which still read the operand words of P(b4)
-        FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_FENCE();
-        FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_FENCE();
-        FB_THR(5); FB_LD_RK(5);
-        FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 0); FB_E(5, 1); FB_FENCE(); FB_G2(4, 5); FB_E(5, 2); FB_E(5, 3); FB_FENCE();
-        FB_G2(4, 6); FB_E(5, 4); FB_E(5, 5); FB_FENCE(); FB_G2(4, 7); FB_E(5, 6); FB_E(5, 7); FB_FENCE();
-        FB_SLOT_G2M(5);
 #undef FB_THR
 #undef FB_LD_RK
 #undef FB_LD_DL
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
               for (int r = 0; r < 16; ++r) {
                 int qg = qt * FB_QROWS + sb * 32 + acc_row(r, lh);
                 qg = qg < p.Lq ? qg : p.Lq - 1;
-                const bool keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg, kbw), ck16, p.drop_thresh);
+                const bool keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg, kwin_w), ck16, p.drop_thresh);
                 // the chain was seeded with -delta: dP' = dP - delta;  dS = P (keep ? dP / (1-p) : 0) - P delta
                 const float nd = del_s[sb * 32 + acc_row(r, lh)];
                 dpacc[r] = sacc[r] * ((keep ? (dpacc[r] - nd) * drop_inv : 0.f) + nd);
