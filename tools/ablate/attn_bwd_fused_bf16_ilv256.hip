@@ -1,3 +1,16 @@
+// VARIANT, built and measured in round 5, NOT shipped ("re-derive the fused backward's geometry without the atomic floor").
+// 256 keys per workgroup (64 per wave, 128 dK^T / dV^T accumulators), a DOUBLE-BUFFERED dS^T image (2 x 32 KB), the dQ product of tile t - 1
+// inside slot 0 of phase A of tile t (no mid-phase barrier: ONE barrier per tile), its K^T operands resident in 64 AGPRs, the dQ hand-off
+// behind slot 3.  Correct: the 118 attention tests and the 4 hand-off guard tests pass on it (gpurun r5j / r5l).  SLOWER than the shipped
+// 384-key kernel: B = 32, L = 10 132, dropout 0.1: 24.4 - 24.7 ms vs 22.8 ms (profiles/r05_attn_probe_b32_256key_ilv_v{1,2}.txt); with
+// fp32 atomics 28.4 ms (the atomic floor at 256 keys, as round 2 derived).  Stamps (tools/fused_stamps2.py, profiles/r05_fused_ilv_stamps_v{1,2}.txt):
+// the dQ product IS off the critical path (slot 0 with its 24 MFMAs: ~1 150 cycles against the 2 024-cycle phase B of the serial form), but
+// a tile of 256 keys takes ~7 100 cycles against ~8 800 for 384 keys: per key 27.8 vs 22.9.  What binds instead: phase A's vector-issue
+// stream, whose per-BLOCK cost rose from 1 128 to ~1 400 cycles because the software pipeline's ramp (the unpaired first slot, the E / M
+// tail of the last two slots) and the per-tile fixed costs (K^T preload + vmcnt + flag wait 320-420, stage write + sum loads + barrier
+// 285-330, preload behind the barrier 340-400: ~1 000 cycles) are amortised over 4 instead of 6 blocks, and the hand-off moves 1.5 x the
+// bytes per key.  A geometry that helps would have to pipeline phase A ACROSS tiles (no ramp per tile), not shrink the key block.
+// Build: tools/ablate/fb_variants.sh takes this file with FB_SRC=ilv256; tools/fused_stamps2.py stamps it.
 // Fused bf16 flash-attention backward for gfx950, head_dim 64: FIVE matrix products per (query, key) pair.
 //
 // The two-kernel form (attn_dkdv_bf16.hip + attn_dq_bf16_kernel) needs no cross-workgroup sum but computes S = Q K^T and
@@ -29,15 +42,18 @@
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int FB_KB = 3;                          // 32-key blocks per wave
-constexpr int FB_WKEYS = 32 * FB_KB;              // 96 keys per wave
-constexpr int FB_KEYS = 4 * FB_WKEYS;             // 384 keys per workgroup
-static_assert(FB_KEYS == ATTN_DROP_KWIN, "a fused key block is one row-key window of the dropout mask");
+constexpr int FB_KB = 2;                          // 32-key blocks per wave
+constexpr int FB_NB = 2 * FB_KB;                  // (query sub-block, key block) blocks of a tile per wave
+constexpr int FB_WKEYS = 32 * FB_KB;              // 64 keys per wave
+constexpr int FB_KEYS = 4 * FB_WKEYS;             // 256 keys per workgroup
+// the dropout mask's row key changes per window of ATTN_DROP_KWIN = 384 key-list positions: a 256-key block lies in one window or
+// straddles two, and then the boundary falls between two WAVES (64 | 384): every wave's keys have ONE window, a block at most two
+static_assert(ATTN_DROP_KWIN % FB_WKEYS == 0 && FB_KEYS <= ATTN_DROP_KWIN, "a wave's keys must lie in one row-key window of the dropout mask");
 constexpr int FB_QROWS = 64;
 constexpr int FB_TILE = FB_QROWS * 128;           // bytes of a 64-row bf16 tile
-constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + (FB_QROWS / 2) * 4;   // Q | dO | -lse*log2e | -delta | dropout row keys (pairs)
+constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + 2 * (FB_QROWS / 2) * 4;   // Q | dO | -lse*log2e | -delta | dropout row keys (pairs) of the block's two windows
 constexpr int FB_KIMG = FB_KEYS * 128;
-constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
+constexpr int FB_SMEM = 3 * FB_KIMG + 2 * FB_STAGE;       // stage x 2 | K image | dS^T image x 2
 
 // ---- dQ across the key blocks of a (sample, head): two forms, chosen per launch (FbWork::handoff).
 // ATOMIC (rounds 2-3): every key block adds its [64 x 64] tile to an fp32 [B Lq, H 64] buffer with float atomics (memory-side,
@@ -184,7 +200,7 @@ __device__ __forceinline__ uint32_t fb_pack2(float a, float b) {
 template <int I, int M, bool DROP>
 __device__ __forceinline__ void fb_g1(f32x16 (&sacc)[2], f32x16 (&dpacc)[2], const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], const bf16x8 (&kf)[4],
                                       const u32x4 (&vf)[FB_KB][4]) {
-  constexpr int s = M / 2, kb = I % 3, par = I & 1;
+  constexpr int s = M / 2, kb = I % FB_KB, par = I & 1;
   if constexpr (M % 2 == 0) FB_MFMA_V(sacc[par], qf[s], kf[s]);
   else if constexpr (DROP && s == 0) FB_MFMA_VAZ(dpacc[par], dof[0], vf[kb][0]);      // dropout: dP from zero, delta subtracted behind the mask
   else FB_MFMA_VA(dpacc[par], dof[s], vf[kb][s]);
@@ -193,7 +209,7 @@ __device__ __forceinline__ void fb_g1(f32x16 (&sacc)[2], f32x16 (&dpacc)[2], con
 template <int I, int M>
 __device__ __forceinline__ void fb_g2(f32x16 (&dvacc)[FB_KB][2], f32x16 (&dkacc)[FB_KB][2], const bf16x8 (&doT)[2][2], const bf16x8 (&qT)[2][2],
                                       const uint32_t (&pfw)[8], const uint32_t (&dsw)[8]) {
-  constexpr int kb = I % 3, s = (M & 3) >> 1, db = M & 1;
+  constexpr int kb = I % FB_KB, s = (M & 3) >> 1, db = M & 1;
   if constexpr (M < 4) {
     const u32x4 b = {pfw[4 * s], pfw[4 * s + 1], pfw[4 * s + 2], pfw[4 * s + 3]};
     FB_MFMA_A(dvacc[kb][db], doT[s][db], b);
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const stage = smem;                        // 2 x (Q tile | dO tile | -lse*log2e | -delta)
   char* const kimg = smem + 2 * FB_STAGE;          // [384 keys][64 d] bf16, tile_off swizzle
-  char* const dsimg = kimg + FB_KIMG;              // [384 keys][64 q] bf16, same layout
+  char* const dsimg = kimg + FB_KIMG;              // 2 x [256 keys][64 q] bf16, same layout: tile t's dS^T goes to image t & 1 in the interleaved sweep
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   float* __restrict__ const dq32 = w.part;         // (atomic form)
   int kblk, h, b;
@@ -397,6 +413,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     // attention-probability dropout (attn_common.h): this lane's column key of each key block in both 16-bit halves; the row keys of
     // the tile's 32 query pairs are hashed by threads 0..31 while the tile is staged (dkdv kernel's scheme: the same mask function)
     const uint32_t salt = DROP ? attn_drop_salt(p.drop_seed_lo, p.drop_seed_hi, (uint32_t)(b * p.H + h)) : 0u;
+    // row-key windows of this block's keys (first / last) and of this wave's 64 keys; the tile's row keys are staged for both
+    const int kwin_a = kp0 / ATTN_DROP_KWIN, kwin_b = (kp0 + FB_KEYS - 1) / ATTN_DROP_KWIN;
+    const int kwin_w = __builtin_amdgcn_readfirstlane((kp0 + wave * FB_WKEYS) / ATTN_DROP_KWIN);
+    const int rk_woff = kwin_w != kwin_a ? FB_QROWS / 2 : 0;           // word offset of this wave's row-key set in the stage buffer
     uint32_t ck2[FB_KB];
 #pragma unroll
     for (int kb = 0; kb < FB_KB; ++kb) ck2[kb] = 0u;         // (set per 256-row window of query rows at the top of every fourth tile)
@@ -429,9 +449,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     fb_dma16(rs_o, dst_ + FB_TILE + 4096, voff_o + (r0_ + 32) * o_rs2, 0);                      \
     if (wave_s == 0) fb_dma4(rs_nl, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE), lane * 4, ld_row0 * 4);                   \
     if (wave_s == 1) fb_dma4(rs_nd, st_lds + (uint32_t)(st_buf * FB_STAGE + 2 * FB_TILE + FB_QROWS * 4), lane * 4, ld_row0 * 4);    \
-    if (DROP && tid < FB_QROWS / 2) {                                                           \
-      const int qa_ = ld_row0 + 2 * tid, qb2_ = qa_ + 1;                                        \
-      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kbw) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1, kbw) << 16); /* window = this key block */ \
+    if (DROP && tid < FB_QROWS) {        /* threads 0..31: the row pairs under the block's first window, 32..63: under its last */ \
+      const int qa_ = ld_row0 + 2 * (tid & 31), qb2_ = qa_ + 1, kw2_ = tid < 32 ? kwin_a : kwin_b;                                \
+      rkreg = attn_drop_rowkey16(salt, qa_ < p.Lq ? qa_ : p.Lq - 1, kw2_) | (attn_drop_rowkey16(salt, qb2_ < p.Lq ? qb2_ : p.Lq - 1, kw2_) << 16); \
     }                                                                                           \
     ld_row0 += FB_QROWS;                                                                        \
   }
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #define FB_STAGE_WRITE(buf_)                                                                    \
   {                                                                                             \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
-    if (DROP && tid < FB_QROWS / 2) reinterpret_cast<uint32_t*>(stage + (buf_) * FB_STAGE + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
+    if (DROP && tid < FB_QROWS) reinterpret_cast<uint32_t*>(stage + (buf_) * FB_STAGE + 2 * FB_TILE + 2 * FB_QROWS * 4)[tid] = rkreg; \
     st_buf ^= 1;                                                                                \
   }
 #define FB_FLAG_WAIT(addr_, fv_)      /* bounded spin until *addr_ >= ho_wait (fv_: a value already read from it) */  \
@@ -475,10 +495,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     auto sweep = [&](auto pipe_tag, auto edge_tag) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(pipe_tag)::value;         // the software-pipelined phase A (all three key blocks of every wave run)
     constexpr bool EDGE = decltype(edge_tag)::value;         // ... with the validity / decoder rule applied to P
-    constexpr bool PREF = FULL && !EDGE;                     // the first operands of tile t+1 are fetched from LDS during phase B of tile t
+    constexpr bool PREF = FULL && !EDGE;                     // the first operands of tile t+1 are fetched from LDS behind the barrier that ends tile t
+    // ILV (round 5): the dQ product ("phase B") of tile t - 1 runs INSIDE phase A of tile t.  With 256 keys per workgroup
+    // the dS^T image is double-buffered (2 x 32 KB), so phase A of tile t fills image t & 1 while the 16 dQ MFMAs of tile t - 1 read image
+    // (t - 1) & 1 from slot 0, the one slot of the software pipeline that has no VALU work of its own (G1(b0) alone): its MFMA count goes
+    // from 8 to 24 and it becomes matrix-bound.  ONE barrier per tile is left (dS^T image of tile t complete + stage buffer of tile t + 1
+    // published); the mid-phase barrier of the 384-key form ("every wave is done reading the dS^T image") is gone, because nobody writes the
+    // image being read.  Hazards: image t & 1 was last READ by the dQ MFMAs of tile t - 2 in slot 0 of tile t - 1, the barrier that ends tile
+    // t - 1 lies between; it is first WRITTEN in slot 2 of tile t.  The edge sweep and the tail launch keep the serial form on image 0.
+    constexpr bool ILV = PREF;
     constexpr bool CAN_LAST = EDGE || !FULL;                 // hand-off: only an edge block (or the tail launch) can end a pair's chain
     bf16x8 qf[4], dof[4], kf[4];
     f32x16 sacc[2], dpacc[2];
+    bf16x8 afA[4];                                 // dS^T operands of the dQ product in flight (ILV: four 16-key steps ahead)
+    u32x4 pin[4];                                  // hand-off: the predecessor's running sum of the tile whose dQ is being formed
+    f32x16 dqacc;
     const char* kw_ = kimg + wave * (FB_WKEYS * 128);
 #define FB_LD_QF(qbase_, dobase_, sb_)                                                              \
   _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
@@ -487,20 +518,82 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   }
 #define FB_LD_SEEDS(lse_, del_, i_)  /* accumulators of block i start from the row constants of this lane's rows (broadcast reads) */  \
   _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
-    const f32x4 l4 = *reinterpret_cast<const f32x4*>((lse_) + ((i_) / 3) * 32 + 8 * g + 4 * lh);    \
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>((lse_) + ((i_) / FB_KB) * 32 + 8 * g + 4 * lh);    \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) sacc[(i_) & 1][4 * g + j] = l4[j];                \
     if (!DROP) {      /* dropout: the dP chain starts from zero, delta is subtracted behind the mask (FB_M) */  \
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>((del_) + ((i_) / 3) * 32 + 8 * g + 4 * lh); \
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>((del_) + ((i_) / FB_KB) * 32 + 8 * g + 4 * lh); \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) dpacc[(i_) & 1][4 * g + j] = d4[j];             \
     }                                                                                               \
   }
 #define FB_LD_KF(kb_)                                                                               \
   _Pragma("unroll") for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kw_ + ka[s] + (kb_) * 4096);
+    // ILV: the K^T operands of the dQ product (this wave's 32 dims x the workgroup's 256 keys: 16 fragments) do not depend on the query
+    // tile: with 128 instead of 192 dK^T / dV^T accumulators there is room to keep them in 64 AGPRs for the whole sweep (an MFMA B operand
+    // may be an AGPR) - half of the dQ product's LDS reads gone (slot 0 ran at the LDS bandwidth with them: profiles/r05_fused_ilv_stamps_v1.txt)
+    u32x4 ktf[FB_KEYS / 16];
+    if constexpr (ILV) {
+#pragma unroll
+      for (int k = 0; k < FB_KEYS / 16; ++k) {
+        ktf[k] = FB_U4(fb_tr(kimg + (16 * k) * 128, vad));
+        asm volatile("" : "+a"(ktf[k]));
+      }
+      // (slot 0 of tile 0 multiplies operands of a tile that does not exist: defined values, result dropped)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) afA[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     if (PREF) {          // tile 0's first operands (stage buffer 0 was written and fenced by the barrier above)
       FB_LD_QF(stage, stage + FB_TILE, 0);
       FB_LD_SEEDS(reinterpret_cast<const float*>(stage + 2 * FB_TILE), reinterpret_cast<const float*>(stage + 2 * FB_TILE) + FB_QROWS, 0);
       FB_LD_KF(0);
     }
+    // dQ of query tile tq leaves this block: dqacc (= c dS K over the block's keys; dQ = acc * ln 2) joins the running sum of the pair's
+    // earlier blocks (hand-off: stored write-through for the successor, or - last block of the pair - rounded to bf16 and written as
+    // dQ), or goes to the fp32 buffer by atomics.  Register r = query row acc_row(r, lh), 32 consecutive dims per half wave: two
+    // 128-byte segments per wave instruction.
+#define FB_DQ_FINALIZE(tq_)                                                                         \
+  {                                                                                                 \
+    asm volatile("s_nop 11" : "+v"(dqacc));              /* MFMA result -> VALU read */              \
+    const int q0 = (tq_) * FB_QROWS + dq_qb * 32;                                                   \
+    if constexpr (HO) {                                                                             \
+      const unsigned ho_off = (unsigned)(((tq_) * 4 + wave_u) * 4096 + lane * 16);                  \
+      f32x16 tot;                                                                                   \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
+        /* (bit_cast of the WHOLE vector, then the element: bit_cast(float, pin[g][j]) is narrowed by this clang to a one-dword load */ \
+        /* whose value stands in for all four elements - seen in the ISA) */                        \
+        const f32x4 pf = __builtin_bit_cast(f32x4, pin[r >> 2]);                                    \
+        tot[r] = __builtin_fmaf(dqacc[r], ho_ln2, pf[r & 3]);                                       \
+      }                                                                                             \
+      if (CAN_LAST && ho_last) {                                                                    \
+        /* the last block of the pair: dQ rows in bf16.  Lanes 2i / 2i+1 hold columns 2i / 2i+1 of the same rows: the even lane */   \
+        /* takes the odd lane's value of register 2m, the odd lane the even lane's value of register 2m+1 (DPP quad_perm 1,0,3,2), */ \
+        /* each then stores ONE 4-byte pair of its own row */                                       \
+        bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.q_bs + h * 64 + dq_db * 32 + (lr & ~1);                       \
+        const bool odd = lr & 1;                                                                    \
+        _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                             \
+          const float a = tot[2 * m], bb = tot[2 * m + 1];                                          \
+          const float send = odd ? a : bb;                                                          \
+          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true)); \
+          const int row = q0 + acc_row(2 * m, lh) + (odd ? 1 : 0);                                  \
+          if (row < p.Lq) *reinterpret_cast<uint32_t*>(dqp + (int64_t)row * p.q_rs) = odd ? fb_pack2(recv, bb) : fb_pack2(a, recv);   \
+        }                                                                                           \
+      } else {                                                                                      \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
+          const f32x4 t4 = {tot[4 * g], tot[4 * g + 1], tot[4 * g + 2], tot[4 * g + 3]};            \
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 16 /* sc1: write-through */); \
+        }                                                                                           \
+      }                                                                                             \
+    } else {                                                                                        \
+      const int rstep = p.H * 64;                                                                   \
+      float* rowp = DQ + (int64_t)q0 * rstep + dq_db * 32;          /* wave-uniform (dq_qb / dq_db come from readfirstlane) */       \
+      const int loff = lr + 4 * lh * rstep;                          /* this lane's element offset */                                \
+      if (q0 + 32 <= p.Lq) {                               /* whole sub-block inside the sequence */                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) unsafeAtomicAdd(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f); \
+      } else {                                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                              \
+          if (q0 + acc_row(r, lh) < p.Lq) unsafeAtomicAdd(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f); \
+      }                                                                                             \
+    }                                                                                               \
+  }
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
       if (DROP && (qt & (ATTN_DROP_QWIN / FB_QROWS - 1)) == 0) {      // a new 256-row window of query rows: re-hash this lane's three column keys
@@ -524,10 +617,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         {   // (EDGE: a wave whose 96 keys all lie past the list runs the phase as well - its P is forced to 0; a branch around the
             // phase costs the edge kernel ~100 spilled registers, whose scratch reloads queue behind the atomics, for no gain: the
             // workgroup waits for its busiest wave at the barrier anyway)
-        // Software pipeline over the tile's six blocks b_i = (query sub-block i / 3, key block i % 3).  One wave per SIMD issues in
+        // Software pipeline over the tile's four blocks b_i = (query sub-block i / 2, key block i % 2).  One wave per SIMD issues in
         // order, so an MFMA only overlaps VALU / LDS work that stands BETWEEN it and the next MFMA in the instruction stream.
         // Slots of 8 MFMAs each, fenced into one-MFMA groups:
-        //   G1(b0) | G1(b1) + E(b0) | G2(b0) + M(b0) | G1(b2) + E(b1) | G2(b1) + M(b1) | ... | G1(b5) + E(b4) | G2(b4) + M(b4), E(b5) | G2(b5) + M(b5)
+        //   G1(b0) | G1(b1) + E(b0) | G2(b0) + M(b0) | G1(b2) + E(b1) | G2(b1) + M(b1) | G1(b3) + E(b2) | G2(b2) + M(b2), E(b3) | G2(b3) + M(b3)
         // G1 = S, dP chains (row constants through the C operand of the first MFMA); E = P = exp2(S') and its bf16 operand
         // words (2 v_exp + 1 cvt per group); G2 = 4 dV^T MFMAs (need P) then 4 dK^T MFMAs (need dS); M = dS = P dP' (4 mul + 2 cvt
         // per group, in the dV^T half).  Every consumer stands at least one MFMA group behind the MFMA that produces its input
@@ -536,21 +629,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         bf16x8 qT[2][2], doT[2][2];
         uint32_t mw[8], rkw[8];       // dropout: mask words of the block in its softmax, row-key words of the next one
         f32x4 dl[4];                  // dropout: -delta of the rows of the block whose dS is formed
-        const uint32_t* rk_s = reinterpret_cast<const uint32_t*>(del_s + FB_QROWS);
+        const uint32_t* rk_s = reinterpret_cast<const uint32_t*>(del_s + FB_QROWS) + rk_woff;
 #define FB_LD_RK(i_)     /* row-key words of block i: registers (2m, 2m+1) = rows 8g + 4lh + {0,1} / {2,3}: word (sb*32 + 8g + 4lh)/2 + (m & 1) */ \
   if (DROP) { _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                       \
-    const uint2 w2 = *reinterpret_cast<const uint2*>(rk_s + ((i_) / 3) * 16 + 4 * g + 2 * lh);      \
+    const uint2 w2 = *reinterpret_cast<const uint2*>(rk_s + ((i_) / FB_KB) * 16 + 4 * g + 2 * lh);      \
     rkw[2 * g] = w2.x; rkw[2 * g + 1] = w2.y; } }
 #define FB_LD_DL(i_)                                                                                \
-  if (DROP) { _Pragma("unroll") for (int g = 0; g < 4; ++g) dl[g] = *reinterpret_cast<const f32x4*>(del_s + ((i_) / 3) * 32 + 8 * g + 4 * lh); }
+  if (DROP) { _Pragma("unroll") for (int g = 0; g < 4; ++g) dl[g] = *reinterpret_cast<const f32x4*>(del_s + ((i_) / FB_KB) * 32 + 8 * g + 4 * lh); }
         int thr[2] = {0, 0};          // EDGE: visibility threshold of the block whose softmax runs (by block parity)
         const int rowb = qt * FB_QROWS + 4 * lh;
-#define FB_THR(i_) if (EDGE) thr[(i_) & 1] = qmin[(i_) % 3] - rowb - ((i_) / 3) * 32;
+#define FB_THR(i_) if (EDGE) thr[(i_) & 1] = qmin[(i_) % FB_KB] - rowb - ((i_) / FB_KB) * 32;
         uint32_t pfw[8], dsw[8];
         // 8-byte stores of rows lr and lr + 1 would hit the same LDS banks (the chunk swizzle ignores bit 0 of the row, and an
         // 8-byte store spans half a chunk): odd rows take the other half of the chunk - 10 % of this kernel's LDS cycles were
         // bank conflicts of these stores (profiles/mfma_busy.json, round 2 / 3)
-        char* dsw_ = dsimg + wave * (FB_WKEYS * 128) + 8 * (lh ^ (lr & 1));
+        char* dsw_ = dsimg + (ILV ? (qt & 1) * FB_KIMG : 0) + wave * (FB_WKEYS * 128) + 8 * (lh ^ (lr & 1));
 #define FB_LD_QT(sb_)                                                                               \
   _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                     \
   _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                \
@@ -559,12 +652,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   }
 #define FB_ST_DS(i_)     /* dS^T image rows of block i: queries sb*32 + 16s + {0..3, 8..11} + 4lh of this lane's key */  \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                   \
-    *reinterpret_cast<uint2*>(dsw_ + ((i_) % 3) * 4096 + (wrow + (((4 * ((i_) / 3) + 2 * s) << 4) ^ wxor))) = make_uint2(dsw[4 * s], dsw[4 * s + 1]);          \
-    *reinterpret_cast<uint2*>(dsw_ + ((i_) % 3) * 4096 + (wrow + (((4 * ((i_) / 3) + 2 * s + 1) << 4) ^ wxor))) = make_uint2(dsw[4 * s + 2], dsw[4 * s + 3]);  \
+    *reinterpret_cast<uint2*>(dsw_ + ((i_) % FB_KB) * 4096 + (wrow + (((4 * ((i_) / FB_KB) + 2 * s) << 4) ^ wxor))) = make_uint2(dsw[4 * s], dsw[4 * s + 1]);          \
+    *reinterpret_cast<uint2*>(dsw_ + ((i_) % FB_KB) * 4096 + (wrow + (((4 * ((i_) / FB_KB) + 2 * s + 1) << 4) ^ wxor))) = make_uint2(dsw[4 * s + 2], dsw[4 * s + 3]);  \
   }
 #define FB_G1(i_, m_) fb_g1<i_, m_, DROP>(sacc, dpacc, qf, dof, kf, vf)
 #define FB_G2(i_, m_) fb_g2<i_, m_>(dvacc, dkacc, doT, qT, pfw, dsw)
-#define FB_E(i_, m_) fb_ve<i_, m_, EDGE, DROP>(sacc, pfw, thr[(i_) & 1], mw, rkw, ck2[(i_) % 3], th2)
+#define FB_E(i_, m_) fb_ve<i_, m_, EDGE, DROP>(sacc, pfw, thr[(i_) & 1], mw, rkw, ck2[(i_) % FB_KB], th2)
 #define FB_M(i_, m_) fb_vm<i_, m_, DROP>(sacc, dpacc, dsw, mw, dl[(m_) >> 1][2 * ((m_) & 1)], dl[(m_) >> 1][2 * ((m_) & 1) + 1], drop_inv)
         // slot "G1(n) + E(e)": eight groups of one MFMA of G1(b_n) and one chunk of E(b_e)
 #define FB_SLOT_G1E(n_, e_)                                                                         \
@@ -580,41 +673,64 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   /* the dK^T MFMAs of s = 0 need chunks 0..3 only: chunks 6, 7 of dS are formed beside the first of them (an MFMA group ahead of */   \
   /* the s = 1 MFMAs that read them: the asm MFMAs get no hazard nops), the seeds of block i + 2 are fetched once the last chunk */     \
   /* has read this block's accumulators, the dS^T stores follow */                                                                   \
-  FB_G2(i_, 4); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE(); \
+  FB_G2(i_, 4); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < FB_NB) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE(); \
   FB_G2(i_, 6); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
         if (!PREF) { FB_LD_QF(qb_, dob_, 0); FB_LD_SEEDS(lse_s, del_s, 0); FB_LD_KF(0); }
         FB_FENCE();
-        // slot 0: G1(b0), nothing to pair yet; the transposed fragments of sub-block 0 arrive meanwhile
+        // slot 0: G1(b0), no VALU work of this tile to pair yet; the transposed fragments of sub-block 0 arrive meanwhile.
+        // ILV: the 16 dQ MFMAs of the PREVIOUS tile ride here, two behind every G1 MFMA, each followed by the transposed reads of the
+        // step four ahead (into the registers it just released).  Tile 0 has no predecessor: its MFMAs run on whatever the image
+        // holds and the result is dropped (no branch in the slot).
+        if constexpr (ILV) {
+          const char* dsp_ = dsimg + ((qt & 1) ^ 1) * FB_KIMG;
+#define FB_DQ_STEP(k_)                                                                              \
+  if ((k_) == 0) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dqacc) : "v"(FB_U4(afA[0])), "a"(ktf[0]));                  \
+  else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(afA[(k_) & 3])), "a"(ktf[(k_)]));                  \
+  if ((k_) + 4 < FB_KEYS / 16) afA[(k_) & 3] = fb_tr(dsp_ + (16 * ((k_) + 4)) * 128, vaq);                                         \
+  FB_FENCE();
+          FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_DQ_STEP(0); FB_DQ_STEP(1);
+          FB_G1(0, 1); FB_FENCE(); FB_DQ_STEP(2); FB_DQ_STEP(3);
+          FB_G1(0, 2); FB_FENCE(); FB_DQ_STEP(4); FB_DQ_STEP(5);
+          FB_G1(0, 3); FB_FENCE(); FB_DQ_STEP(6); FB_DQ_STEP(7);
+          FB_G1(0, 4); FB_FENCE(); FB_DQ_STEP(8); FB_DQ_STEP(9);
+          FB_G1(0, 5); FB_FENCE(); FB_DQ_STEP(10); FB_DQ_STEP(11);
+          FB_G1(0, 6); FB_FENCE(); FB_DQ_STEP(12); FB_DQ_STEP(13);
+          FB_G1(0, 7); FB_FENCE(); FB_DQ_STEP(14); FB_DQ_STEP(15);
+        } else {
         FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
+        }
         FB_LD_KF(1); FB_FENCE();
-        FB_SLOT_G1E(1, 0);
+        FB_SLOT_G1E(1, 0);                                   // last use of sub-block 0's row fragments and row constants
+        if constexpr (!ILV) {
         // the barrier that ends the PREVIOUS tile (every wave is done reading its dS^T image) stands here, ahead of the first dS^T
         // store of this tile, instead of behind the atomics: a wave that got its atomics out early starts the next tile.  A bare
         // s_barrier: it orders later LDS writes behind earlier LDS reads whose data has long been consumed by MFMAs - nothing
         // to wait for (__syncthreads would drain the LDS loads in flight here)
         asm volatile("s_barrier" ::: "memory");
-        FB_LD_KF(2); FB_FENCE();
-        FB_SLOT_G2M(0);
-        FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
+        }
         FB_LD_QF(qb_, dob_, 1); FB_LD_KF(0); FB_FENCE();
-        FB_SLOT_G2M(1);
+        FB_SLOT_G2M(0);
         FB_STAGE_LOAD(); FB_FENCE();
-        FB_SLOT_G1E(3, 2);
+        FB_SLOT_G1E(2, 1);
+        if constexpr (ILV) {
+          // dQ of the previous tile leaves here: running sum + this block's share -> the hand-off buffer (or the atomics).  Not right
+          // behind slot 0: the predecessor's sum, requested just ahead of the last barrier, takes ~2 000 cycles to arrive
+          // (profiles/r05_fused_ilv_stamps_v1.txt: 400 cycles of slot 1 were that wait)
+          if (qt > 0) { FB_DQ_FINALIZE(qt - 1); }
+        }
         FB_LD_KF(1); FB_FENCE();
-        FB_SLOT_G2M(2);                                      // last use of sub-block 0's transposed fragments
+        FB_SLOT_G2M(1);                                      // last use of sub-block 0's transposed fragments
         FB_LD_QT(1); FB_FENCE();
-        FB_SLOT_G1E(4, 3);
-        FB_LD_KF(2); FB_FENCE();
+        FB_SLOT_G1E(3, 2);
+        // slot "G2(b2) + M(b2) + E(b3)": E(b3) only behind the dV^T MFMAs of b2, which still read the operand words of P(b2)
+        FB_LD_DL(2);                                         // (b2 is the first block of sub-block 1: its rows' -delta)
+        FB_G2(2, 0); FB_M(2, 0); FB_M(2, 1); FB_FENCE(); FB_G2(2, 1); FB_M(2, 2); FB_M(2, 3); FB_FENCE();
+        FB_G2(2, 2); FB_M(2, 4); FB_M(2, 5); FB_FENCE(); FB_G2(2, 3); FB_M(2, 6); FB_M(2, 7); FB_FENCE();
+        FB_THR(3); FB_LD_RK(3);
+        FB_G2(2, 4); FB_ST_DS(2); FB_E(3, 0); FB_E(3, 1); FB_FENCE(); FB_G2(2, 5); FB_E(3, 2); FB_E(3, 3); FB_FENCE();
+        FB_G2(2, 6); FB_E(3, 4); FB_E(3, 5); FB_FENCE(); FB_G2(2, 7); FB_E(3, 6); FB_E(3, 7); FB_FENCE();
         FB_SLOT_G2M(3);
-        FB_SLOT_G1E(5, 4);
-        // slot "G2(b4) + M(b4) + E(b5)": E(b5) only behind the dV^T MFMAs of b4, which still read the operand words of P(b4)
-        FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_FENCE();
-        FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_FENCE();
-        FB_THR(5); FB_LD_RK(5);
-        FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 0); FB_E(5, 1); FB_FENCE(); FB_G2(4, 5); FB_E(5, 2); FB_E(5, 3); FB_FENCE();
-        FB_G2(4, 6); FB_E(5, 4); FB_E(5, 5); FB_FENCE(); FB_G2(4, 7); FB_E(5, 6); FB_E(5, 7); FB_FENCE();
-        FB_SLOT_G2M(5);
 #undef FB_THR
 #undef FB_LD_RK
 #undef FB_LD_DL
@@ -678,7 +794,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
               for (int r = 0; r < 16; ++r) {
                 int qg = qt * FB_QROWS + sb * 32 + acc_row(r, lh);
                 qg = qg < p.Lq ? qg : p.Lq - 1;
-                const bool keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg, kbw), ck16, p.drop_thresh);
+                const bool keep = attn_drop_keep16(attn_drop_rowkey16(salt, qg, kwin_w), ck16, p.drop_thresh);
                 // the chain was seeded with -delta: dP' = dP - delta;  dS = P (keep ? dP / (1-p) : 0) - P delta
                 const float nd = del_s[sb * 32 + acc_row(r, lh)];
                 dpacc[r] = sacc[r] * ((keep ? (dpacc[r] - nd) * drop_inv : 0.f) + nd);
@@ -704,20 +820,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         }
       }
       }   // general form
-      // Stage the next tile here, at the end of phase A: the global loads issued at the top of the tile have long landed (the
-      // LDS writes wait on vmcnt, which retires in order - behind the 16 atomics of phase B that wait would last their
-      // ~3000-cycle round trip), the buffer was last read in phase A of the previous tile, and the barrier below publishes it,
-      // so that phase B can already fetch the next tile's first operands.
-      // K^T fragments of the first two groups of the dQ product: they do not depend on this tile, so they are fetched ahead of
-      // the barrier (their registers were the transposed Q / dO fragments until a moment ago)
-      bf16x8 afA[4], bfA[4], afB[4], bfB[4];
-      if constexpr (PREF) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { bfA[u] = fb_tr(kimg + (16 * u) * 128, vad); bfB[u] = fb_tr(kimg + (16 * (4 + u)) * 128, vad); }
-      }
-      // hand-off: the running sum of the blocks before this one (zeros for block 0: zero-record descriptor)
-      u32x4 pin[4];
-      const unsigned ho_off = (unsigned)((qt * 4 + wave_u) * 4096 + lane * 16);
+      // Stage the next tile here, at the end of phase A: its DMA pieces, issued a third of the way into the phase, have long landed; the
+      // buffer was last read in phase A of the previous tile, and the barrier below publishes it.
+      // K^T fragments of the first steps of the dQ product: they do not depend on this tile, so they are fetched ahead of the barrier
+      // (their registers were the transposed Q / dO fragments until a moment ago)
       if constexpr (HO) {
         // every wave: its running-sum stores of the PREVIOUS tile have landed (the flag below is stored behind this wait and the
         // barrier: Guideline 16 R1); the stage loads of this tile are younger and are needed right below anyway
@@ -726,11 +832,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       }
       FB_STAGE_WRITE(buf ^ 1);
       if constexpr (HO) {
-        // this wave's own poll has matched: its loads of the sum may go out now (every load of handed-off bytes is an sc1 load issued
-        // by a wave behind its own matching poll) - ahead of the barrier, behind the staging wait (which would wait for them too),
-        // so that they have the barrier and all of phase B to come back
+        // hand-off: the running sum of the blocks before this one (zeros for block 0: zero-record descriptor).  This wave's own poll has
+        // matched: its loads of the sum may go out now (every load of handed-off bytes is an sc1 load issued by a wave behind its own
+        // matching poll) - ahead of the barrier, behind the staging wait (which would wait for them too); they have the barrier and the
+        // dQ MFMAs of this tile (ILV: slot 0 of the next tile) to come back
+        const unsigned ho_ld = (unsigned)((qt * 4 + wave_u) * 4096 + lane * 16);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pin[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ho_off + g * 1024, 0, 16 /* sc1 */);
+        for (int g = 0; g < 4; ++g) pin[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ho_ld + g * 1024, 0, 16 /* sc1 */);
       }
       __syncthreads();                                       // the dS^T image of this query tile is complete
       if constexpr (HO && !TAIL) {
@@ -738,13 +846,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         if ((!CAN_LAST || !ho_last) && tid == 0 && qt > 0 && !w.never_publish)
           __hip_atomic_store(flags_pair + (qt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // ================= phase B: dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
-      {
-        f32x16 dqacc;
+      if constexpr (ILV) {
+        // the dQ product of this tile runs in slot 0 of the next one (or in the drain behind the loop): its first dS^T fragments and
+        // the next tile's first operands (its stage buffer was published by the barrier above) are fetched here
+        const char* dsc_ = dsimg + (qt & 1) * FB_KIMG;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) afA[k] = fb_tr(dsc_ + (16 * k) * 128, vaq);
+        const char* nq_ = stage + (buf ^ 1) * FB_STAGE;
+        FB_LD_QF(nq_, nq_ + FB_TILE, 0);
+        FB_LD_SEEDS(reinterpret_cast<const float*>(nq_ + 2 * FB_TILE), reinterpret_cast<const float*>(nq_ + 2 * FB_TILE) + FB_QROWS, 0);
+        FB_LD_KF(0);
+        FB_FENCE();
+      } else {
+      // ================= phase B (serial form): dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqacc[i] = 0.f;
-        // steps of 16 keys in groups of 4; full key blocks: 24 steps with the transposed reads of group g+1 in flight under the
-        // MFMAs of group g, otherwise the steps that hold valid keys (rows past them may never have been written)
+        // steps of 16 keys in groups of 4, the steps that hold valid keys (rows past them may never have been written)
 #define FB_DQ_LOAD_A(af_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) af_[u] = fb_tr(dsimg + (16 * (4 * (g_) + u)) * 128, vaq);
 #define FB_DQ_LOAD_B(bf_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) bf_[u] = fb_tr(kimg + (16 * (4 * (g_) + u)) * 128, vad);
 #define FB_DQ_LOAD(af_, bf_, g_) FB_DQ_LOAD_A(af_, g_) FB_DQ_LOAD_B(bf_, g_)
@@ -757,37 +874,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       : "+v"(dqacc)                                                                                 \
       : "v"(FB_U4(af_[0])), "v"(FB_U4(af_[1])), "v"(FB_U4(af_[2])), "v"(FB_U4(af_[3])), "v"(FB_U4(bf_[0])), "v"(FB_U4(bf_[1])),  \
         "v"(FB_U4(bf_[2])), "v"(FB_U4(bf_[3])));
-        if constexpr (PREF) {
-          // 24 steps of 16 keys, eight steps of operands in flight: step k's MFMA is followed in the stream by the four transposed
-          // reads of step k + 8 (into the registers it just released), so the reads run under the MFMAs instead of between them
-          // (reads and MFMAs of this phase measured ADDITIVE in the grouped form: tools/fused_stamps.py)
-          // afA/bfA hold steps k with (k & 7) < 4, afB/bfB those with (k & 7) >= 4; the K^T fragments of steps 0..7 were fetched
-          // ahead of the barrier
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            if (k < 4) afA[k] = fb_tr(dsimg + (16 * k) * 128, vaq);
-            else afB[k & 3] = fb_tr(dsimg + (16 * k) * 128, vaq);
-          }
-          {   // the next tile's first operands (its stage buffer was published by the barrier above)
-            const char* nq_ = stage + (buf ^ 1) * FB_STAGE;
-            FB_LD_QF(nq_, nq_ + FB_TILE, 0);
-            FB_LD_SEEDS(reinterpret_cast<const float*>(nq_ + 2 * FB_TILE), reinterpret_cast<const float*>(nq_ + 2 * FB_TILE) + FB_QROWS, 0);
-            FB_LD_KF(0);
-          }
-          FB_FENCE();
-#pragma unroll
-          for (int k = 0; k < FB_KEYS / 16; ++k) {
-            const bool hiHalf = (k & 7) >= 4;
-            bf16x8& a_ = hiHalf ? afB[k & 3] : afA[k & 3];
-            bf16x8& b_ = hiHalf ? bfB[k & 3] : bfA[k & 3];
-            asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(a_)), "v"(FB_U4(b_)));
-            if (k + 8 < FB_KEYS / 16) {
-              a_ = fb_tr(dsimg + (16 * (k + 8)) * 128, vaq);
-              b_ = fb_tr(kimg + (16 * (k + 8)) * 128, vad);
-            }
-            FB_FENCE();
-          }
-        } else {
+        {
           const int nsteps = FULL ? (EDGE ? nks : FB_KEYS / 16) : nks;
           int k4 = 0;
           for (; k4 + 4 <= nsteps; k4 += 4) {
@@ -804,57 +891,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_DQ_LOAD_A
 #undef FB_DQ_LOAD_B
 #undef FB_DQ_MFMA
-        asm volatile("s_nop 11" : "+v"(dqacc));              // MFMA result -> VALU read
-        // dS (K c) = c dS K;  dQ = scale dS K = acc * ln 2.  Register r = query row acc_row(r, lh), 32 consecutive dims per
-        // half wave: two 128-byte segments per wave instruction
-        const int q0 = qt * FB_QROWS + dq_qb * 32;
-        if constexpr (HO) {
-          f32x16 tot;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            // (bit_cast of the WHOLE vector, then the element: bit_cast(float, pin[g][j]) is narrowed by this clang to a one-dword load
-            // whose value stands in for all four elements - seen in the ISA)
-            const f32x4 pf = __builtin_bit_cast(f32x4, pin[r >> 2]);
-            tot[r] = __builtin_fmaf(dqacc[r], ho_ln2, pf[r & 3]);
-          }
-          if (CAN_LAST && ho_last) {
-            // the last block of the pair: dQ rows in bf16.  Lanes 2i / 2i+1 hold columns 2i / 2i+1 of the same rows: the even lane
-            // takes the odd lane's value of register 2m, the odd lane the even lane's value of register 2m+1 (DPP quad_perm 1,0,3,2),
-            // each then stores ONE 4-byte pair of its own row
-            bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.q_bs + h * 64 + dq_db * 32 + (lr & ~1);
-            const bool odd = lr & 1;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-              const float a = tot[2 * m], bb = tot[2 * m + 1];
-              const float send = odd ? a : bb;
-              const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
-              const int row = q0 + acc_row(2 * m, lh) + (odd ? 1 : 0);
-              if (row < p.Lq) *reinterpret_cast<uint32_t*>(dqp + (int64_t)row * p.q_rs) = odd ? fb_pack2(recv, bb) : fb_pack2(a, recv);
-            }
-          } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const f32x4 t4 = {tot[4 * g], tot[4 * g + 1], tot[4 * g + 2], tot[4 * g + 3]};
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 16 /* sc1: write-through */);
-            }
-          }
-        } else {
-        const int rstep = p.H * 64;
-        float* rowp = DQ + (int64_t)q0 * rstep + dq_db * 32;          // wave-uniform (dq_qb / dq_db come from readfirstlane)
-        const int loff = lr + 4 * lh * rstep;                          // this lane's element offset
-#define FB_DQ_OUT(ptr_, v_) unsafeAtomicAdd(ptr_, v_)
-        if (q0 + 32 <= p.Lq) {                               // whole sub-block inside the sequence
-#pragma unroll
-          for (int r = 0; r < 16; ++r) FB_DQ_OUT(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (q0 + acc_row(r, lh) < p.Lq) FB_DQ_OUT(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
-        }
-#undef FB_DQ_OUT
-        }
+        FB_DQ_FINALIZE(qt);
+        if constexpr (!FULL) __syncthreads();                // every wave is done reading the dS^T image (pipelined edge sweep: see phase A)
       }
-      if constexpr (!FULL) __syncthreads();                  // every wave is done reading the dS^T image (pipelined form: see phase A)
+    }
+    if constexpr (ILV) {
+      // drain: the dQ product of the LAST tile (its dS^T image was completed by the loop's last barrier, its first operands are in
+      // registers, its predecessor sum is on its way)
+      const char* dsp_ = dsimg + ((nqt - 1) & 1) * FB_KIMG;
+      FB_DQ_STEP(0); FB_DQ_STEP(1); FB_DQ_STEP(2); FB_DQ_STEP(3); FB_DQ_STEP(4); FB_DQ_STEP(5); FB_DQ_STEP(6); FB_DQ_STEP(7);
+      FB_DQ_STEP(8); FB_DQ_STEP(9); FB_DQ_STEP(10); FB_DQ_STEP(11); FB_DQ_STEP(12); FB_DQ_STEP(13); FB_DQ_STEP(14); FB_DQ_STEP(15);
+      FB_DQ_FINALIZE(nqt - 1);
     }
     if constexpr (HO) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last tile's stores (the tail launch reads them back in its next key block)
@@ -875,6 +922,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_LD_QF
 #undef FB_LD_SEEDS
 #undef FB_LD_KF
+#undef FB_DQ_FINALIZE
+#undef FB_DQ_STEP
     // dK^T / dV^T were last written by asm MFMAs the compiler does not see as such: cover MFMA result -> v_accvgpr_read
 #pragma unroll
     for (int kb = 0; kb < FB_KB; ++kb)

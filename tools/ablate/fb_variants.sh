@@ -13,5 +13,5 @@ for f in $src/*.hip $src/*.cpp; do
   b=$(basename $f); [ $b = attn_bwd_fused_bf16.hip ] && continue
   [ $out/obj/$b.o -nt $f ] || echo $f
 done | xargs -P 8 -I{} sh -c "/opt/rocm/bin/hipcc $flags -c {} -o $out/obj/\$(basename {}).o"
-for spec in "$@"; do echo "$spec"; done | xargs -P 8 -I{} sh -c 'spec="{}"; name=${spec%%=*}; fl=${spec#*=}; /opt/rocm/bin/hipcc '"$flags"' $fl -c '"$root"'/tools/ablate/attn_bwd_fused_bf16_diag.hip -o '"$out"'/obj/fbv_$name.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o '"$out"'/libt2s_fb_$name.so $(ls '"$out"'/obj/*.o | grep -v "fbv_\|pw_abl\|attn_bwd_fused_bf16") '"$out"'/obj/fbv_$name.o'
+for spec in "$@"; do echo "$spec"; done | xargs -P 8 -I{} sh -c 'spec="{}"; name=${spec%%=*}; fl=${spec#*=}; /opt/rocm/bin/hipcc '"$flags"' $fl -I'"$src"' -c '"$root"'/tools/ablate/attn_bwd_fused_bf16_${FB_SRC:-diag}.hip -o '"$out"'/obj/fbv_$name.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o '"$out"'/libt2s_fb_$name.so $(ls '"$out"'/obj/*.o | grep -v "fbv_\|pw_abl\|attn_bwd_fused_bf16") '"$out"'/obj/fbv_$name.o'
 ls -la $out/libt2s_fb_*.so

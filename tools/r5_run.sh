@@ -35,6 +35,10 @@ for n in ("bench_lib", "bench_own", "bench_lib2", "bench_own2"):
 PYEOF
              ;;
     dropdyn) timeout -k 10 1100 python3 tools/dropout_dynamics.py ${DD_SEEDS:-5} ${DD_STEPS:-200} > $OUT/dropout_dynamics.txt 2> $OUT/dropout_dynamics.err || { tail -30 $OUT/dropout_dynamics.err; exit 1; }; cat $OUT/dropout_dynamics.txt ;;
+    stamps2) timeout -k 10 600 python3 tools/fused_stamps2.py 8 0.7 0.1 > $OUT/fused_stamps_ilv.txt 2>&1 || { tail -30 $OUT/fused_stamps_ilv.txt; exit 1; }
+             timeout -k 10 600 python3 tools/fused_stamps2.py 8 0.7 0.0 >> $OUT/fused_stamps_ilv.txt 2>&1 || { tail -30 $OUT/fused_stamps_ilv.txt; exit 1; }; cat $OUT/fused_stamps_ilv.txt ;;
+    fwdstamps) timeout -k 10 600 python3 tools/fwd_stamps.py 8 0.7 0.1 > $OUT/fwd_stamps.txt 2>&1 || { tail -30 $OUT/fwd_stamps.txt; exit 1; }
+             timeout -k 10 600 python3 tools/fwd_stamps.py 8 0.7 0.0 >> $OUT/fwd_stamps.txt 2>&1 || { tail -30 $OUT/fwd_stamps.txt; exit 1; }; cat $OUT/fwd_stamps.txt ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
 done
