@@ -491,7 +491,7 @@ def test_attention_entry_points_refuse_bad_arguments():
                                     x.stride(1), x.stride(0), kv_rs, x.stride(0), out.stride(1), out.stride(0),
                                     0.125, X.dtype_code(x), 0.0, 0, X.stream())
     assert fwd(x.stride(1)) == 0
-    for bad in (1 << 24, 1 << 22):                       # stride too wide for a 24-bit multiply; 256 rows x 2^22 x 4 B = 4 GB
+    for bad in (1 << 24, 1 << 23):                       # 256 rows x 2^24 (or 2^23) elements x 2 B >= 4 GB of 32-bit byte offsets
         rc = fwd(bad)
         assert rc != 0
         with pytest.raises(RuntimeError, match="span < 4 GB"):

@@ -39,6 +39,17 @@ PYEOF
              timeout -k 10 600 python3 tools/fused_stamps2.py 8 0.7 0.0 >> $OUT/fused_stamps_ilv.txt 2>&1 || { tail -30 $OUT/fused_stamps_ilv.txt; exit 1; }; cat $OUT/fused_stamps_ilv.txt ;;
     fwdstamps) timeout -k 10 600 python3 tools/fwd_stamps.py 8 0.7 0.1 > $OUT/fwd_stamps.txt 2>&1 || { tail -30 $OUT/fwd_stamps.txt; exit 1; }
              timeout -k 10 600 python3 tools/fwd_stamps.py 8 0.7 0.0 >> $OUT/fwd_stamps.txt 2>&1 || { tail -30 $OUT/fwd_stamps.txt; exit 1; }; cat $OUT/fwd_stamps.txt ;;
+    fwdab)   # same box, interleaved: the product forward vs a variant source (FWD_VARIANT=name, tools/ablate/variants/attn_fwd_<name>.hip)
+             bash tools/ablate/fwd_variant.sh ${FWD_VARIANT} tools/ablate/variants/attn_fwd_${FWD_VARIANT}.hip > $OUT/fwd_variant_build.log 2>&1 || { tail -20 $OUT/fwd_variant_build.log; exit 1; }
+             T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fwd_${FWD_VARIANT}.so timeout -k 10 600 python3 -m pytest tests/test_kernels_gpu.py tests/test_dropout_gpu.py -m gpu -x -q -k "fwd or forward or dropout or attention" > $OUT/pytest_fwd_variant.log 2>&1 || { tail -30 $OUT/pytest_fwd_variant.log; exit 1; }; tail -2 $OUT/pytest_fwd_variant.log
+             rm -f $OUT/fwd_ab.txt
+             for rep in 1 2 3; do
+               echo "== product" >> $OUT/fwd_ab.txt
+               T2S_PROBE_FORMS=shipped timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 0.1 2>&1 | grep "fwd " | sed -E 's/ \| bwd.*$//' >> $OUT/fwd_ab.txt
+               echo "== variant ${FWD_VARIANT}" >> $OUT/fwd_ab.txt
+               T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fwd_${FWD_VARIANT}.so timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 0.1 2>&1 | grep "fwd " | sed -E 's/ \| bwd.*$//' >> $OUT/fwd_ab.txt
+             done
+             cat $OUT/fwd_ab.txt | cut -c1-150 ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
 done

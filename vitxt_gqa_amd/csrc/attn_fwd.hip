@@ -203,10 +203,14 @@ int check_common(const AttnParams& p, int dtype) {
   T2S_CHECK_ARG(p.q_rs % al == 0 && p.kv_rs % al == 0 && p.o_rs % al == 0 && p.q_bs % al == 0 && p.kv_bs % al == 0 && p.o_bs % al == 0,
                 "attn: strides must be multiples of 16 bytes");
   T2S_CHECK_ARG(p.B <= 65535 && p.H <= 65535, "attn: B/H exceed grid limits");
-  // the kernels address a sample's K / V rows by 32-bit byte offsets built with 24-bit multiplies (row index x row stride)
+  // the kernels address a sample's K / V rows by 32-bit BYTE offsets (row index x row stride x element size) ...
   const int64_t rows = p.idx_cap > p.Lq ? p.idx_cap : p.Lq;
-  T2S_CHECK_ARG(p.kv_rs > 0 && p.kv_rs < ((int64_t)1 << 24) && rows < ((int64_t)1 << 24) && rows * p.kv_rs * 4 < ((int64_t)1 << 32),
-                "attn: a sample's K / V rows must span < 4 GB (rows %lld, row stride %lld)", (long long)rows, (long long)p.kv_rs);
+  const int64_t esz = dtype == T2S_BF16 ? 2 : 4;
+  T2S_CHECK_ARG(p.kv_rs > 0 && rows * p.kv_rs * esz < ((int64_t)1 << 32),
+                "attn: a sample's K / V rows must span < 4 GB (rows %lld x row stride %lld x %lld bytes)", (long long)rows, (long long)p.kv_rs, (long long)esz);
+  // ... which the bf16 kernels build with 24-bit multiplies (__umul24: full rate where v_mul_lo_u32 runs at a quarter)
+  T2S_CHECK_ARG(dtype != T2S_BF16 || (p.kv_rs < ((int64_t)1 << 24) && rows < ((int64_t)1 << 24)),
+                "attn (bf16): rows %lld and row stride %lld must both be < 2^24 (24-bit multiplies)", (long long)rows, (long long)p.kv_rs);
   return 0;
 }
 
