@@ -459,6 +459,9 @@ def main():
         from vitxt_gqa_amd import ops as _ops
         # how the fused attention backward sums dQ across key blocks, and the OR of the status words of EVERY call of the run (0: no
         # bounded spin of the hand-off ever timed out; read here, behind the timed region's synchronisation)
+        from vitxt_gqa_amd import functional as _FN
+        # which GEMMs of the BERT block ran on the own MFMA kernels (csrc/gemm_bf16.hip) instead of the library (T2S_OWN_GEMM)
+        res["own_gemm"] = sorted(_FN.OWN_GEMM)
         res["attn_bwd_dq"] = {"mode": "ordered hand-off (bit-reproducible)" if _ops.ATTN_BWD_DQ_MODE == 1 else "fp32 atomics",
                               "status": _ops.fused_handoff_status()}
         res["loss"] = float(last.detach())
