@@ -15,7 +15,8 @@ os.makedirs(out, exist_ok=True)
 from vitxt_gqa_amd import build as Bld  # noqa: E402
 lib = os.path.join(out, "libt2s_stamp2.so")
 diag = os.path.join(out, "attn_bwd_fused_bf16_stamp.hip")
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ablate", "make_fb_diag.py"), diag])
+WHICH = os.environ.get("FB_SRC", "ilv256")       # "ilv256": the 256-key variant; "ilv384": the 384-key interleaved variant
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ablate", "make_fb_diag.py"), WHICH, diag])
 srcs = [s for s in Bld.sources() if not s.endswith("attn_bwd_fused_bf16.hip")] + [diag]
 subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-w", "-o", lib] + srcs)
 os.environ["T2S_HIP_LIB"] = lib
@@ -41,13 +42,15 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = ops._LAST_DQ32.view(torch.uint8)[-16384:].view(torch.int64).view(-1, 8)[:256].cpu()
 d = d[d[:, 6] > 0]
-names = ["slot 0: G1(b0) + 16 dQ MFMAs", "slots 1..3, dQ hand-off", "slots 4..7", "K^T preload, vmcnt(0), flag wait", "stage write, sum loads, barrier", "preload behind the barrier"]
+names = (["slot 0: G1(b0) + 16 dQ MFMAs", "slots 1..3, dQ hand-off", "slots 4..7"] if WHICH == "ilv256" else
+         ["slot 0: G1(b0) + 12 dQ MFMAs", "slot 1: G1(b1) + E(b0) + 12 dQ MFMAs, hand-off", "slots 2..11"]) + [ "K^T preload, vmcnt(0), flag wait", "stage write, sum loads, barrier", "preload behind the barrier"]
+mfmas = 80 if WHICH == "ilv256" else 120
 tiles = d[:, 6].double()
 per = d[:, :6].double() / tiles.unsqueeze(1)
 print("dropout %.2f, B = %d: workgroups sampled %d, tiles per workgroup %d" % (dp, B, len(d), int(tiles[0])))
 tot = per.sum(1).mean().item()
 for i, n in enumerate(names):
     print("  %-36s %8.0f cycles per tile  (%4.1f %%)" % (n, per[:, i].mean().item(), 100 * per[:, i].mean().item() / tot))
-print("  %-36s %8.0f cycles per tile (stamped build; MFMA time of a tile: 80 x 32 = 2560)" % ("sum", tot))
+print("  %-36s %8.0f cycles per tile (stamped build; MFMA time of a tile: %d x 32 = %d)" % ("sum", tot, mfmas, mfmas * 32))
 clk = d[:, 7].double().mean().item() / 1e4
 print("  shader clock over the sweep: %.2f GHz; a tile = %.2f us" % (clk, tot / clk / 1e3))

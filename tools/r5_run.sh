@@ -35,7 +35,8 @@ for n in ("bench_lib", "bench_own", "bench_lib2", "bench_own2"):
 PYEOF
              ;;
     dropdyn) timeout -k 10 1100 python3 tools/dropout_dynamics.py ${DD_SEEDS:-5} ${DD_STEPS:-200} > $OUT/dropout_dynamics.txt 2> $OUT/dropout_dynamics.err || { tail -30 $OUT/dropout_dynamics.err; exit 1; }; cat $OUT/dropout_dynamics.txt ;;
-    stamps2) timeout -k 10 600 python3 tools/fused_stamps2.py 8 0.7 0.1 > $OUT/fused_stamps_ilv.txt 2>&1 || { tail -30 $OUT/fused_stamps_ilv.txt; exit 1; }
+    stamps2) # FB_SRC=ilv384 stamps the 384-key interleaved variant, default the 256-key variant
+             timeout -k 10 600 python3 tools/fused_stamps2.py 8 0.7 0.1 > $OUT/fused_stamps_ilv.txt 2>&1 || { tail -30 $OUT/fused_stamps_ilv.txt; exit 1; }
              timeout -k 10 600 python3 tools/fused_stamps2.py 8 0.7 0.0 >> $OUT/fused_stamps_ilv.txt 2>&1 || { tail -30 $OUT/fused_stamps_ilv.txt; exit 1; }; cat $OUT/fused_stamps_ilv.txt ;;
     fwdstamps) timeout -k 10 600 python3 tools/fwd_stamps.py 8 0.7 0.1 > $OUT/fwd_stamps.txt 2>&1 || { tail -30 $OUT/fwd_stamps.txt; exit 1; }
              timeout -k 10 600 python3 tools/fwd_stamps.py 8 0.7 0.0 >> $OUT/fwd_stamps.txt 2>&1 || { tail -30 $OUT/fwd_stamps.txt; exit 1; }; cat $OUT/fwd_stamps.txt ;;
@@ -50,6 +51,16 @@ PYEOF
                T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fwd_${FWD_VARIANT}.so timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 0.1 2>&1 | grep "fwd " | sed -E 's/ \| bwd.*$//' >> $OUT/fwd_ab.txt
              done
              cat $OUT/fwd_ab.txt | cut -c1-150 ;;
+    fbab)    # same box, interleaved: the product fused backward vs a variant source (FB_VARIANT=name, tools/ablate/variants/attn_bwd_fused_bf16_<name>.hip)
+             bash tools/ablate/fb_variant.sh ${FB_VARIANT} tools/ablate/variants/attn_bwd_fused_bf16_${FB_VARIANT}.hip > $OUT/fb_variant_build.log 2>&1 || { tail -20 $OUT/fb_variant_build.log; exit 1; }
+             rm -f $OUT/fb_ab.txt
+             for dp in 0.1 0.0; do for rep in 1 2 3; do
+               echo "== product, dropout $dp" >> $OUT/fb_ab.txt
+               T2S_PROBE_FORMS=shipped timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 $dp 2>&1 | grep "bwd fused/handoff  " >> $OUT/fb_ab.txt
+               echo "== variant ${FB_VARIANT}, dropout $dp" >> $OUT/fb_ab.txt
+               T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_${FB_VARIANT}.so timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 $dp 2>&1 | grep "bwd fused/handoff  " >> $OUT/fb_ab.txt
+             done; done
+             cat $OUT/fb_ab.txt | cut -c1-150 ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
 done
