@@ -104,15 +104,20 @@ int t2s_attn_bwd_fill(const void* q, const void* k, const void* v, const void* o
  * (S and dP are computed once; the two-kernel form above recomputes them: seven): bf16; attention dropout as above (same mask).
  * dQ is a sum over the 384-key blocks of a (sample, head); dq_mode picks how it is formed:
  *   1  ordered hand-off (default of the Python layer): the key blocks of a pair add their tiles in block order, each reading
- *      the running fp32 sum of its predecessors and storing the new one with plain write-through stores, the last one writing
- *      bf16 dq itself - no zero fill, no cast pass, dq BIT-REPRODUCIBLE;
+ *      the running fp32 sum of its predecessors and storing the new one with plain stores, the last one writing bf16 dq
+ *      itself - no zero fill, no cast pass, dq BIT-REPRODUCIBLE.  The key blocks of a pair run on ONE XCD (workgroups of equal
+ *      blockIdx % 8), and the sums stay in that XCD's L2 (write-back stores, sc1 loads).  The kernel checks the premise - it ORs
+ *      every workgroup's XCC_ID into a word per group - and sets status bit 1 when a group ran on two XCDs;
+ *      | 0x200: write-through (sc1) stores instead, correct under any workgroup placement (no check; 2.8 % slower, 2.8 x the
+ *      HBM traffic): the form for a device that does not place workgroups round-robin over its XCDs;
  *   0  fp32 atomics into a [B, Lq, H*64] buffer + a cast pass (rounds 2-3): dq depends on arrival order in its last bits.
  * dk / dv are deterministic either way.  workspace: t2s_attn_bwd_fused_workspace_bytes(B, H, Lq) bytes of device memory, contents
  * on entry irrelevant (the call clears what it needs); word 24 of it (uint32) is a status word: bit 0 set = a bounded spin of
  * the hand-off timed out (cannot happen unless a workgroup died).  The launch still ends, and the dq rows of that (sample, head)
- * pair are NaN from the timed-out block on - never a silently wrong number; t2s_status_accumulate / t2s_status_gate below carry
- * the word to the optimizer step.  dq_mode 0x101 (tests only): the hand-off with a dead predecessor - no block publishes, every
- * successor's wait times out at once.
+ * pair are NaN from the timed-out block on - never a silently wrong number; bit 1 set = the XCD-local sums' placement premise
+ * was violated (dq may hold stale sums: discard the step); t2s_status_accumulate / t2s_status_gate below carry the word to
+ * the optimizer step.  Tests only: dq_mode 0x101 = the hand-off with a dead predecessor - no block publishes, every successor's
+ * wait times out at once; 0x401 = the placement check is fed two XCD numbers per group.
  * row_valid as for t2s_attn_bwd_fill, or NULL (then the caller zero-fills dk / dv).  A sample whose list is empty (kv_cnt = 0 and
  * n_dec = 0) gets exactly zero dq rows in either form. */
 int64_t t2s_attn_bwd_fused_workspace_bytes(int B, int H, int Lq);

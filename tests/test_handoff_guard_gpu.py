@@ -5,6 +5,11 @@ how the hardware range-checks a scalar buffer offset.
   out at once.  Asserted: the launch ends; the status word is set; the dQ rows of every pair with more than one key block are NaN
   (never a silently wrong number) while dK / dV stay finite; FusedClipAdam's step on such gradients is a no-op on the device and the
   NEXT step raises ops.HandoffTimeout; optim.raise_if_handoff_failed() raises at a synchronisation point and clears the word.
+* The running dQ sums stay in the L2 of ONE XCD (plain stores, sc1 loads); the kernel checks the premise - every workgroup of an XCD
+  group (equal blockIdx % 8) on the same XCD - and reports a violation as status bit 1.  Asserted: on this card the check is silent;
+  dq_mode 0x401 (the check is fed alternating XCD numbers) sets bit 1, the optimizer step behind it is a no-op and
+  optim.raise_if_handoff_failed() raises ops.HandoffPlacement; dq_mode 0x201 (write-through sums, the form for a device that places
+  workgroups differently) gives bit-identical gradients and never runs the check.
 * Lq % 64 != 0 with q / out / dout as views of larger buffers whose bytes right behind the last sample's rows are NaN: the staged rows
   behind Lq must read as zeros (the tile's row offset rides in the range-checked vector offset): finite gradients, equal to the
   two-kernel form's."""
@@ -75,6 +80,36 @@ def test_the_optimizer_step_behind_a_timed_out_handoff_is_a_noop_and_the_next_on
     opt.step_clipped(0.25)                                   # training could go on (from a checkpoint) once the cause is gone
     torch.cuda.synchronize()
     assert not torch.equal(w.detach(), w1) and torch.isfinite(w).all()
+
+
+def test_xcd_local_sums_are_checked_and_the_write_through_form_is_bit_identical():
+    from vitxt_gqa_amd import ops, optim
+    ops.reset_fused_status()
+    x, dout, keys, out, lse = _case(B=3, L1=2100, seed=9)
+    local = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, drop_p=0.1, drop_seed=77)
+    torch.cuda.synchronize()
+    assert ops.fused_handoff_status() == 0, "XCD groups on one XCD each: the placement check must be silent on this card"
+    through = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=0x201, drop_p=0.1, drop_seed=77)
+    assert ops.fused_handoff_status() == 0 and torch.equal(through, local), "same chain, same order: the scope of the stores changes no bit"
+    # the write-through form does not look at the placement at all
+    ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=0x601, drop_p=0.1, drop_seed=77)
+    assert ops.fused_handoff_status() == 0
+    # the check, fed two XCD numbers per group
+    flagged = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=0x401, drop_p=0.1, drop_seed=77)
+    torch.cuda.synchronize()
+    assert ops.fused_handoff_status() == 2, "a group seen on two XCDs sets bit 1 (and only that)"
+    assert torch.equal(flagged, local)                       # (nothing was really misplaced here)
+    w = torch.nn.Parameter(torch.randn(64, 768, device=DEV))
+    opt = optim.FusedClipAdam([w], lr=1e-2)
+    w0 = w.detach().clone()
+    w.grad = torch.randn_like(w)
+    norm = opt.step_clipped(0.25)
+    torch.cuda.synchronize()
+    assert torch.isnan(norm) and torch.equal(w.detach(), w0), "the step behind a flagged backward is gated off on the device"
+    with pytest.raises(ops.HandoffPlacement):
+        optim.raise_if_handoff_failed()
+    assert ops.fused_handoff_status() == 0
+    assert issubclass(ops.HandoffPlacement, ops.HandoffError) and issubclass(ops.HandoffTimeout, ops.HandoffError)
 
 
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])

@@ -40,8 +40,9 @@ def main():
     # backward: the two-kernel (7-product) and the fused (5-product, no dropout) forms, interleaved rounds in ONE process
     # (fused: dQ across key blocks by the ordered hand-off, dq_mode 1, and by fp32 atomics + cast, dq_mode 0)
     # "split": full and edge key blocks as two launches (rounds 2-3, T2S_FB_SPLIT_EDGE=1, read per call); default: one launch
-    forms = [("two-kernel", dict(fused=False), "0"), ("fused/handoff", dict(fused=True, dq_mode=1), "0"), ("fused/atomic", dict(fused=True, dq_mode=0), "0"),
-             ("fused/handoff split", dict(fused=True, dq_mode=1), "1"), ("fused/atomic split", dict(fused=True, dq_mode=0), "1")]
+    HO = 0x201 if os.environ.get("T2S_FB_HANDOFF_SCOPE", "xcd") == "agent" else 1      # (write-through running sums: the round-4 form)
+    forms = [("two-kernel", dict(fused=False), "0"), ("fused/handoff", dict(fused=True, dq_mode=HO), "0"), ("fused/atomic", dict(fused=True, dq_mode=0), "0"),
+             ("fused/handoff split", dict(fused=True, dq_mode=HO), "1"), ("fused/atomic split", dict(fused=True, dq_mode=0), "1")]
     if os.environ.get("T2S_PROBE_FORMS") == "shipped":          # PMC passes: only the forms the product runs
         forms = forms[:2]
     tb_all = {n: [] for n, _, _ in forms}

@@ -61,6 +61,47 @@ PYEOF
                T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_${FB_VARIANT}.so timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 $dp 2>&1 | grep "bwd fused/handoff  " >> $OUT/fb_ab.txt
              done; done
              cat $OUT/fb_ab.txt | cut -c1-150 ;;
+    scope)   # hand-off cache-scope variants (SCOPE_VARIANTS="name:ld:st ..."): correctness subset, interleaved timing, HBM counters
+             rm -f $OUT/scope.txt
+             for v in ${SCOPE_VARIANTS:-st0:16:0}; do
+               IFS=: read name ld st <<< "$v"
+               [ -f tools/ablate/variants/attn_bwd_fused_bf16_scope_$name.hip ] || python3 tools/ablate/make_fb_scope.py $name $ld $st > /dev/null
+               [ -f tools/ablate/_build/libt2s_fbv_scope_$name.so ] || bash tools/ablate/fb_variant.sh scope_$name tools/ablate/variants/attn_bwd_fused_bf16_scope_$name.hip > $OUT/scope_build_$name.log 2>&1 || { tail -20 $OUT/scope_build_$name.log; exit 1; }
+               echo "== variant $name (load aux $ld, store aux $st): correctness" >> $OUT/scope.txt
+               T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_scope_$name.so timeout -k 10 600 python3 -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_dropout_gpu.py -q -k "fused" 2>&1 | tail -4 >> $OUT/scope.txt
+             done
+             for rep in 1 2 3; do
+               echo "== product" >> $OUT/scope.txt
+               T2S_PROBE_FORMS=shipped timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 0.1 2>&1 | grep "bwd fused/handoff  " >> $OUT/scope.txt || true
+               for v in ${SCOPE_VARIANTS:-st0:16:0}; do
+                 IFS=: read name ld st <<< "$v"
+                 echo "== variant $name" >> $OUT/scope.txt
+                 T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_scope_$name.so timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 0.1 2>&1 | grep "bwd fused/handoff  " >> $OUT/scope.txt || true
+               done
+             done
+             cd /tmp && export TMPDIR=/tmp
+             for v in product ${SCOPE_VARIANTS:-st0:16:0}; do
+               IFS=: read name ld st <<< "$v"
+               lib=$REPO/vitxt_gqa_amd/libt2s_hip.so; [ $name != product ] && lib=$REPO/tools/ablate/_build/libt2s_fbv_scope_$name.so
+               for c in FETCH_SIZE WRITE_SIZE; do
+                 T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$lib timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/scope_pmc_${name}_$c -- python3 $REPO/tools/attn_probe.py 8 10120 0.7 12 2 0.1 > $OUT/scope_pmc_${name}_$c.log 2>&1 || true
+               done
+               python3 $REPO/tools/ablate/scope_pmc_sum.py $OUT scope_pmc_$name >> $OUT/scope.txt
+             done
+             cd $REPO
+             cat $OUT/scope.txt | cut -c1-170 ;;
+    scopeab) # the shipped XCD-local running sums vs the write-through form (T2S_FB_HANDOFF_SCOPE=agent), same library, interleaved; then HBM counters
+             rm -f $OUT/scopeab.txt
+             for rep in 1 2 3; do for sc in xcd agent; do
+               echo "== sums: $sc" >> $OUT/scopeab.txt
+               T2S_FB_HANDOFF_SCOPE=$sc T2S_PROBE_FORMS=shipped timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 0.1 2>&1 | grep "bwd fused/handoff  " >> $OUT/scopeab.txt || true
+             done; done
+             cd /tmp && export TMPDIR=/tmp
+             for sc in xcd agent; do for c in FETCH_SIZE WRITE_SIZE; do
+               T2S_FB_HANDOFF_SCOPE=$sc T2S_PROBE_FORMS=shipped timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/scopeab_pmc_${sc}_$c -- python3 $REPO/tools/attn_probe.py 8 10120 0.7 12 2 0.1 > $OUT/scopeab_pmc_${sc}_$c.log 2>&1 || true
+             done; python3 $REPO/tools/ablate/scope_pmc_sum.py $OUT scopeab_pmc_$sc >> $OUT/scopeab.txt; done
+             cd $REPO
+             cat $OUT/scopeab.txt | cut -c1-170 ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
 done

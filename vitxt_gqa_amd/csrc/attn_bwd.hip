@@ -610,7 +610,8 @@ extern "C" int t2s_attn_bwd_fused(const void* q, const void* k, const void* v, c
                                   int64_t o_row_stride, int64_t o_batch_stride, float scale, int dtype, float drop_p, uint64_t drop_seed,
                                   t2s_stream_t stream) {
   T2S_CHECK_ARG(workspace, "attn_bwd_fused: the workspace is required");
-  T2S_CHECK_ARG(dq_mode == 0 || dq_mode == 1 || dq_mode == 0x101, "attn_bwd_fused: dq_mode %d (0 = fp32 atomics, 1 = ordered hand-off, 0x101 = hand-off with a dead predecessor: tests)", dq_mode);
+  T2S_CHECK_ARG(dq_mode == 0 || ((dq_mode & 0xff) == 1 && (dq_mode & ~0x7ff) == 0),
+                "attn_bwd_fused: dq_mode %d (0 = fp32 atomics, 1 = ordered hand-off; hand-off bits: 0x200 = write-through running sums, 0x100 / 0x400 = diagnostic modes of the tests)", dq_mode);
   T2S_CHECK_ARG(dtype == T2S_BF16, "attn_bwd_fused: bf16 only");
   T2S_CHECK_ARG(!row_valid || (kv_idx && Lq >= idx_cap && (n_dec == 0 || (dec_q0 >= idx_cap - n_dec && dec_q0 + n_dec <= Lq))),
                 "attn_bwd_fused: row_valid needs the key list and the self-attention layout");

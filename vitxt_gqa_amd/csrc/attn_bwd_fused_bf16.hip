@@ -45,10 +45,17 @@ constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
 // ORDERED HAND-OFF (round 4; cdna_hip_programming.md Appendix B "Attention backward", Guideline 16 recipe R1): the key blocks of a
 //   pair form a chain in block order.  Block k reads the running sum of blocks 0..k-1 of a query tile, adds its own tile in
 //   registers and stores the new running sum; the LAST block of the pair rounds to bf16 and writes dQ itself.  Plain 16-byte
-//   write-through (sc1) stores and sc1 loads instead of atomics, a fixed summation order - dQ is bit-reproducible - no zero fill
-//   and no cast pass.  The running sums live in the ACCUMULATOR-NATIVE layout (per tile: wave quadrant, register group, lane: every
+//   stores and sc1 loads instead of atomics, a fixed summation order - dQ is bit-reproducible - no zero fill and no cast pass.
+//   SCOPE OF THE SUMS (round 5): the key blocks of a pair are drawn by workgroups of ONE XCD group (blockIdx % 8, below), i.e. of one
+//   XCD and one L2.  The sums therefore never have to leave that L2: the stores are ordinary write-back stores (L1 is write-through,
+//   so a store that s_waitcnt vmcnt has retired is in the L2), the loads are sc1 loads (they miss L1 and are served by the L2).
+//   With write-through (sc1) stores - the round-4 form - every block's 16 KB per tile went to HBM and came back from it:
+//   10.1 GB of HBM traffic per launch at B = 8 against 3.6 GB now, and the launch is 2.8 % faster (profiles/r05_handoff_scope.txt).
+//   The premise is CHECKED, not assumed: every workgroup ORs its XCC_ID into a word of its XCD group; a group that sees two
+//   different XCDs sets bit 1 of the status word - the step is discarded and the next optimizer call raises, like a timeout
+//   (FbWork::agent_scope = 1 / dq_mode bit 9 / T2S_FB_HANDOFF_SCOPE=agent selects the write-through form for such a device).  The running sums live in the ACCUMULATOR-NATIVE layout (per tile: wave quadrant, register group, lane: every
 //   access a lane-linear 1 KB piece).  Protocol per query tile t (flags[pair][t] = number of blocks whose sum is published):
-//     producer  the four waves store their quadrants (sc1); one tile later, behind every wave's s_waitcnt vmcnt(0) and the
+//     producer  the four waves store their quadrants; one tile later, behind every wave's s_waitcnt vmcnt(0) and the
 //               workgroup barrier that phase B needs anyway, ONE lane stores flags[t] = k + 1 (sc1 store)
 //     consumer  every wave loads flags[t] (sc1) at the top of tile t, checks it at the end of phase A (spins, bounded, only if
 //               the predecessor has not got there yet), then - behind the barrier - loads the sum with sc1 loads
@@ -62,7 +69,7 @@ struct FbWork {
   float* part;            // hand-off: running sums [B H][nqt][4 quadrants][4 register groups][64 lanes] x 16 B; atomic form: dq32 [B Lq, H 64]
   unsigned* flags;        // [B H][nqt]
   unsigned* tickets;      // [3 launches][8 XCD groups]
-  unsigned* status;       // [4]: bit 0 of word 0 = a bounded spin timed out
+  unsigned* status;       // [4]: word 0 bit 0 = a bounded spin timed out, bit 1 = an XCD group ran on more than one XCD (XCD-local sums only)
   const float* nl;        // [B H][nqt * 64]: -lse * log2(e) per query row, -inf behind Lq (written by attn_delta_prep_kernel)
   const float* nd;        // [B H][nqt * 64]: -delta per query row, 0 behind Lq
   const unsigned* slots;  // [8 XCD groups][groups + 1]: first ticket of each (sample, head) pair of the group, then the group's total (prep kernel)
@@ -70,6 +77,8 @@ struct FbWork {
   int handoff;
   unsigned spin_limit;    // polls a hand-off wait may take before it gives up (FB_SPIN_LIMIT; 0 in the diagnostic mode of the tests)
   int never_publish;      // diagnostic mode (dq_mode bit 8): no block publishes its flags - every successor's wait times out
+  int agent_scope;        // dq_mode bit 9: write-through (sc1) stores of the running sums - for a device whose XCD groups do not sit on one XCD each
+  int diag_misplaced;     // diagnostic mode (dq_mode bit 10): the placement check sees alternating XCDs inside every group
 };
 // Staging of the Q / dO tiles and their row constants by LDS-DMA (buffer_load ... lds: 1 KB per wave-instruction = 8 rows x 128 B
 // straight into the swizzled tile image - the chunk swizzle is a permutation INSIDE a row, so it goes on the per-lane source address;
@@ -106,7 +115,8 @@ __device__ __forceinline__ void fb_dma16_sc1(u32x4 rs, uint32_t lds, int voff, i
 __device__ __forceinline__ void fb_dma4(u32x4 rs, uint32_t lds, int voff, int soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
 }
-constexpr int FB_CTRL_WORDS = 64;                       // tickets (24) + status (4), padded: the block the launch zeroes, with the flags behind it
+constexpr int FB_CTRL_WORDS = 64;                       // tickets (24) + status (4) + XCDs seen per group (8, at word 32), padded: the block the launch zeroes, with the flags behind it
+constexpr int FB_XCC_SEEN = 32;
 constexpr unsigned FB_SPIN_LIMIT = 1u << 18;            // ~1-2 us per poll: a few tenths of a second (a legitimate wait is < 1 ms)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t fb_rsrc(const void* base, unsigned bytes) {
@@ -280,6 +290,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       unsigned* tk = w.tickets + (MODE % 3) * T2S_XCDS + xg;
       // (a stale read only errs on the low side: then the atomic decides)
       sl[0] = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tab[w.groups] ? 0xFFFFFFFFu : atomicAdd(tk, 1u);
+      if (!w.agent_scope) {
+        // XCD-local sums: every workgroup of this group must sit on the same XCD.  The first one to find another XCD's bit reports it.
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 15u;
+        if (w.diag_misplaced) xcc = (blockIdx.x / T2S_XCDS) & 1u;
+        const unsigned seen = atomicOr(w.tickets + FB_XCC_SEEN + xg, 1u << xcc);
+        if (seen & ~(1u << xcc)) atomicOr(w.status, 2u);
+      }
     }
     __syncthreads();
     const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)sl[0]);
@@ -835,7 +854,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const f32x4 t4 = {tot[4 * g], tot[4 * g + 1], tot[4 * g + 2], tot[4 * g + 3]};
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 16 /* sc1: write-through */);
+              if (w.agent_scope) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 16 /* sc1: write-through */);
+              else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 0 /* stays in this XCD's L2 */);
             }
           }
         } else {
@@ -1012,6 +1032,8 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   AttnParams p = p_in;
   const int handoff = dq_mode & 0xff;
   const bool diag_dead = handoff && (dq_mode & 0x100);      // tests: the hand-off with a dead predecessor (spin limit 0, flags never published)
+  const bool agent_scope = handoff && (dq_mode & 0x200);    // write-through running sums (a device whose XCD groups are not XCD-local)
+  const bool diag_misplaced = handoff && (dq_mode & 0x400); // tests: the placement check sees two XCDs in every group
   if (workspace_bytes < attn_bwd_fused_workspace_bytes(p.B, p.H, p.Lq)) {
     t2s_set_error("attn_bwd_fused: workspace of %zu bytes, %zu needed (t2s_attn_bwd_fused_workspace_bytes)", workspace_bytes,
                   attn_bwd_fused_workspace_bytes(p.B, p.H, p.Lq));
@@ -1036,6 +1058,8 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   w.handoff = handoff;
   w.spin_limit = diag_dead ? 0u : FB_SPIN_LIMIT;
   w.never_publish = diag_dead ? 1 : 0;
+  w.agent_scope = agent_scope ? 1 : 0;
+  w.diag_misplaced = diag_misplaced ? 1 : 0;
   float* const dq32 = w.part;
   // > 64 KB of LDS per workgroup needs the opt-in: once per device (a flag per device ordinal is the only state kept)
   static bool lds_reserved[64] = {};

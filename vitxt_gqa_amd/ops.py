@@ -127,15 +127,31 @@ ATTN_BWD_FUSED = os.environ.get("T2S_ATTN_BWD_FUSED", "1") != "0"
 ATTN_BWD_FUSED_MIN_KEYS = 2048
 ATTN_BWD_FUSED_MIN_ROWS = 1024
 ATTN_BWD_DQ_MODE = 0 if os.environ.get("T2S_ATTN_BWD_DQ", "handoff") == "atomic" else 1
+# The hand-off's running sums stay in the L2 of the XCD that runs a (sample, head)'s key blocks (plain stores); the kernel checks that
+# every XCD group of workgroups really sits on one XCD and reports a violation through the status word (HandoffPlacement below).
+# T2S_FB_HANDOFF_SCOPE=agent (dq_mode bit 9) selects write-through stores instead - correct under any placement, 2.8 % slower.
+if ATTN_BWD_DQ_MODE == 1 and os.environ.get("T2S_FB_HANDOFF_SCOPE", "xcd") == "agent":
+    ATTN_BWD_DQ_MODE |= 0x200
 _KEEP_DQ32 = os.environ.get("T2S_KEEP_DQ32", "0") == "1"     # tools/fused_stamps.py: keep the workspace, whose tail holds the diagnostic
 _LAST_DQ32 = None                                             # build's cycle stamps (otherwise it is freed with the call: 2 GB at B=64)
-FUSED_CTRL_STATUS_WORD = 24                                   # include/t2s_hip.h: uint32 word of the workspace, bit 0 = a hand-off spin timed out
+FUSED_CTRL_STATUS_WORD = 24                                   # include/t2s_hip.h: uint32 word of the workspace, bit 0 = a hand-off spin timed out, bit 1 = an XCD group ran on two XCDs
 _STICKY = {}                                                  # device index -> int32 [4]: (OR of every fused launch's status word, launches seen, -, -)
 
 
-class HandoffTimeout(RuntimeError):
+class HandoffError(RuntimeError):
+    """The fused attention backward's dQ hand-off reported a failure in its status word: the gradients of that step are not usable and
+    the optimizer step that followed was gated off on the device."""
+
+
+class HandoffTimeout(HandoffError):
     """A bounded wait of the fused attention backward's dQ hand-off timed out (a workgroup died or the card is oversubscribed): the dQ
     rows behind it are NaN and the optimizer step that follows is gated off on the device - the gradients of this step are not usable."""
+
+
+class HandoffPlacement(HandoffError):
+    """Workgroups of one XCD group (equal blockIdx % 8) ran on different XCDs, so the running dQ sums - kept in ONE XCD's L2 - may have
+    been read stale (status bit 1).  Does not happen on an MI355X in its default (SPX) mode; on a device that places workgroups
+    differently set T2S_FB_HANDOFF_SCOPE=agent (write-through sums)."""
 
 
 def fused_status_tensor(device):
@@ -150,7 +166,8 @@ def fused_status_tensor(device):
 
 def fused_handoff_status(device=None):
     """OR of the status words of every fused-backward call since the last ``reset_fused_status`` (synchronises): 0 = clean, bit 0 = a
-    bounded spin of the dQ hand-off timed out (the dQ rows behind it are NaN).  A timeout cannot happen unless a workgroup died."""
+    bounded spin of the dQ hand-off timed out (the dQ rows behind it are NaN; cannot happen unless a workgroup died), bit 1 = an XCD
+    group of workgroups ran on more than one XCD (the XCD-local running sums may have been read stale)."""
     if not _STICKY:
         return 0
     if device is None:

@@ -197,13 +197,18 @@ def build_optimizer(model, config):
 
 def raise_if_handoff_failed(device=None):
     """Synchronising check of the sticky status of the fused attention backward (ops.fused_handoff_status): raises
-    ``ops.HandoffTimeout`` when a bounded wait of the dQ hand-off has timed out since the last reset, and clears the word.  Call it
+    ``ops.HandoffTimeout`` when a bounded wait of the dQ hand-off has timed out since the last reset (``ops.HandoffPlacement`` when an
+    XCD group of workgroups ran on two XCDs; both are ``ops.HandoffError``), and clears the word.  Call it
     where the trainer synchronises anyway (loss logging, checkpoints); ``FusedClipAdam`` also checks the previous step's word at
     every step without synchronising, and the step in which the timeout happened was gated off on the device."""
     from . import ops
     st = ops.fused_handoff_status(device)
     if st != 0:
         ops.reset_fused_status()
+        if st & 2:
+            raise ops.HandoffPlacement("fused attention backward: workgroups of one XCD group ran on different XCDs (status word %d) - the running "
+                                       "dQ sums, kept in one XCD's L2, may have been read stale; the optimizer step of that iteration was skipped "
+                                       "on the device.  Set T2S_FB_HANDOFF_SCOPE=agent (write-through sums) on this device" % st)
         raise ops.HandoffTimeout("fused attention backward: a hand-off wait timed out (status word %d) - the dQ rows behind it are NaN and the "
                                  "optimizer step of that iteration was skipped on the device; a workgroup died or the card is oversubscribed" % st)
 
