@@ -529,7 +529,8 @@ def main():
                              ">= 2 048 keys (the ref pass and QTV: the 45 ms launches); "
                              "mfma_busy: SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle of the fused kernel alone (profiles/mfma_busy.json); "
                              "traffic_over_algorithmic: PMC bytes per launch / (Q, K, V, O, dO read + dQ, dK, dV written once) - the "
-                             "running fp32 dQ sums every key block reads and writes are the excess (DESIGN section 5)"}
+                             "excess is the hand-off's running fp32 dQ sums: they stay in the XCD's L2 between key blocks (write-back "
+                             "stores) but are still written back several times per launch (DESIGN section 5, profiles/r05_handoff_scope.txt)"}
     # `roofline` = the dominant kernel group of the step (the attention backward in a train step, the forward otherwise)
     if bwd_block is not None:
         res["roofline"], res["roofline_fwd"] = bwd_block, fwd_block

@@ -1,3 +1,5 @@
+// VARIANT kept for A/B runs, NOT shipped: the SERIAL 384-key fused backward (phase B = the dQ product of a tile, after the barrier that ends its phase A)
+// as the product had it until the interleaved form took over in round 5 (with the XCD-local running sums; profiles/r05_fused_ilv384_l2.txt).
 // Fused bf16 flash-attention backward for gfx950, head_dim 64: FIVE matrix products per (query, key) pair.
 //
 // The two-kernel form (attn_dkdv_bf16.hip + attn_dq_bf16_kernel) needs no cross-workgroup sum but computes S = Q K^T and
@@ -20,8 +22,6 @@
 // 32 x 32 tile (query sub-block w >> 1, dim block w & 1) of dQ = dS K over ALL 384 keys (both operands by
 // ds_read_b64_tr_b16 from the two images) and adds it to the running sum of the pair's earlier key blocks (hand-off) or to the fp32
 // dQ buffer (atomics: each accumulator register is two 128-byte row segments, the shape the atomics run at full rate for).
-// In the straight-line sweep (all 384 keys valid prefix keys: almost every workgroup of a long list) phase B of tile t - 1 runs
-// INSIDE slots 0 and 1 of phase A of tile t ("ILV" below, shipped since round 5); the edge sweep and the tail launch keep it serial.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -376,12 +376,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     // running sums of this pair through a buffer descriptor: block 0 gets ZERO records - its loads return 0.0 without touching
     // memory, so the sweep needs no branch around them
     const __amdgpu_buffer_rsrc_t rs_ld = fb_rsrc(part_pair, (HO && kbw > 0) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
-    // two store descriptors, ONE of them with zero records: the XCD-local form stores through rs_st (plain stores, the line stays in this
-    // XCD's L2), the write-through form through rs_st_wt (sc1).  Both stores are issued, the one through the empty descriptor is dropped by
-    // the range check - a BRANCH between them would sit inside a slot of the interleaved sweep and let the compiler sink that slot's VALU
-    // work out of the MFMA shadow (measured: the interleave's 3.5 % were gone with the branch in place)
-    const __amdgpu_buffer_rsrc_t rs_st = fb_rsrc(part_pair, (HO && !w.agent_scope) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
-    const __amdgpu_buffer_rsrc_t rs_st_wt = fb_rsrc(part_pair, (HO && w.agent_scope) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
+    const __amdgpu_buffer_rsrc_t rs_st = fb_rsrc(part_pair, HO ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
     // ---- K image of the workgroup's keys, pre-scaled by scale*log2e (one bf16 rounding per element, as the dK/dV kernel's
     // register fragments); rows past the list repeat its last key (their P is forced to 0 below)
 #pragma unroll
@@ -501,29 +496,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     auto sweep = [&](auto pipe_tag, auto edge_tag) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(pipe_tag)::value;         // the software-pipelined phase A (all three key blocks of every wave run)
     constexpr bool EDGE = decltype(edge_tag)::value;         // ... with the validity / decoder rule applied to P
-    constexpr bool PREF = FULL && !EDGE;                     // the first operands of tile t+1 are fetched from LDS behind the barrier that ends tile t
-    // ILV (round 5): the dQ product ("phase B") of tile t - 1 runs INSIDE slots 0 and 1 of phase A of tile t, twelve of its 24 MFMAs
-    // in each, every one followed by the transposed reads of the step four ahead.  The dS^T image stays single: the barrier at the end of
-    // phase A of tile t - 1 completes it, the bare s_barrier behind slot 1 of tile t ("every wave is done reading the dS^T image") - which
-    // the serial form has too - retires its readers ahead of the first dS^T store of tile t in slot 2.  What goes away is the serial
-    // phase B (2 024 cycles of LDS-bound MFMAs with the vector ALU idle) and nothing is added to the 6-block pipeline's ramp: the
-    // 256-key variant (tools/ablate/attn_bwd_fused_bf16_ilv256.hip) lost exactly there.  The edge sweep and the tail launch keep the serial form.
-    // Measured, same box, interleaved runs.  With WRITE-THROUGH running sums the interleave bought nothing: 11 % fewer cycles per tile,
-    // the clock down from 2.28 to 2.03 GHz (profiles/r05_fused_ilv384_vs_serial_ab.txt, r05_fused_ilv384_stamps.txt) - the chip gave the
-    // cycles back.  With the sums in the XCD's L2 (1.9 TB/s of fabric traffic gone) it is 2.6 - 3.5 % faster than the serial form at
-    // B = 32 (21.4 vs 22.0 ms; 18.8 vs 19.2 without dropout) and the B = 64 step 3.7 ms shorter (profiles/r05_fused_ilv384_l2.txt); the
-    // serial form is kept as tools/ablate/variants/attn_bwd_fused_bf16_serial384.hip.  Two rules the form depends on, both met the hard way:
-    // NO BRANCH inside slots 0 / 1 (the compiler sinks the slot's exponentials out of the MFMA shadow behind it: the hand-off of "tile -1"
-    // and the choice of store scope are both done with out-of-range buffer offsets / zero-record descriptors instead), and twelve wait
-    // states behind the last dQ MFMA on EVERY path (its destination registers are free for the compiler the moment the asm statement has
-    // issued; on tile 0, where the result is dropped, the next VALU results landed in them and were overwritten by the MFMA's late write).
-    constexpr bool ILV = PREF;
+    constexpr bool PREF = FULL && !EDGE;                     // the first operands of tile t+1 are fetched from LDS during phase B of tile t
     constexpr bool CAN_LAST = EDGE || !FULL;                 // hand-off: only an edge block (or the tail launch) can end a pair's chain
     bf16x8 qf[4], dof[4], kf[4];
     f32x16 sacc[2], dpacc[2];
-    bf16x8 afA[3], bfA[3];                         // operands of the dQ product in flight (three 16-key steps ahead: registers are tight)
-    u32x4 pin[4];                                  // hand-off: the predecessor's running sum of the tile whose dQ is being formed
-    f32x16 dqacc;
     const char* kw_ = kimg + wave * (FB_WKEYS * 128);
 #define FB_LD_QF(qbase_, dobase_, sb_)                                                              \
   _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                   \
@@ -546,61 +522,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       FB_LD_SEEDS(reinterpret_cast<const float*>(stage + 2 * FB_TILE), reinterpret_cast<const float*>(stage + 2 * FB_TILE) + FB_QROWS, 0);
       FB_LD_KF(0);
     }
-    if constexpr (ILV) {   // (slots 0 / 1 of tile 0 multiply operands of a tile that does not exist: defined values, result dropped)
-#pragma unroll
-      for (int u = 0; u < 3; ++u) { afA[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; bfA[u] = afA[u]; }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) pin[g] = u32x4{0u, 0u, 0u, 0u};
-    }
-    // dQ of query tile tq leaves this block: dqacc (= c dS K over the block's keys; dQ = acc * ln 2) joins the running sum of the pair's
-    // earlier blocks (hand-off: stored write-through for the successor, or - last block of the pair - rounded to bf16 and written as
-    // dQ), or goes to the fp32 buffer by atomics.  Register r = query row acc_row(r, lh), 32 consecutive dims per half wave: two
-    // 128-byte segments per wave instruction.
-#define FB_DQ_FINALIZE(tq_)                                                                         \
-  {                                                                                                 \
-    asm volatile("s_nop 11" : "+v"(dqacc));              /* MFMA result -> VALU read */              \
-    const int q0 = (tq_) * FB_QROWS + dq_qb * 32;                                                   \
-    if constexpr (HO) {                                                                             \
-      const unsigned ho_off = (unsigned)(((tq_) * 4 + wave_u) * 4096 + lane * 16);                  \
-      f32x16 tot;                                                                                   \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
-        /* (bit_cast of the WHOLE vector, then the element: bit_cast(float, pin[g][j]) is narrowed by this clang to a one-dword load */ \
-        /* whose value stands in for all four elements - seen in the ISA) */                        \
-        const f32x4 pf = __builtin_bit_cast(f32x4, pin[r >> 2]);                                    \
-        tot[r] = __builtin_fmaf(dqacc[r], ho_ln2, pf[r & 3]);                                       \
-      }                                                                                             \
-      if (CAN_LAST && ho_last) {                                                                    \
-        /* the last block of the pair: dQ rows in bf16.  Lanes 2i / 2i+1 hold columns 2i / 2i+1 of the same rows: the even lane */   \
-        /* takes the odd lane's value of register 2m, the odd lane the even lane's value of register 2m+1 (DPP quad_perm 1,0,3,2), */ \
-        /* each then stores ONE 4-byte pair of its own row */                                       \
-        bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.q_bs + h * 64 + dq_db * 32 + (lr & ~1);                       \
-        const bool odd = lr & 1;                                                                    \
-        _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                             \
-          const float a = tot[2 * m], bb = tot[2 * m + 1];                                          \
-          const float send = odd ? a : bb;                                                          \
-          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true)); \
-          const int row = q0 + acc_row(2 * m, lh) + (odd ? 1 : 0);                                  \
-          if (row < p.Lq) *reinterpret_cast<uint32_t*>(dqp + (int64_t)row * p.q_rs) = odd ? fb_pack2(recv, bb) : fb_pack2(a, recv);   \
-        }                                                                                           \
-      } else {                                                                                      \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
-          const f32x4 t4 = {tot[4 * g], tot[4 * g + 1], tot[4 * g + 2], tot[4 * g + 3]};            \
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 0 /* stays in this XCD's L2 */); \
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st_wt, ho_off + g * 1024, 0, 16 /* sc1: write-through (zero records unless FbWork::agent_scope) */); \
-        }                                                                                           \
-      }                                                                                             \
-    } else {                                                                                        \
-      const int rstep = p.H * 64;                                                                   \
-      float* rowp = DQ + (int64_t)q0 * rstep + dq_db * 32;          /* wave-uniform (dq_qb / dq_db come from readfirstlane) */       \
-      const int loff = lr + 4 * lh * rstep;                          /* this lane's element offset */                                \
-      if (q0 + 32 <= p.Lq) {                               /* whole sub-block inside the sequence */                                 \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) unsafeAtomicAdd(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f); \
-      } else {                                                                                      \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                              \
-          if (q0 + acc_row(r, lh) < p.Lq) unsafeAtomicAdd(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f); \
-      }                                                                                             \
-    }                                                                                               \
-  }
     for (int qt = 0; qt < nqt; ++qt) {
       const int buf = qt & 1;
       if (DROP && (qt & (ATTN_DROP_QWIN / FB_QROWS - 1)) == 0) {      // a new 256-row window of query rows: re-hash this lane's three column keys
@@ -684,59 +605,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   FB_G2(i_, 6); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
         if (!PREF) { FB_LD_QF(qb_, dob_, 0); FB_LD_SEEDS(lse_s, del_s, 0); FB_LD_KF(0); }
         FB_FENCE();
-        // slot 0: G1(b0), no VALU work of this tile to pair yet; the transposed fragments of sub-block 0 arrive meanwhile.  ILV: twelve of
-        // the 24 dQ MFMAs of the PREVIOUS tile ride here and twelve in slot 1 (tile 0 has no predecessor: they run on whatever the image
-        // holds and the result is dropped - no branch in the slots)
-        if constexpr (ILV) {
-#define FB_DQ_STEP(k_)                                                                              \
-  if ((k_) == 0) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dqacc) : "v"(FB_U4(afA[0])), "v"(FB_U4(bfA[0])));           \
-  else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(afA[(k_) % 3])), "v"(FB_U4(bfA[(k_) % 3])));        \
-  if ((k_) + 3 < FB_KEYS / 16) {                                                                    \
-    afA[(k_) % 3] = fb_tr(dsimg + (16 * ((k_) + 3)) * 128, vaq);                                    \
-    bfA[(k_) % 3] = fb_tr(kimg + (16 * ((k_) + 3)) * 128, vad);                                     \
-  }                                                                                                 \
-  FB_FENCE();
-          FB_G1(0, 0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_DQ_STEP(0); FB_DQ_STEP(1);
-          FB_G1(0, 1); FB_FENCE(); FB_DQ_STEP(2); FB_DQ_STEP(3);
-          FB_G1(0, 2); FB_FENCE(); FB_DQ_STEP(4); FB_DQ_STEP(5);
-          FB_G1(0, 3); FB_FENCE(); FB_DQ_STEP(6); FB_DQ_STEP(7);
-          FB_G1(0, 4); FB_FENCE(); FB_DQ_STEP(8);
-          FB_G1(0, 5); FB_FENCE(); FB_DQ_STEP(9);
-          FB_G1(0, 6); FB_FENCE(); FB_DQ_STEP(10);
-          FB_G1(0, 7); FB_FENCE(); FB_DQ_STEP(11);
-          FB_LD_KF(1); FB_FENCE();
-          FB_THR(0); FB_LD_RK(0);
-          FB_G1(1, 0); FB_E(0, 0); FB_FENCE(); FB_DQ_STEP(12); FB_DQ_STEP(13);
-          FB_G1(1, 1); FB_E(0, 1); FB_FENCE(); FB_DQ_STEP(14); FB_DQ_STEP(15);
-          FB_G1(1, 2); FB_E(0, 2); FB_FENCE(); FB_DQ_STEP(16); FB_DQ_STEP(17);
-          FB_G1(1, 3); FB_E(0, 3); FB_FENCE(); FB_DQ_STEP(18); FB_DQ_STEP(19);
-          FB_G1(1, 4); FB_E(0, 4); FB_FENCE(); FB_DQ_STEP(20);
-          FB_G1(1, 5); FB_E(0, 5); FB_FENCE(); FB_DQ_STEP(21);
-          FB_G1(1, 6); FB_E(0, 6); FB_FENCE(); FB_DQ_STEP(22);
-          FB_G1(1, 7); FB_E(0, 7); FB_FENCE(); FB_DQ_STEP(23);
-          // The last dQ MFMA writes its 16 registers at the END of its 32 cycles, and the compiler - which does not see an MFMA in the asm
-          // statement - hands those registers to whatever comes next: on tile 0, where the result is dropped, the exponentials of slot 2
-          // landed in them and were overwritten by the MFMA's late write (garbage P for one key block, seen as 1e37 in dK / dV with the
-          // atomic form and dropout).  Twelve wait states on EVERY path, not only inside the hand-off below.
-          asm volatile("s_nop 11" : "+v"(dqacc));
-          // dQ of the previous tile leaves: running sum + this block's share -> the hand-off buffer (or the atomics).  Hand-off form: NO
-          // branch around it on tile 0 - its byte offset ((-1) * 4 + wave) * 4096 wraps far behind the descriptor's records and the four
-          // stores are dropped by the range check; a branch here splits the slot's basic block, and the compiler then SINKS the
-          // exponentials of E(b0) out of the MFMA shadow into the block behind the branch (seen in the ISA)
-          if constexpr (HO) { FB_DQ_FINALIZE(qt - 1); }
-          else if (qt > 0) { FB_DQ_FINALIZE(qt - 1); }
-        } else {
+        // slot 0: G1(b0), nothing to pair yet; the transposed fragments of sub-block 0 arrive meanwhile
         FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();
         FB_LD_KF(1); FB_FENCE();
         FB_SLOT_G1E(1, 0);
-        }
         // the barrier that ends the PREVIOUS tile (every wave is done reading its dS^T image) stands here, ahead of the first dS^T
         // store of this tile, instead of behind the atomics: a wave that got its atomics out early starts the next tile.  A bare
         // s_barrier: it orders later LDS writes behind earlier LDS reads whose data has long been consumed by MFMAs - nothing
         // to wait for (__syncthreads would drain the LDS loads in flight here)
         asm volatile("s_barrier" ::: "memory");
-        if constexpr (ILV) { FB_LD_QT(0); }                  // (ILV: the transposed Q / dO fragments of sub-block 0, first used right below)
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(0);
         FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
@@ -847,14 +725,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         }
       }
       }   // general form
-      // Stage the next tile here, at the end of phase A: its DMA pieces, issued a third of the way into the phase, have long landed; the
-      // buffer was last read in phase A of the previous tile, and the barrier below publishes it.
-      // K^T fragments of the first steps of the dQ product: they do not depend on this tile, so they are fetched ahead of the barrier
-      // (their registers were the transposed Q / dO fragments until a moment ago)
-      if constexpr (ILV) {
+      // Stage the next tile here, at the end of phase A: the global loads issued at the top of the tile have long landed (the
+      // LDS writes wait on vmcnt, which retires in order - behind the 16 atomics of phase B that wait would last their
+      // ~3000-cycle round trip), the buffer was last read in phase A of the previous tile, and the barrier below publishes it,
+      // so that phase B can already fetch the next tile's first operands.
+      // K^T fragments of the first two groups of the dQ product: they do not depend on this tile, so they are fetched ahead of
+      // the barrier (their registers were the transposed Q / dO fragments until a moment ago)
+      bf16x8 afA[4], bfA[4], afB[4], bfB[4];
+      if constexpr (PREF) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) bfA[u] = fb_tr(kimg + (16 * u) * 128, vad);
+        for (int u = 0; u < 4; ++u) { bfA[u] = fb_tr(kimg + (16 * u) * 128, vad); bfB[u] = fb_tr(kimg + (16 * (4 + u)) * 128, vad); }
       }
+      // hand-off: the running sum of the blocks before this one (zeros for block 0: zero-record descriptor)
+      u32x4 pin[4];
+      const unsigned ho_off = (unsigned)((qt * 4 + wave_u) * 4096 + lane * 16);
       if constexpr (HO) {
         // every wave: its running-sum stores of the PREVIOUS tile have landed (the flag below is stored behind this wait and the
         // barrier: Guideline 16 R1); the stage loads of this tile are younger and are needed right below anyway
@@ -863,13 +747,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       }
       FB_STAGE_WRITE(buf ^ 1);
       if constexpr (HO) {
-        // hand-off: the running sum of the blocks before this one (zeros for block 0: zero-record descriptor).  This wave's own poll has
-        // matched: its loads of the sum may go out now (every load of handed-off bytes is an sc1 load issued by a wave behind its own
-        // matching poll) - ahead of the barrier, behind the staging wait (which would wait for them too); they have the barrier and the
-        // dQ MFMAs of this tile (ILV: slot 0 of the next tile) to come back
-        const unsigned ho_ld = (unsigned)((qt * 4 + wave_u) * 4096 + lane * 16);
+        // this wave's own poll has matched: its loads of the sum may go out now (every load of handed-off bytes is an sc1 load issued
+        // by a wave behind its own matching poll) - ahead of the barrier, behind the staging wait (which would wait for them too),
+        // so that they have the barrier and all of phase B to come back
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pin[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ho_ld + g * 1024, 0, 16 /* sc1 */);
+        for (int g = 0; g < 4; ++g) pin[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ho_off + g * 1024, 0, 16 /* sc1 */);
       }
       __syncthreads();                                       // the dS^T image of this query tile is complete
       if constexpr (HO && !TAIL) {
@@ -877,22 +759,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         if ((!CAN_LAST || !ho_last) && tid == 0 && qt > 0 && !w.never_publish)
           __hip_atomic_store(flags_pair + (qt - 1), (unsigned)(kbw + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if constexpr (ILV) {
-        // the dQ product of this tile runs in slots 0 and 1 of the next one (or in the drain behind the loop): its first dS^T fragments and
-        // the next tile's first operands (its stage buffer was published by the barrier above) are fetched here
-        const char* dsc_ = dsimg;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) afA[k] = fb_tr(dsc_ + (16 * k) * 128, vaq);
-        const char* nq_ = stage + (buf ^ 1) * FB_STAGE;
-        FB_LD_QF(nq_, nq_ + FB_TILE, 0);
-        FB_LD_SEEDS(reinterpret_cast<const float*>(nq_ + 2 * FB_TILE), reinterpret_cast<const float*>(nq_ + 2 * FB_TILE) + FB_QROWS, 0);
-        FB_LD_KF(0);
-        FB_FENCE();
-      } else {
-      // ================= phase B (serial form): dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
+      // ================= phase B: dQ[32 q, 32 d] of this wave over all keys of the workgroup =================
+      {
+        f32x16 dqacc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqacc[i] = 0.f;
-        // steps of 16 keys in groups of 4, the steps that hold valid keys (rows past them may never have been written)
+        // steps of 16 keys in groups of 4; full key blocks: 24 steps with the transposed reads of group g+1 in flight under the
+        // MFMAs of group g, otherwise the steps that hold valid keys (rows past them may never have been written)
 #define FB_DQ_LOAD_A(af_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) af_[u] = fb_tr(dsimg + (16 * (4 * (g_) + u)) * 128, vaq);
 #define FB_DQ_LOAD_B(bf_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) bf_[u] = fb_tr(kimg + (16 * (4 * (g_) + u)) * 128, vad);
 #define FB_DQ_LOAD(af_, bf_, g_) FB_DQ_LOAD_A(af_, g_) FB_DQ_LOAD_B(bf_, g_)
@@ -905,7 +778,37 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       : "+v"(dqacc)                                                                                 \
       : "v"(FB_U4(af_[0])), "v"(FB_U4(af_[1])), "v"(FB_U4(af_[2])), "v"(FB_U4(af_[3])), "v"(FB_U4(bf_[0])), "v"(FB_U4(bf_[1])),  \
         "v"(FB_U4(bf_[2])), "v"(FB_U4(bf_[3])));
-        {
+        if constexpr (PREF) {
+          // 24 steps of 16 keys, eight steps of operands in flight: step k's MFMA is followed in the stream by the four transposed
+          // reads of step k + 8 (into the registers it just released), so the reads run under the MFMAs instead of between them
+          // (reads and MFMAs of this phase measured ADDITIVE in the grouped form: tools/fused_stamps.py)
+          // afA/bfA hold steps k with (k & 7) < 4, afB/bfB those with (k & 7) >= 4; the K^T fragments of steps 0..7 were fetched
+          // ahead of the barrier
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (k < 4) afA[k] = fb_tr(dsimg + (16 * k) * 128, vaq);
+            else afB[k & 3] = fb_tr(dsimg + (16 * k) * 128, vaq);
+          }
+          {   // the next tile's first operands (its stage buffer was published by the barrier above)
+            const char* nq_ = stage + (buf ^ 1) * FB_STAGE;
+            FB_LD_QF(nq_, nq_ + FB_TILE, 0);
+            FB_LD_SEEDS(reinterpret_cast<const float*>(nq_ + 2 * FB_TILE), reinterpret_cast<const float*>(nq_ + 2 * FB_TILE) + FB_QROWS, 0);
+            FB_LD_KF(0);
+          }
+          FB_FENCE();
+#pragma unroll
+          for (int k = 0; k < FB_KEYS / 16; ++k) {
+            const bool hiHalf = (k & 7) >= 4;
+            bf16x8& a_ = hiHalf ? afB[k & 3] : afA[k & 3];
+            bf16x8& b_ = hiHalf ? bfB[k & 3] : bfA[k & 3];
+            asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(a_)), "v"(FB_U4(b_)));
+            if (k + 8 < FB_KEYS / 16) {
+              a_ = fb_tr(dsimg + (16 * (k + 8)) * 128, vaq);
+              b_ = fb_tr(kimg + (16 * (k + 8)) * 128, vad);
+            }
+            FB_FENCE();
+          }
+        } else {
           const int nsteps = FULL ? (EDGE ? nks : FB_KEYS / 16) : nks;
           int k4 = 0;
           for (; k4 + 4 <= nsteps; k4 += 4) {
@@ -922,17 +825,58 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_DQ_LOAD_A
 #undef FB_DQ_LOAD_B
 #undef FB_DQ_MFMA
-        FB_DQ_FINALIZE(qt);
-        if constexpr (!FULL) __syncthreads();                // every wave is done reading the dS^T image (pipelined edge sweep: see phase A)
+        asm volatile("s_nop 11" : "+v"(dqacc));              // MFMA result -> VALU read
+        // dS (K c) = c dS K;  dQ = scale dS K = acc * ln 2.  Register r = query row acc_row(r, lh), 32 consecutive dims per
+        // half wave: two 128-byte segments per wave instruction
+        const int q0 = qt * FB_QROWS + dq_qb * 32;
+        if constexpr (HO) {
+          f32x16 tot;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            // (bit_cast of the WHOLE vector, then the element: bit_cast(float, pin[g][j]) is narrowed by this clang to a one-dword load
+            // whose value stands in for all four elements - seen in the ISA)
+            const f32x4 pf = __builtin_bit_cast(f32x4, pin[r >> 2]);
+            tot[r] = __builtin_fmaf(dqacc[r], ho_ln2, pf[r & 3]);
+          }
+          if (CAN_LAST && ho_last) {
+            // the last block of the pair: dQ rows in bf16.  Lanes 2i / 2i+1 hold columns 2i / 2i+1 of the same rows: the even lane
+            // takes the odd lane's value of register 2m, the odd lane the even lane's value of register 2m+1 (DPP quad_perm 1,0,3,2),
+            // each then stores ONE 4-byte pair of its own row
+            bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dq) + (int64_t)b * p.q_bs + h * 64 + dq_db * 32 + (lr & ~1);
+            const bool odd = lr & 1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+              const float a = tot[2 * m], bb = tot[2 * m + 1];
+              const float send = odd ? a : bb;
+              const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+              const int row = q0 + acc_row(2 * m, lh) + (odd ? 1 : 0);
+              if (row < p.Lq) *reinterpret_cast<uint32_t*>(dqp + (int64_t)row * p.q_rs) = odd ? fb_pack2(recv, bb) : fb_pack2(a, recv);
+            }
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 t4 = {tot[4 * g], tot[4 * g + 1], tot[4 * g + 2], tot[4 * g + 3]};
+              if (w.agent_scope) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 16 /* sc1: write-through */);
+              else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 0 /* stays in this XCD's L2 */);
+            }
+          }
+        } else {
+        const int rstep = p.H * 64;
+        float* rowp = DQ + (int64_t)q0 * rstep + dq_db * 32;          // wave-uniform (dq_qb / dq_db come from readfirstlane)
+        const int loff = lr + 4 * lh * rstep;                          // this lane's element offset
+#define FB_DQ_OUT(ptr_, v_) unsafeAtomicAdd(ptr_, v_)
+        if (q0 + 32 <= p.Lq) {                               // whole sub-block inside the sequence
+#pragma unroll
+          for (int r = 0; r < 16; ++r) FB_DQ_OUT(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (q0 + acc_row(r, lh) < p.Lq) FB_DQ_OUT(rowp + ((r & 3) + 8 * (r >> 2)) * rstep + loff, dqacc[r] * 0.6931471805599453f);
+        }
+#undef FB_DQ_OUT
+        }
       }
-    }
-    if constexpr (ILV) {
-      // drain: the dQ product of the LAST tile (its dS^T image was completed by the loop's last barrier, its first operands are in
-      // registers, its predecessor sum is on its way)
-      FB_DQ_STEP(0); FB_DQ_STEP(1); FB_DQ_STEP(2); FB_DQ_STEP(3); FB_DQ_STEP(4); FB_DQ_STEP(5); FB_DQ_STEP(6); FB_DQ_STEP(7);
-      FB_DQ_STEP(8); FB_DQ_STEP(9); FB_DQ_STEP(10); FB_DQ_STEP(11); FB_DQ_STEP(12); FB_DQ_STEP(13); FB_DQ_STEP(14); FB_DQ_STEP(15);
-      FB_DQ_STEP(16); FB_DQ_STEP(17); FB_DQ_STEP(18); FB_DQ_STEP(19); FB_DQ_STEP(20); FB_DQ_STEP(21); FB_DQ_STEP(22); FB_DQ_STEP(23);
-      FB_DQ_FINALIZE(nqt - 1);
+      if constexpr (!FULL) __syncthreads();                  // every wave is done reading the dS^T image (pipelined form: see phase A)
     }
     if constexpr (HO) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last tile's stores (the tail launch reads them back in its next key block)
@@ -953,8 +897,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_LD_QF
 #undef FB_LD_SEEDS
 #undef FB_LD_KF
-#undef FB_DQ_FINALIZE
-#undef FB_DQ_STEP
     // dK^T / dV^T were last written by asm MFMAs the compiler does not see as such: cover MFMA result -> v_accvgpr_read
 #pragma unroll
     for (int kb = 0; kb < FB_KB; ++kb)

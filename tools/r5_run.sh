@@ -102,6 +102,36 @@ PYEOF
              done; python3 $REPO/tools/ablate/scope_pmc_sum.py $OUT scopeab_pmc_$sc >> $OUT/scopeab.txt; done
              cd $REPO
              cat $OUT/scopeab.txt | cut -c1-170 ;;
+    scopestep) # same box, back to back: the whole step with the write-through running sums (round-4 form), then the XCD-local ones (shipped), twice
+             for i in 1 2; do for sc in agent xcd; do
+               T2S_FB_HANDOFF_SCOPE=$sc timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-dropout0 > $OUT/bench_${sc}$i.json 2> $OUT/bench_${sc}$i.err || { tail -30 $OUT/bench_${sc}$i.err; exit 1; }
+             done; done
+             python3 - $OUT <<'PYEOF' | tee $OUT/scope_step_ab.txt
+import json, sys
+out = sys.argv[1]
+for name in ("agent1", "xcd1", "agent2", "xcd2"):
+    b = json.loads([l for l in open("%s/bench_%s.json" % (out, name)) if l.startswith("{")][-1])
+    r = b["roofline"]
+    print("%-7s %8.1f ms/step  %6.2f samples/s   attention backward %6.1f ms/step (frac %.3f)  forward attention %6.1f ms/step" % (
+        name, b["ms_per_step"], b["value"], r["ms_per_step"], r["frac"], b.get("roofline_fwd", {}).get("ms_per_step", float("nan"))))
+PYEOF
+             ;;
+    fbstep)  # same box, back to back: the whole step with a variant fused backward (FB_VARIANT), then the product, twice
+             bash tools/ablate/fb_variant.sh ${FB_VARIANT} tools/ablate/variants/attn_bwd_fused_bf16_${FB_VARIANT}.hip > $OUT/fb_variant_build.log 2>&1 || { tail -20 $OUT/fb_variant_build.log; exit 1; }
+             for i in 1 2; do
+               T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_${FB_VARIANT}.so timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-dropout0 > $OUT/bench_variant$i.json 2> $OUT/bench_variant$i.err || { tail -30 $OUT/bench_variant$i.err; exit 1; }
+               timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-dropout0 > $OUT/bench_product$i.json 2> $OUT/bench_product$i.err || { tail -30 $OUT/bench_product$i.err; exit 1; }
+             done
+             python3 - $OUT ${FB_VARIANT} <<'PYEOF' | tee $OUT/fb_step_ab.txt
+import json, sys
+out, var = sys.argv[1], sys.argv[2]
+for name in ("variant1", "product1", "variant2", "product2"):
+    b = json.loads([l for l in open("%s/bench_%s.json" % (out, name)) if l.startswith("{")][-1])
+    r = b["roofline"]
+    print("%-22s %8.1f ms/step  %6.2f samples/s   attention backward %6.1f ms/step (frac %.3f)  forward attention %6.1f ms/step" % (
+        name.replace("variant", var + " "), b["ms_per_step"], b["value"], r["ms_per_step"], r["frac"], b.get("roofline_fwd", {}).get("ms_per_step", float("nan"))))
+PYEOF
+             ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
 done
