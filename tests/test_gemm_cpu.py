@@ -32,3 +32,28 @@ def test_wgrad_map_keeps_a_row_split_on_one_xcd_for_the_step_shapes():
     for x in range(8):
         hosted = [G.wgrad_item(x + 8 * j, c, 27, 9) for j in range(27)]
         assert {h[0] for h in hosted} == {x} and sorted(h[1] for h in hosted) == list(range(27))
+
+
+def test_nt_workgroup_map_covers_every_tile_once_and_groups_the_weight_panels():
+    """csrc/gemm_bf16.hip nt_item through its Python mirror: every (M-block, N-tile) exactly once for ragged shapes and every group width;
+    with b = 4 on the step's FFN shape the 32 workgroups an XCD runs at a time see 4 weight panels and 8 activation panels."""
+    from vitxt_gqa_amd import gemm as G
+    for tiles_m in (1, 3, 7, 8, 9, 64, 2539):
+        for tiles_n in (1, 3, 9, 12, 13):
+            for b in sorted({1, 2, 3, 4, 5, tiles_n, G.nt_group(tiles_n)}):
+                if b > tiles_n:
+                    continue
+                seen = {}
+                for wg in range(G.nt_grid(tiles_m, tiles_n)):
+                    it = G.nt_item(wg, tiles_m, tiles_n, b)
+                    if it is not None:
+                        assert 0 <= it[0] < tiles_m and 0 <= it[1] < tiles_n
+                        assert it not in seen, (tiles_m, tiles_n, b, it, wg, seen[it])
+                        seen[it] = wg
+                assert len(seen) == tiles_m * tiles_n, (tiles_m, tiles_n, b, len(seen))
+    assert G.nt_group(12) == 12      # shipped default: all N-tiles of an M-block side by side
+    tiles_m, tiles_n, b = 2539, 12, 4
+    for x in range(8):
+        first = [G.nt_item(8 * j + x, tiles_m, tiles_n, b) for j in range(32)]      # the first 32 workgroups of XCD x
+        assert len({t[1] for t in first}) == 4 and len({t[0] for t in first}) == 8
+        assert len({G.nt_item(8 * j + x, tiles_m, tiles_n, b)[0] // ((tiles_m + 7) // 8) for j in range(0, 3000, 97)}) == 1      # one M range per XCD

@@ -132,6 +132,26 @@ for name in ("variant1", "product1", "variant2", "product2"):
         name.replace("variant", var + " "), b["ms_per_step"], b["value"], r["ms_per_step"], r["frac"], b.get("roofline_fwd", {}).get("ms_per_step", float("nan"))))
 PYEOF
              ;;
+    ntmap)   # the NT GEMM's work map: N-tiles per group, timing + one FETCH_SIZE pass (tools/gemm_nt_map_probe.py)
+             timeout -k 10 600 python3 -m pytest tests/test_gemm_gpu.py -m gpu -x -q > $OUT/pytest_gemm.log 2>&1 || { tail -60 $OUT/pytest_gemm.log; exit 1; }; tail -2 $OUT/pytest_gemm.log
+             timeout -k 10 600 python3 tools/gemm_nt_map_probe.py > $OUT/gemm_nt_map.txt 2>&1 || { tail -40 $OUT/gemm_nt_map.txt; exit 1; }
+             cd /tmp && export TMPDIR=/tmp
+             PROBE_PMC=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/ntmap_pmc -- python3 $REPO/tools/gemm_nt_map_probe.py > $OUT/ntmap_pmc.log 2>&1 || true
+             cd $REPO
+             python3 - $OUT >> $OUT/gemm_nt_map.txt <<'PYEOF'
+import csv, glob, sys
+out = sys.argv[1]
+rows = []
+for f in glob.glob(out + "/ntmap_pmc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "FETCH_SIZE" and "gemm_nt_bf16" in r["Kernel_Name"]:
+            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"][:60], float(r["Counter_Value"])))
+rows.sort()
+print("# FETCH_SIZE per dispatch of the NT kernel, in dispatch order (PROBE_PMC=1: per form and width one warm-up call and one timed call); GB = 2 x KB x 1024")
+for d, k, v in rows:
+    print("  dispatch %4d  %-60s  %7.2f GB" % (d, k, 2 * v * 1024 / 1e9))
+PYEOF
+             cat $OUT/gemm_nt_map.txt | cut -c1-150 ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
 done

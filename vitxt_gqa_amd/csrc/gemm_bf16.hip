@@ -66,6 +66,7 @@ struct GemmArgs {
   int M, N, K;            // TN: M = No, N = Ni, K = rows of this launch
   int64_t lda, ldw, ldc;
   int tiles_m, tiles_n;
+  int ngroup;             // NT: N-tiles per group of the work map (nt_item)
   int k_chunk;            // TN: rows per split (a multiple of 128)
   int splits;             // TN: row splits
 };
@@ -89,13 +90,6 @@ __device__ __forceinline__ void g_dma16(u32x4 rs, uint32_t lds, int voff, int so
 #define G_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ int g_f(int row) { return (row >> 1) & 7; }      // NT image: 16-byte chunk c of row r sits at c ^ f(r)
-
-// bijective XCD-aware remap of a 1-D grid: hardware deals workgroup ids round-robin to the 8 XCDs; logical ids are handed out so that
-// the workgroups of one XCD walk a CONTIGUOUS range (neighbouring tiles share operand panels through that XCD's L2)
-__device__ __forceinline__ int g_xcd_remap(int wg, int nwg) {
-  const int q = nwg / G_XCDS, r = nwg % G_XCDS, x = wg % G_XCDS;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / G_XCDS;
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // operand loaders.  Both present the same interface to the main loop:
@@ -326,14 +320,47 @@ __device__ __forceinline__ void gemm_mainloop(Loader& ld, f32x4 (&acc)[8][4], in
 // ---------------------------------------------------------------------------------------------------------------------------------
 // NT kernel
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Work map of the NT kernel.  XCD x (workgroups with id % 8 == x, dispatched in id order, 32 at a time) owns a contiguous range of
+// M-blocks.  Inside it the N-tiles are taken in GROUPS of b: group-major, then M-block, then the N-tile inside the group - so the 32
+// workgroups an XCD runs at a time cover 32 / b M-blocks x b N-tiles, the b weight panels of the group (b x 384 KB at K = 768) stay in
+// that XCD's L2 for the whole pass over the M range, and an activation panel is shared by b workgroups that start together.
+// Measured on the step's shapes (profiles/r05_gemm_nt_map.txt, M = 649 984, N = 3072, K = 768; FETCH_SIZE per launch | time):
+//   b = 12 (all N-tiles of an M-block side by side: the 12 weight panels, 4.7 MB, do not fit the 4 MB L2 and are fetched again from the
+//   Infinity Cache by every round of workgroups)  5.9 GB | 3.92 ms with the dual epilogue, 16.6 GB | 3.89 ms with the gelu' epilogue;
+//   b = 6  4.8 GB | 3.96 ms, 10.9 GB | 3.85 ms;   b = 4  4.5 GB | 4.03 ms, 8.7 GB | 3.97 ms;   b = 1  12.4 GB | 4.61 ms.
+// Fewer bytes, not less time: these launches are bound by the matrix pipe at its power-limited clock and by their epilogues, not by
+// operand fetch - so the default stays b = tiles_n (T2S_GEMM_NT_GROUP overrides it for probe runs).
+__device__ __forceinline__ bool nt_item(int wg, int tiles_m, int tiles_n, int b, int& tm, int& tn) {
+  const int x = wg % G_XCDS, j = wg / G_XCDS;
+  const int mbx = (tiles_m + G_XCDS - 1) / G_XCDS;
+  const int m_lo = x * mbx;
+  const int mcount = tiles_m - m_lo < mbx ? tiles_m - m_lo : mbx;
+  if (mcount <= 0) return false;
+  const int full = tiles_n / b, rem = tiles_n - full * b;
+  const int in_full = full * mcount * b;
+  if (j < in_full) {
+    const int per = mcount * b, g = j / per, r = j - g * per;
+    tm = m_lo + r / b;
+    tn = g * b + (r - (r / b) * b);
+    return true;
+  }
+  const int jr = j - in_full;
+  if (rem == 0 || jr >= mcount * rem) return false;
+  tm = m_lo + jr / rem;
+  tn = full * b + (jr - (jr / rem) * rem);
+  return true;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, lq = lane >> 4;
-  const int tile = g_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  int tm, tn;
+  if (!nt_item((int)blockIdx.x, p.tiles_m, p.tiles_n, p.ngroup, tm, tn)) return;      // workgroup-uniform
+  tm = __builtin_amdgcn_readfirstlane(tm);
+  tn = __builtin_amdgcn_readfirstlane(tn);
   const int m0 = tm * 256, n0 = tn * 256;
 
   f32x4 acc[8][4];
@@ -613,7 +640,13 @@ extern "C" int t2s_gemm_nt(const void* a, const void* w, const void* bias, void*
   p.M = (int)M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
   p.tiles_m = (int)((M + 255) / 256);
   p.tiles_n = (N + 255) / 256;
-  const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
+  // N-tiles per group of the work map (nt_item): all of them (the measured optimum in TIME, see nt_item); T2S_GEMM_NT_GROUP overrides it (probe runs)
+  p.ngroup = p.tiles_n;
+  if (const char* e = getenv("T2S_GEMM_NT_GROUP")) {
+    const int v = atoi(e);
+    if (v >= 1) p.ngroup = v < p.tiles_n ? v : p.tiles_n;
+  }
+  const int64_t grid = (int64_t)G_XCDS * ((p.tiles_m + G_XCDS - 1) / G_XCDS) * p.tiles_n;
   T2S_CHECK_ARG(grid < ((int64_t)1 << 31), "gemm_nt: too many tiles");
   static bool done[4] = {false, false, false, false};
   hipStream_t st = (hipStream_t)stream;

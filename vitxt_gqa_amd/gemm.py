@@ -120,3 +120,34 @@ def wgrad_item(wg, c, T, S):
     q = (x - S) * c + j
     split, tile = q // L, c + q % L
     return (split, tile) if split < S else None
+
+
+# ---- the NT kernel's work map (csrc/gemm_bf16.hip nt_item), mirrored for the CPU tests: XCD x = wg % 8 owns a contiguous range of
+# M-blocks; inside it the N-tiles go in groups of b - group-major, then M-block, then the N-tile inside the group
+def nt_grid(tiles_m, tiles_n):
+    return 8 * ((tiles_m + 7) // 8) * tiles_n
+
+
+def nt_group(tiles_n):
+    return tiles_n          # the shipped default (fewer N-tiles per group move fewer bytes but take longer: profiles/r05_gemm_nt_map.txt)
+
+
+def nt_item(wg, tiles_m, tiles_n, b):
+    x, j = wg % 8, wg // 8
+    mbx = (tiles_m + 7) // 8
+    m_lo = x * mbx
+    mcount = min(mbx, tiles_m - m_lo)
+    if mcount <= 0:
+        return None
+    full = tiles_n // b
+    rem = tiles_n - full * b
+    in_full = full * mcount * b
+    if j < in_full:
+        per = mcount * b
+        g, r = j // per, j % per
+        return (m_lo + r // b, g * b + r % b)
+    jr = j - in_full
+    if rem == 0 or jr >= mcount * rem:
+        return None
+    return (m_lo + jr // rem, full * b + jr % rem)
+
