@@ -55,7 +55,7 @@ constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
 //   10.1 GB of HBM traffic per launch at B = 8 against 3.6 GB now, and the launch is 2.8 % faster (profiles/r05_handoff_scope.txt).
 //   The premise is CHECKED, not assumed: every workgroup ORs its XCC_ID into a word of its XCD group; a group that sees two
 //   different XCDs sets bit 1 of the status word - the step is discarded and the next optimizer call raises, like a timeout
-//   (FbWork::agent_scope = 1 / dq_mode bit 9 / T2S_FB_HANDOFF_SCOPE=agent selects the write-through form for such a device).  The running sums live in the ACCUMULATOR-NATIVE layout (per tile: wave quadrant, register group, lane: every
+//   (the kernel's WT instantiations / dq_mode bit 9 / T2S_FB_HANDOFF_SCOPE=agent are the write-through form for such a device).  The running sums live in the ACCUMULATOR-NATIVE layout (per tile: wave quadrant, register group, lane: every
 //   access a lane-linear 1 KB piece).  Protocol per query tile t (flags[pair][t] = number of blocks whose sum is published):
 //     producer  the four waves store their quadrants; one tile later, behind every wave's s_waitcnt vmcnt(0) and the
 //               workgroup barrier that phase B needs anyway, ONE lane stores flags[t] = k + 1 (sc1 store)
@@ -79,7 +79,6 @@ struct FbWork {
   int handoff;
   unsigned spin_limit;    // polls a hand-off wait may take before it gives up (FB_SPIN_LIMIT; 0 in the diagnostic mode of the tests)
   int never_publish;      // diagnostic mode (dq_mode bit 8): no block publishes its flags - every successor's wait times out
-  int agent_scope;        // dq_mode bit 9: write-through (sc1) stores of the running sums - for a device whose XCD groups do not sit on one XCD each
   int diag_misplaced;     // diagnostic mode (dq_mode bit 10): the placement check sees alternating XCDs inside every group
 };
 // Staging of the Q / dO tiles and their row constants by LDS-DMA (buffer_load ... lds: 1 KB per wave-instruction = 8 rows x 128 B
@@ -268,7 +267,11 @@ __device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dp
 // complement (the same pipeline with the validity / decoder rule applied to P); MODE 2:
 // the tail launch (plain sweep, loops over the key blocks beyond the static bound).  Separate kernels, so that each is
 // register-allocated for one sweep.
-template <bool USE_IDX, int MODE, bool DROP, bool HO>
+// WT: the hand-off's running sums are stored write-through (sc1) and the placement of the XCD groups is not looked at (dq_mode bit 9);
+// a compile-time choice - a run-time one would be a branch inside a slot of the interleaved sweep (see ILV below), and issuing both
+// stores through two descriptors, one of them empty, measured ~1 % slower than one store.  Instantiated for the shipped launch
+// forms only (MODE 3 and the tail launch).
+template <bool USE_IDX, int MODE, bool DROP, bool HO, bool WT = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams p, FbWork w) {
   constexpr bool TAIL = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       unsigned* tk = w.tickets + (MODE % 3) * T2S_XCDS + xg;
       // (a stale read only errs on the low side: then the atomic decides)
       sl[0] = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tab[w.groups] ? 0xFFFFFFFFu : atomicAdd(tk, 1u);
-      if (!w.agent_scope) {
+      if constexpr (!WT) {
         // XCD-local sums: every workgroup of this group must sit on the same XCD.  The first one to find another XCD's bit reports it.
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -376,12 +379,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     // running sums of this pair through a buffer descriptor: block 0 gets ZERO records - its loads return 0.0 without touching
     // memory, so the sweep needs no branch around them
     const __amdgpu_buffer_rsrc_t rs_ld = fb_rsrc(part_pair, (HO && kbw > 0) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
-    // two store descriptors, ONE of them with zero records: the XCD-local form stores through rs_st (plain stores, the line stays in this
-    // XCD's L2), the write-through form through rs_st_wt (sc1).  Both stores are issued, the one through the empty descriptor is dropped by
-    // the range check - a BRANCH between them would sit inside a slot of the interleaved sweep and let the compiler sink that slot's VALU
-    // work out of the MFMA shadow (measured: the interleave's 3.5 % were gone with the branch in place)
-    const __amdgpu_buffer_rsrc_t rs_st = fb_rsrc(part_pair, (HO && !w.agent_scope) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
-    const __amdgpu_buffer_rsrc_t rs_st_wt = fb_rsrc(part_pair, (HO && w.agent_scope) ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
+    const __amdgpu_buffer_rsrc_t rs_st = fb_rsrc(part_pair, HO ? (unsigned)(nqt * (FB_QROWS * 64 * 4)) : 0u);
     // ---- K image of the workgroup's keys, pre-scaled by scale*log2e (one bf16 rounding per element, as the dK/dV kernel's
     // register fragments); rows past the list repeat its last key (their P is forced to 0 below)
 #pragma unroll
@@ -585,8 +583,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       } else {                                                                                      \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
           const f32x4 t4 = {tot[4 * g], tot[4 * g + 1], tot[4 * g + 2], tot[4 * g + 3]};            \
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, 0 /* stays in this XCD's L2 */); \
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st_wt, ho_off + g * 1024, 0, 16 /* sc1: write-through (zero records unless FbWork::agent_scope) */); \
+          /* plain store: the line stays in this XCD's L2;  WT: sc1, write-through */                \
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), rs_st, ho_off + g * 1024, 0, WT ? 16 : 0);           \
         }                                                                                           \
       }                                                                                             \
     } else {                                                                                        \
@@ -1118,7 +1116,6 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   w.handoff = handoff;
   w.spin_limit = diag_dead ? 0u : FB_SPIN_LIMIT;
   w.never_publish = diag_dead ? 1 : 0;
-  w.agent_scope = agent_scope ? 1 : 0;
   w.diag_misplaced = diag_misplaced ? 1 : 0;
   float* const dq32 = w.part;
   // > 64 KB of LDS per workgroup needs the opt-in: once per device (a flag per device ordinal is the only state kept)
@@ -1127,9 +1124,12 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
   if (dev < 0 || !lds_reserved[dev]) {
 #define FB_K(I_, M_, D_) reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, false>), reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, true>)
+#define FB_KW(I_, M_, D_) reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<I_, M_, D_, true, true>)      /* write-through sums: MODE 3 and the tail launch only */
   const void* kernels[] = {FB_K(true, 0, false), FB_K(true, 1, false), FB_K(true, 2, false), FB_K(false, 0, false), FB_K(false, 1, false),
                            FB_K(true, 0, true),  FB_K(true, 1, true),  FB_K(true, 2, true),  FB_K(false, 0, true),  FB_K(false, 1, true),
-                           FB_K(true, 3, false), FB_K(false, 3, false), FB_K(true, 3, true), FB_K(false, 3, true)};
+                           FB_K(true, 3, false), FB_K(false, 3, false), FB_K(true, 3, true), FB_K(false, 3, true),
+                           FB_KW(true, 3, false), FB_KW(false, 3, false), FB_KW(true, 3, true), FB_KW(false, 3, true), FB_KW(true, 2, false), FB_KW(true, 2, true)};
+#undef FB_KW
 #undef FB_K
   for (const void* k : kernels)
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
@@ -1157,27 +1157,36 @@ int launch_attn_bwd_fused_bf16(const AttnParams& p_in, int max_keys, void* works
 #define FB_LAUNCH2(IDX_, MODE_, DROP_, grid_)                                                                            \
   if (handoff) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, true>), grid_, block, FB_SMEM, st, p, w);   \
   else hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, false>), grid_, block, FB_SMEM, st, p, w);
+  // the shipped launch forms (MODE 3, tail) also exist with write-through sums
+#define FB_LAUNCH2W(IDX_, MODE_, DROP_, grid_)                                                                           \
+  if (handoff && agent_scope) hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<IDX_, MODE_, DROP_, true, true>), grid_, block, FB_SMEM, st, p, w); \
+  else { FB_LAUNCH2(IDX_, MODE_, DROP_, grid_) }
+#define FB_LAUNCHW(IDX_, MODE_, grid_)                                                                                 \
+  if (p.drop_thresh) { FB_LAUNCH2W(IDX_, MODE_, true, grid_) } else { FB_LAUNCH2W(IDX_, MODE_, false, grid_) }          \
+  T2S_CHECK_LAUNCH("attn_bwd_fused (five-product kernel)");
 #define FB_LAUNCH(IDX_, MODE_, grid_)                                                                                  \
   if (p.drop_thresh) { FB_LAUNCH2(IDX_, MODE_, true, grid_) } else { FB_LAUNCH2(IDX_, MODE_, false, grid_) }            \
   T2S_CHECK_LAUNCH("attn_bwd_fused (five-product kernel)");
   const char* split_env = getenv("T2S_FB_SPLIT_EDGE");          // A/B runs: the two-launch form of rounds 2-3 (read per call)
-  const bool split_edge = split_env && split_env[0] == '1';
+  const bool split_edge = split_env && split_env[0] == '1' && !agent_scope;      // (the write-through form exists as one launch only)
   if (p.kv_idx) {
     if (split_edge) {
       FB_LAUNCH(true, 0, grid);
       FB_LAUNCH(true, 1, grid);
     } else {
-      FB_LAUNCH(true, 3, grid);
+      FB_LAUNCHW(true, 3, grid);
     }
-    if (p.kblocks * FB_KEYS < p.idx_cap) { FB_LAUNCH(true, 2, tail); }
+    if (p.kblocks * FB_KEYS < p.idx_cap) { FB_LAUNCHW(true, 2, tail); }
   } else {
     if (split_edge) {
       FB_LAUNCH(false, 0, grid);
       FB_LAUNCH(false, 1, grid);
     } else {
-      FB_LAUNCH(false, 3, grid);
+      FB_LAUNCHW(false, 3, grid);
     }
   }
+#undef FB_LAUNCHW
+#undef FB_LAUNCH2W
 #undef FB_LAUNCH
 #undef FB_LAUNCH2
   if (!handoff) {
