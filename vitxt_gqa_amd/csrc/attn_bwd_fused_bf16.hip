@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     // B = 32 (21.4 vs 22.0 ms; 18.8 vs 19.2 without dropout) and the B = 64 step 3.7 ms shorter (profiles/r05_fused_ilv384_l2.txt); the
     // serial form is kept as tools/ablate/variants/attn_bwd_fused_bf16_serial384.hip.  Two rules the form depends on, both met the hard way:
     // NO BRANCH inside slots 0 / 1 (the compiler sinks the slot's exponentials out of the MFMA shadow behind it: the hand-off of "tile -1"
-    // and the choice of store scope are both done with out-of-range buffer offsets / zero-record descriptors instead), and twelve wait
+    // is done with out-of-range buffer offsets instead, and the scope of the sums' stores is the template parameter WT), and twelve wait
     // states behind the last dQ MFMA on EVERY path (its destination registers are free for the compiler the moment the asm statement has
     // issued; on tile 0, where the result is dropped, the next VALU results landed in them and were overwritten by the MFMA's late write).
     constexpr bool ILV = PREF;
