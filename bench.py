@@ -462,7 +462,10 @@ def main():
         from vitxt_gqa_amd import functional as _FN
         # which GEMMs of the BERT block ran on the own MFMA kernels (csrc/gemm_bf16.hip) instead of the library (T2S_OWN_GEMM)
         res["own_gemm"] = sorted(_FN.OWN_GEMM)
-        res["attn_bwd_dq"] = {"mode": "ordered hand-off (bit-reproducible)" if _ops.ATTN_BWD_DQ_MODE == 1 else "fp32 atomics",
+        _ho = (_ops.ATTN_BWD_DQ_MODE & 0xff) == 1
+        res["attn_bwd_dq"] = {"mode": "ordered hand-off (bit-reproducible)" if _ho else "fp32 atomics",
+                              "running_sums": ("write-through (T2S_FB_HANDOFF_SCOPE=agent)" if _ops.ATTN_BWD_DQ_MODE & 0x200 else
+                                               "XCD-local: kept in the L2 of the XCD that runs the pair's key blocks, placement checked in the kernel") if _ho else None,
                               "status": _ops.fused_handoff_status()}
         res["loss"] = float(last.detach())
         # the loss of the FIRST executed step (warm-up or timed): a function of --seed, the name-seeded weights and the block-seeded

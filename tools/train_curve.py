@@ -39,4 +39,4 @@ for i in range(steps):
     assert torch.isfinite(loss) and torch.isfinite(norm)
     launches = ops.fused_launches_seen(dev)
     timeouts += ops.fused_handoff_status(dev) & 1
-print("fused attention-backward launches: %d (dQ %s), hand-off spins that timed out: %d" % (launches, "hand-off" if ops.ATTN_BWD_DQ_MODE == 1 else "atomics", timeouts))
+print("fused attention-backward launches: %d (dQ %s), hand-off spins that timed out: %d" % (launches, "hand-off" if (ops.ATTN_BWD_DQ_MODE & 0xff) == 1 else "atomics", timeouts))

@@ -129,7 +129,7 @@ ATTN_BWD_FUSED_MIN_ROWS = 1024
 ATTN_BWD_DQ_MODE = 0 if os.environ.get("T2S_ATTN_BWD_DQ", "handoff") == "atomic" else 1
 # The hand-off's running sums stay in the L2 of the XCD that runs a (sample, head)'s key blocks (plain stores); the kernel checks that
 # every XCD group of workgroups really sits on one XCD and reports a violation through the status word (HandoffPlacement below).
-# T2S_FB_HANDOFF_SCOPE=agent (dq_mode bit 9) selects write-through stores instead - correct under any placement, 2.8 % slower.
+# T2S_FB_HANDOFF_SCOPE=agent (dq_mode bit 9) selects write-through stores instead - correct under any placement, 3 - 5 % slower.
 if ATTN_BWD_DQ_MODE == 1 and os.environ.get("T2S_FB_HANDOFF_SCOPE", "xcd") == "agent":
     ATTN_BWD_DQ_MODE |= 0x200
 _KEEP_DQ32 = os.environ.get("T2S_KEEP_DQ32", "0") == "1"     # tools/fused_stamps.py: keep the workspace, whose tail holds the diagnostic
@@ -191,7 +191,7 @@ def _fused_policy(fused, qkv, keys, L, mode):
     pays once the list is long (the round 2-3 rule: a static key bound of >= 2 048), and sequences of a few rows (text_bert: 20) stay on
     the two-kernel form (a 147 KB-LDS workgroup per (sample, head) for one query tile)."""
     if fused is None:
-        fused = ATTN_BWD_FUSED and (keys.cap_hint >= ATTN_BWD_FUSED_MIN_KEYS or (mode == 1 and L >= ATTN_BWD_FUSED_MIN_ROWS))
+        fused = ATTN_BWD_FUSED and (keys.cap_hint >= ATTN_BWD_FUSED_MIN_KEYS or ((mode & 0xff) == 1 and L >= ATTN_BWD_FUSED_MIN_ROWS))
     return bool(fused) and qkv.dtype == torch.bfloat16
 
 
