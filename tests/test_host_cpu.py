@@ -194,3 +194,24 @@ def test_backward_form_policy():
     assert not ops._fused_policy(None, bf, k(20), 20, 1) and not ops._fused_policy(None, bf, k(549), 1000, 1)
     assert not ops._fused_policy(None, f32, k(10132), 10132, 1) and not ops._fused_policy(True, f32, k(10132), 10132, 1)
     assert ops._fused_policy(True, bf, k(20), 20, 0) and not ops._fused_policy(False, bf, k(10132), 10132, 1)
+
+
+def test_handoff_scope_switch_keeps_the_launch_policy():
+    """T2S_FB_HANDOFF_SCOPE=agent sets dq_mode bit 9 (write-through running sums) on top of the hand-off: the backward-form policy
+    and everything else that asks "is this the hand-off" looks at the low byte only."""
+    import subprocess
+    import sys
+    import types
+    import torch
+    from vitxt_gqa_amd import ops
+    bf = torch.empty(1, dtype=torch.bfloat16)
+    k = lambda hint: types.SimpleNamespace(cap_hint=hint)
+    assert ops._fused_policy(None, bf, k(74), 10132, 0x201) and not ops._fused_policy(None, bf, k(74), 10132, 0)
+    env = dict(os.environ, T2S_FB_HANDOFF_SCOPE="agent")
+    out = subprocess.run([sys.executable, "-c", "from vitxt_gqa_amd import ops; print(ops.ATTN_BWD_DQ_MODE)"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.split()[-1] == str(0x201), (out.stdout, out.stderr)
+    env["T2S_ATTN_BWD_DQ"] = "atomic"          # the atomic form has no running sums: the switch is ignored
+    out = subprocess.run([sys.executable, "-c", "from vitxt_gqa_amd import ops; print(ops.ATTN_BWD_DQ_MODE)"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.split()[-1] == "0", (out.stdout, out.stderr)
