@@ -201,6 +201,63 @@ def cpu_baseline(V, seed=0, budget_s=330, full=(100, 100), guard_s=230):
     return result
 
 
+RANK_REPORT_FIELDS = ("elapsed_s", "finish_wait_gpu_ms_per_step", "finish_wait_host_ms_per_step", "handoff_status", "fused_launches",
+                      "attn_bwd_ms_per_step", "attn_fwd_ms_per_step", "peak_mem_gb")
+
+
+def _or_of(words):
+    st = 0
+    for v in words:
+        if v is not None:          # (None = a rank that did not report the field)
+            st |= int(v)
+    return st
+
+
+def gather_rank_report(local, device=None, group=None):
+    """What makes a first multi-GPU run diagnosable from its one JSON line: every rank contributes one float64 vector
+    (RANK_REPORT_FIELDS: its own wall time over the timed region, the time its compute stream / its host sat in
+    ``GradBuckets.finish()`` per step = the EXPOSED part of the gradient all-reduce, its sticky hand-off status word and fused launch
+    count, its attention kernel time per step), gathered with ONE ``all_gather``; rank 0 prints the per-rank lists plus min / max /
+    rank-of-max of the step time.  Works on any backend (``dist.all_gather`` of equal-sized tensors); with no process group it reports
+    the single rank."""
+    import torch.distributed as dist
+    vec = torch.tensor([float(local.get(k) if local.get(k) is not None else float("nan")) for k in RANK_REPORT_FIELDS], dtype=torch.float64,
+                       device=device if device is not None else "cpu")
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        got = [torch.empty_like(vec) for _ in range(world)]
+        dist.all_gather(got, vec, group=group)
+    else:
+        got = [vec]
+    rows = [g.cpu().tolist() for g in got]
+    per = {k: [(r[i] if r[i] == r[i] else None) for r in rows] for i, k in enumerate(RANK_REPORT_FIELDS)}      # NaN (not reported) -> null: strict JSON
+    el = per["elapsed_s"]
+    slow = max(range(len(el)), key=lambda r: el[r])
+    return {"ranks": len(rows), "per_rank": per, "elapsed_min_s": min(el), "elapsed_max_s": max(el), "rank_of_max": slow,
+            "spread_pct": 100.0 * (max(el) - min(el)) / max(el) if max(el) > 0 else 0.0,
+            "exposed_allreduce_wait_ms_per_step_max": max([v for v in per["finish_wait_gpu_ms_per_step"] if v is not None] or [None]),
+            "handoff_status_or": _or_of(per["handoff_status"]),
+            "note": "per_rank lists are indexed by rank; elapsed_s = that rank's own wall time over the K timed steps (`ms_per_step` is the "
+                    "MAX); finish_wait_gpu = HIP-event time the compute stream spent between the end of backward and the moment clip + "
+                    "Adam could start (the exposed all-reduce, incl. the 16-byte status exchange); finish_wait_host = host time inside "
+                    "GradBuckets.finish(); handoff_status = the rank's sticky status word of the fused attention backward (0 = clean)"}
+
+
+def comm_environment():
+    """The communication-side settings a scaling post-mortem asks for first: RCCL version and every NCCL_* / RCCL_* / HSA_* / HIP_* /
+    GPU_* / ROCR_* variable of the process (channel counts are RCCL's to choose unless NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS pin
+    them; this records whether they were pinned)."""
+    env = {k: v for k, v in sorted(os.environ.items()) if k.split("_")[0] in ("NCCL", "RCCL", "HSA", "HIP", "GPU", "ROCR")}
+    ver = None
+    try:
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:          # a build without the binding: not fatal for a report field
+        pass
+    return {"rccl_version": ver, "env": env,
+            "channels": {"NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+                         "pinned": "NCCL_MIN_NCHANNELS" in os.environ or "NCCL_MAX_NCHANNELS" in os.environ}}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
     flags>` as a child process (one rank per GPU over RCCL; base_trainer.py:51-71 is the reference's counterpart)."""
@@ -327,9 +384,11 @@ def main():
     batch.grounding_noise = tuple(t.to(dev) for t in make_noise(B, F, P, seed=100 + block))
     scalar_reduces = [0]
     first_loss = []
+    finish_log = None          # a list inside the timed region: (event before, event after, host seconds) of every GradBuckets.finish()
     torch.manual_seed(args.seed)        # (model and batch above are name- / block-seeded; this governs the dropout seeds of the steps)
 
     def step(batch=batch):
+        nonlocal finish_log
         if args.forward_only:
             with torch.no_grad():
                 return model.forward(batch)
@@ -344,7 +403,17 @@ def main():
             first_loss.append(loss.detach())          # kept on the device; read after the timed region
         buckets.reset()
         loss.backward()
-        buckets.finish()
+        if dist_on and finish_log is not None:
+            # the exposed part of the gradient exchange: what the compute stream (events) and the host (wall clock) spend in finish()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            h0 = time.perf_counter()
+            buckets.finish()
+            h1 = time.perf_counter()
+            e1.record()
+            finish_log.append((e0, e1, h1 - h0))
+        else:
+            buckets.finish()
         clip_and_step(model, opt, cfg)          # global-norm clip 0.25 + Adam (one fused multi-tensor pass)
         sched.step()
         return loss
@@ -360,12 +429,18 @@ def main():
         sync()
         timer.enabled = True
         sr0 = scalar_reduces[0]
+        finish_log = []
         t0 = time.perf_counter()
         for _ in range(args.steps):
             last = step()
+        # this rank's OWN time for its K steps (its device drained), taken before the barrier that makes every rank wait for the
+        # slowest: the per-rank figures of `multi_gpu` - the contract's `elapsed` (barrier on both sides, MAX over ranks) follows
+        torch.cuda.synchronize()
+        own_elapsed = time.perf_counter() - t0
         sync()
         elapsed = time.perf_counter() - t0
         timer.enabled = False
+        timed_finish, finish_log = finish_log, None
         scalar_reduces_per_step = (scalar_reduces[0] - sr0) / max(1, args.steps)
     collectives_per_step = buckets.launched / max(1, args.steps + args.warmup)        # gradient all-reduces launched per step
     if dist_on:
@@ -539,6 +614,21 @@ def main():
         res["roofline"], res["roofline_fwd"] = bwd_block, fwd_block
     elif fwd_block is not None:
         res["roofline"] = fwd_block
+    if dist_on:
+        from vitxt_gqa_amd import ops as _ops
+        k = max(1, args.steps)
+        local = {"elapsed_s": own_elapsed,
+                 "finish_wait_gpu_ms_per_step": sum(a.elapsed_time(b) for a, b, _ in timed_finish) / k,
+                 "finish_wait_host_ms_per_step": 1e3 * sum(h for _, _, h in timed_finish) / k,
+                 "handoff_status": _ops.fused_handoff_status() if not args.forward_only else 0,
+                 "fused_launches": _ops.fused_launches_seen(dev) if not args.forward_only else 0,
+                 "attn_bwd_ms_per_step": (att_b["total_ms"] / k) if att_b else None,
+                 "attn_fwd_ms_per_step": (att_f["total_ms"] / k) if att_f else None,
+                 "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+        rep = gather_rank_report(local, device=dev if backend == "nccl" else None)
+        rep["comm"] = comm_environment()
+        rep["buckets_mb"] = [round(f.numel() * 4 / 2 ** 20, 1) for f, _ in buckets.buckets]
+        res["multi_gpu"] = rep
     if cpu_res is not None:
         res["cpu_baseline"] = cpu_res
     if pcie is not None:

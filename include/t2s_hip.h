@@ -315,9 +315,11 @@ int t2s_fasttext_rows(const float* table, int64_t table_rows, int dim, const int
  * t2s_adam_step (no clipping); write_grad != 0 writes the clipped gradients back (the reference clips p.grad in place). */
 int t2s_optim_chunk_elems(void);
 /* Sticky status of a train step: t2s_status_accumulate ORs uint32 word `word` of a launch's workspace (T2S_FUSED_STATUS_WORD of the
- * fused attention backward's) into sticky[0] and counts the launch in sticky[1] (sticky: 2+ uint32 of device memory the caller
- * keeps and zeroes); t2s_status_gate, enqueued between t2s_clip_coef and t2s_adam_step, makes the step a no-op when sticky[0] != 0:
- * norm_coef = (NaN, -1) and t2s_adam_step returns without touching parameters, moments or gradients. */
+ * fused attention backward's) into sticky[0], counts the launch in sticky[1] and sets sticky[2] / sticky[3] to 1 when bit 0 / bit 1 of
+ * the word is set (the bits as flags of their own: a MAX reduction of the four words over ranks then keeps every bit); sticky: 4
+ * uint32 of device memory the caller keeps and zeroes.  t2s_status_gate, enqueued between t2s_clip_coef and t2s_adam_step, makes the
+ * step a no-op when sticky[0] | sticky[2] | sticky[3] != 0: norm_coef = (NaN, -1) and t2s_adam_step returns without touching
+ * parameters, moments or gradients. */
 #define T2S_FUSED_STATUS_WORD 24
 int t2s_status_accumulate(const void* workspace, int word, void* sticky, t2s_stream_t stream);
 int t2s_status_gate(const void* sticky, float* norm_coef, t2s_stream_t stream);
@@ -336,7 +338,8 @@ int t2s_adam_step(const int64_t* desc, const int32_t* chunks, int n_chunks, cons
  * t2s_gemm_nt:  C[M, N] = A[M, K] W[N, K]^T, row strides lda / ldw / ldc (elements; multiples of 8), K a multiple of 128, N of 8.
  *   epilogue 0  C = bf16(acc + bias)                  (bias [N] bf16 or NULL)                       nn.Linear forward / dgrad
  *            1  C = bf16(C + bf16(acc))               (the residual branch a LayerNorm backward left in C)
- *            2  C = bf16(acc * gelu'(u[m, n])), colsum_part[2 * ceil(M / 256)][N] fp32 = column sums of C per 128-row group
+ *            2  C = bf16(acc * gelu'(u[m, n])), colsum_part[2 * ceil(M / 256)][N] fp32 = column sums per 128-row group of the
+ *               UNROUNDED fp32 products acc * gelu'(u) (not of the bf16 values stored in C); a non-finite u[m, n] makes its product NaN
  *               (u [M, N] bf16 row stride ldc = the FFN pre-activation; table = fp32 gelu'(x) of every bf16 bit pattern from
  *               t2s_gelu_tables): BertIntermediate's GELU backward + the FFN bias gradient folded into the dgrad of BertOutput.dense
  *            3  C = u = bf16(acc + bias) and g[m, n] = gelu(u) (table = bf16 gelu(x) of every bf16 bit pattern): BertIntermediate

@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 ROW_STRIDE = 29
+PEAKY_GAIN = 6.0
 
 
 def install_shims():
@@ -99,7 +100,34 @@ def build_reference(F_, P, V, text_vocab):
     return m
 
 
-def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs, gains=None, ocr_prev_frac=0.0):
+def _attention_stats(qk, valid, rows_per_sample=24, seed=0):
+    """Entropy (nats) and score range (nats) of softmax(q k^T / 8) over the VISIBLE keys, per captured layer, on a sample of query rows x
+    all 12 heads - the numbers that say how far the fixture's attention is from uniform.  qk: name -> (q [B, L, 768], k [B, L, 768])
+    as the reference's own query / key Linear modules produced them; valid: [B, L1] bool (key visibility of the prefix)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, (q, k) in qk.items():
+        B, L, _ = q.shape
+        ent, rng, top1 = [], [], []
+        for b in range(B):
+            vis = valid[b].nonzero().flatten()
+            rows = torch.randint(0, valid.shape[1], (rows_per_sample,), generator=g)
+            qh = q[b, rows].view(-1, 12, 64).transpose(0, 1).double()                  # [12, r, 64]
+            kh = k[b, vis].view(-1, 12, 64).transpose(0, 1).double()                   # [12, keys, 64]
+            s = qh @ kh.transpose(1, 2) / 8.0
+            p = torch.softmax(s, -1)
+            ent.append(-(p * torch.log(p.clamp_min(1e-300))).sum(-1).flatten())
+            rng.append((s.max(-1).values - s.min(-1).values).flatten())
+            top1.append(p.max(-1).values.flatten())
+        ent, rng, top1 = torch.cat(ent), torch.cat(rng), torch.cat(top1)
+        out[name] = dict(entropy_mean=float(ent.mean()), entropy_median=float(ent.median()), entropy_max=float(ent.max()),
+                         range_mean=float(rng.mean()), range_min=float(rng.min()), range_max=float(rng.max()),
+                         top1_prob_mean=float(top1.mean()), uniform_entropy=float(torch.log(valid.sum(1).double()).mean()))
+    return out
+
+
+def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs, gains=None, ocr_prev_frac=0.0, ocr_keep=0.7,
+             text_len=None, attn_stats=False, forward_only=False):
     from vitxt_gqa_amd.schema import state_dict_schema
     from vitxt_gqa_amd.init import make_state_dict, fingerprint
     from vitxt_gqa_amd.synth import make_batch
@@ -114,7 +142,8 @@ def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs, gains
     sd = make_state_dict(schema, seed=seed, attn_gain=attn_gain, gains=gains)
     m.load_state_dict(sd)
 
-    batch = make_batch(B, F_, P, V=V, seed=seed, text_vocab=text_vocab, ocr_prev_frac=ocr_prev_frac)
+    batch = make_batch(B, F_, P, V=V, seed=seed, text_vocab=text_vocab, ocr_prev_frac=ocr_prev_frac, ocr_keep=ocr_keep,
+                       text_len=text_len)
     sl = AD(batch)
     sl.dataset_name, sl.dataset_type = "vtextgqa", "train"
 
@@ -168,11 +197,39 @@ def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs, gains
     hooks.append(m.Grounding_Module.ocr_grounding_indicator.ocr_pos_att.register_forward_hook(h_ocr))
     hooks.append(m.mmt.register_forward_hook(h_mmt))
     hooks.append(m.mmt.prev_pred_embeddings.register_forward_hook(h_dec))
+    qk_cap = {}
+    if attn_stats:
+        def grab(tag, which):
+            def h(mod, i, o):
+                qk_cap.setdefault(tag, {}).setdefault(which, o.detach())          # first call only: the ref pass of the MMT
+            return h
+        for stack, mod in (("TransLayer", m.TransLayer), ("mmt", m.mmt)):
+            for li, layer in enumerate(mod.encoder.layer):
+                hooks.append(layer.attention.self.query.register_forward_hook(grab("%s.%d" % (stack, li), "q")))
+                hooks.append(layer.attention.self.key.register_forward_hook(grab("%s.%d" % (stack, li), "k")))
 
     # ---- train-mode forward + losses + backward + clip + Adam (base_trainer.py:251-278)
     m.train()
     torch.manual_seed(noise_seed)
-    out = m.forward(sl)
+    if forward_only:
+        with torch.no_grad():
+            out = m.forward(sl)
+    else:
+        out = m.forward(sl)
+    stats = None
+    if attn_stats:
+        L1 = 20 + F_ + F_ * P
+        valid = torch.cat([torch.arange(20)[None] < batch["text_len"][:, None], batch["frame_mask"].bool(), batch["ocr_mask"].bool()], 1)
+        stats = _attention_stats({k: (v["q"][:, :L1], v["k"][:, :L1]) for k, v in qk_cap.items()}, valid, seed=seed)
+        for k, v in stats.items():
+            print("attention", k, " ".join("%s %.3f" % kv for kv in v.items()), flush=True)
+        qk_cap.clear()
+    if forward_only:
+        for h in hooks:
+            h.remove()
+        t2s_mod.Grounding_Module.forward = orig_ground
+        t2s_mod.QTV.forward = orig_qtv
+        return stats
     bce = POSBCEWithMaskLoss()(sl, out)
     nce = InfoNCE()(sl, out)
     loss = 1.0 * bce + 1000.0 * nce
@@ -244,6 +301,7 @@ def run_case(name, B, F_, P, V, text_vocab, seed, attn_gain, store_inputs, gains
 
     meta = dict(name=name, B=B, F=F_, P=P, V=V, text_vocab=text_vocab, seed=seed, attn_gain=attn_gain,
                 gains=gains or {}, ocr_prev_frac=ocr_prev_frac, noise_seed=noise_seed, grad_names=gnames,
+                ocr_keep=ocr_keep, text_len=text_len, attention_stats=stats,
                 weight_fingerprint=fingerprint(sd, ["mmt.encoder.layer.0.attention.self.query.weight",
                                                     "classifier.module.weight", "ocr_ptr_net.key.bias",
                                                     "frame_embeddings.weight"]),
@@ -282,6 +340,21 @@ def main():
         # noise, losses, every gradient norm, ROW_STRIDE-thinned intermediates.
         run_case("full_b1_f100_p100", B=1, F_=100, P=100, V=5000, text_vocab=30522, seed=17, attn_gain=1.0,
                  store_inputs=False)
+        return
+    if "peaky-probe" in only:
+        # forward only: how peaky the reference's own attention is at a given gain (entropy / score range per layer)
+        for gain in [float(a) for a in sys.argv[1:] if a.replace(".", "").isdigit()] or [6.0]:
+            print("== attn_gain", gain, flush=True)
+            run_case("probe", B=1, F_=100, P=100, V=5000, text_vocab=30522, seed=23, attn_gain=gain, store_inputs=False,
+                     attn_stats=True, forward_only=True)
+        return
+    if "peaky" in only:
+        # the metric's length under PEAKY attention with two DIFFERENT samples: query / key weights scaled by attn_gain
+        # (scores scale with its square: sigma ~ 0.3 nats at the reference init, ~ 11 nats at gain 6), ocr_mask densities 0.7 and 0.3 and
+        # question lengths 20 and 7 -> ~7 100 and ~3 100 visible keys: the two samples' key lists (and the fused backward's hand-off chains)
+        # have different lengths in one launch.  The reference's own attention entropy / score range per layer go into the fixture's meta.
+        run_case("full_peaky_b2_f100_p100", B=2, F_=100, P=100, V=5000, text_vocab=30522, seed=23, attn_gain=PEAKY_GAIN,
+                 store_inputs=False, ocr_keep=[0.7, 0.3], text_len=[20, 7], attn_stats=True)
         return
     # tiny: P >= ocr_topk, F >= frame_topk (Appendix E); peaky attention (attn_gain) so that the
     # softmax is far from uniform and a wrong mask / wrong scale shows up

@@ -40,7 +40,7 @@ class Fixture:
         if "in:text" in self.arr:
             return {k[3:]: v for k, v in self.arr.items() if k.startswith("in:")}
         b = make_batch(m["B"], m["F"], m["P"], V=m["V"], seed=m["seed"], text_vocab=m["text_vocab"],
-                       ocr_prev_frac=m.get("ocr_prev_frac", 0.0))
+                       ocr_prev_frac=m.get("ocr_prev_frac", 0.0), ocr_keep=m.get("ocr_keep", 0.7), text_len=m.get("text_len"))
         for k, v in m["input_fingerprint"].items():
             assert abs(float(b[k].double().sum()) - v) <= 1e-6 * max(1.0, abs(v)), \
                 "synthetic input generator mismatch for %s" % k

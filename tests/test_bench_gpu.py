@@ -74,3 +74,13 @@ def test_bench_two_ranks_end_to_end_on_one_card():
     assert d["scalar_reduces_per_step"] == 1
     assert abs(d["value"] - 2 * 2 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]    # whole-job samples of the K steps / MAX time
     assert "cpu_baseline" not in d and d["loss"] == d["loss"]
+    # the fields that make a badly scaling first multi-GPU run diagnosable
+    m = d["multi_gpu"]
+    assert m["ranks"] == 2 and all(len(v) == 2 for v in m["per_rank"].values())
+    el = m["per_rank"]["elapsed_s"]
+    assert m["elapsed_max_s"] == max(el) and m["elapsed_min_s"] == min(el) and el[m["rank_of_max"]] == max(el)
+    assert max(el) <= d["ms_per_step"] * 2e-3 + 1e-6                                    # no rank's own time exceeds the MAX the line reports
+    assert all(w >= 0 for w in m["per_rank"]["finish_wait_gpu_ms_per_step"]) and m["exposed_allreduce_wait_ms_per_step_max"] >= 0
+    assert m["per_rank"]["handoff_status"] == [0.0, 0.0] and m["handoff_status_or"] == 0
+    assert all(v >= 0 for v in m["per_rank"]["fused_launches"]) and all(v > 0 for v in m["per_rank"]["attn_bwd_ms_per_step"])
+    assert len(m["buckets_mb"]) == d["n_buckets"] and "rccl_version" in m["comm"] and "channels" in m["comm"]

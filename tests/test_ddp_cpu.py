@@ -265,3 +265,48 @@ def test_world_size_8_sampler_buckets_and_logging_exchange():
     assert abs(ddp_mean - global_mean) < 0.05 * global_mean        # ... by a few per cent here (and by nothing for equal masks)
     print("pos_bce local-mean deviation at world 8, mask counts 48..20: ddp %.6f vs global %.6f (%.2f %%)"
           % (ddp_mean, global_mean, 100 * (ddp_mean / global_mean - 1)))
+
+
+def _report_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # rank 1 is the straggler: slower wall time, a longer exposed all-reduce wait, and a hand-off timeout in its status word
+    local = {"elapsed_s": 2.0 + 0.5 * rank, "finish_wait_gpu_ms_per_step": 1.25 + 3.0 * rank, "finish_wait_host_ms_per_step": 0.5,
+             "handoff_status": rank, "fused_launches": 22, "attn_bwd_ms_per_step": 240.0 + rank, "attn_fwd_ms_per_step": None,
+             "peak_mem_gb": 210.0}
+    rep = bench.gather_rank_report(local)
+    out[rank] = rep
+    dist.destroy_process_group()
+
+
+def test_bench_rank_report_gathers_every_rank_over_gloo():
+    """the N > 1 bench line must say WHY a run scaled badly - per-rank step times (min / max / rank of max), the exposed
+    wait in GradBuckets.finish(), the hand-off status per rank.  bench.gather_rank_report over a two-rank gloo group: every rank gets
+    the same report, lists indexed by rank, the slow rank named, the status words OR-ed."""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_report_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["per_rank"] == r1["per_rank"]
+    assert r0["ranks"] == 2 and r0["per_rank"]["elapsed_s"] == [2.0, 2.5]
+    assert r0["elapsed_min_s"] == 2.0 and r0["elapsed_max_s"] == 2.5 and r0["rank_of_max"] == 1
+    assert abs(r0["spread_pct"] - 20.0) < 1e-9
+    assert r0["per_rank"]["finish_wait_gpu_ms_per_step"] == [1.25, 4.25] and r0["exposed_allreduce_wait_ms_per_step_max"] == 4.25
+    assert r0["per_rank"]["handoff_status"] == [0.0, 1.0] and r0["handoff_status_or"] == 1
+    assert r0["per_rank"]["attn_bwd_ms_per_step"] == [240.0, 241.0]
+    assert r0["per_rank"]["attn_fwd_ms_per_step"] == [None, None]                                # a field a rank did not report: null
+    import json
+    json.loads(json.dumps(r0), parse_constant=lambda c: (_ for _ in ()).throw(ValueError("non-finite constant %s in the line" % c)))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    solo = bench.gather_rank_report({"elapsed_s": 1.0, "finish_wait_gpu_ms_per_step": 0.0, "handoff_status": 0})
+    assert solo["ranks"] == 1 and solo["rank_of_max"] == 0 and solo["handoff_status_or"] == 0   # no process group: the single rank
+    comm = bench.comm_environment()
+    assert set(comm) == {"rccl_version", "env", "channels"} and "pinned" in comm["channels"]

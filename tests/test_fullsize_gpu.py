@@ -233,45 +233,37 @@ def test_attn_bwd_fill_equals_zero_fill_path_full_length():
     assert (fa[..., :768].float() - fc[..., :768].float()).abs().max().item() < 1e-2 * sc
 
 
-@pytest.mark.parametrize("drop_p", [0.0, 0.1])
-def test_attention_bwd_fused_full_length_against_fp64_heads(drop_p):
-    """The fused five-product backward at the benchmark's length (L = 10 132: 27 key blocks of 384, 70 % of the prefix keys
-    visible, 12 decoder keys) against the fp64 gradient of whole heads: dQ of EVERY query over all keys, dK / dV of EVERY key over
-    all queries, for two (sample, head) pairs, both fill paths (rows outside the key list zeroed in the call / by the caller),
-    with and without attention dropout (the exported keep mask, indexed by key-LIST position, enters the fp64 restatement)."""
-    _need_gpu()
+def _heads_against_fp64(x, dout, keys, valid, b, heads, drop_p, drop_seed, out, lse, results, tol_out=3e-2, tol_lse=4e-2):
+    """fp64 restatement of WHOLE heads of sample ``b`` (every query over every visible key: [L, L] matrices) against the forward
+    (``out``, ``lse``) and each backward result in ``results``: dQ of every query, dK / dV of every key; the exported dropout keep
+    mask (indexed by key-LIST position) enters the restatement.  Returns the worst deviations seen."""
     from vitxt_gqa_amd import ops
-    B = 1
-    keys, valid = _keys_and_mask(B, [0.7], seed=11)
-    g = torch.Generator().manual_seed(12)
-    x = (torch.randn(B, L, 2304, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
-    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
-    kw = dict(drop_p=drop_p, drop_seed=991) if drop_p else {}
-    out, lse = ops.attn_fwd(x, keys, **kw)
-    cnt = int(keys.cnt[0])
+    B = x.shape[0]
+    cnt = int(keys.cnt[b])
     npos = cnt + D
-    rows_of_pos = keys.idx[0, :npos].long()
+    rows_of_pos = keys.idx[b, :npos].long()
     assert torch.equal(rows_of_pos[cnt:], torch.arange(L1, L, device=DEV))            # the decoder keys close the list
     vis = torch.zeros(L, L, dtype=torch.bool, device=DEV)
-    vis[:, :L1] = valid[0]
+    vis[:, :L1] = valid[b]
     r = torch.arange(L, device=DEV)
     vis[:, L1:] = (r.view(-1, 1) - L1) >= torch.arange(D, device=DEV).view(1, -1)
     p_eff = round(65536 * drop_p) / 65536
-    keep_all = ops.attn_dropout_mask(B, L, npos, drop_p, kw["drop_seed"], DEV) if drop_p else None     # [1, 12, L, npos]
-    results = []
-    for kl in (keys, ops.KeyList(keys.idx, keys.cnt, keys.n_dec, keys.dec_q0, None, None)):
-        results.append(ops.attn_bwd(x, out, dout, lse, kl, fused=True, **kw))
-        assert ops.LAST_ATTN_BWD_PRODUCTS == 5
-    for h in (3, 10):
-        q, k, v = [x[0, :, c * 768 + h * 64:c * 768 + (h + 1) * 64].double() for c in range(3)]     # [L, 64]
-        do = dout[0, :, h * 64:(h + 1) * 64].double()
+    keep_all = ops.attn_dropout_mask(B, L, npos, drop_p, drop_seed, DEV)[b] if drop_p else None     # [12, L, npos]
+    worst = dict(out=0.0, lse=0.0, dQ=0.0, dK=0.0, dV=0.0, entropy=0.0, score_range=0.0)
+    for h in heads:
+        q, k, v = [x[b, :, c * 768 + h * 64:c * 768 + (h + 1) * 64].double() for c in range(3)]     # [L, 64]
+        do = dout[b, :, h * 64:(h + 1) * 64].double()
         sc = (q @ k.t()) * 0.125
+        worst["score_range"] = max(worst["score_range"], (sc.masked_fill(~vis, float("-inf")).max(-1).values
+                                                           - sc.masked_fill(~vis, float("inf")).min(-1).values).max().item())
         sc.masked_fill_(~vis, float("-inf"))
+        rlse = torch.logsumexp(sc, -1)
         pr = torch.softmax(sc, -1)
         del sc
+        worst["entropy"] = max(worst["entropy"], -(pr * torch.log(pr.clamp_min(1e-300))).sum(-1).mean().item())      # (mean entropy of the head, nats)
         if keep_all is not None:
             m = torch.zeros(L, L, dtype=torch.float64, device=DEV)
-            m[:, rows_of_pos] = keep_all[0, h].double() / (1.0 - p_eff)
+            m[:, rows_of_pos] = keep_all[h].double() / (1.0 - p_eff)
         else:
             m = None
         a = pr * m if m is not None else pr
@@ -287,16 +279,100 @@ def test_attention_bwd_fused_full_length_against_fp64_heads(drop_p):
         dk = (ds.t() @ q) * 0.125
         del ds, pr, m
         # the forward the kernel's delta comes from is this head too
-        assert (out[0, :, h * 64:(h + 1) * 64].double() - o).abs().max().item() < 3e-2
+        e_out = (out[b, :, h * 64:(h + 1) * 64].double() - o).abs().max().item()
+        e_lse = (lse[b, h].double() - rlse).abs().max().item()
+        assert e_out < tol_out * max(1.0, o.abs().max().item()), "sample %d head %d: forward output max err %.3e" % (b, h, e_out)
+        assert e_lse < tol_lse, "sample %d head %d: LSE max err %.3e" % (b, h, e_lse)
+        worst["out"], worst["lse"] = max(worst["out"], e_out), max(worst["lse"], e_lse)
         for got in results:
-            gq, gk, gv = [got[0, :, c * 768 + h * 64:c * 768 + (h + 1) * 64].double() for c in range(3)]
+            gq, gk, gv = [got[b, :, c * 768 + h * 64:c * 768 + (h + 1) * 64].double() for c in range(3)]
             for name, gg, rr in (("dQ", gq, dq), ("dK", gk, dk), ("dV", gv, dv)):
                 err = (gg - rr).abs().max().item()
                 rel = (gg - rr).norm().item() / rr.norm().item()
+                worst[name] = max(worst[name], rel)
                 assert err < 3e-2 * max(1.0, rr.abs().max().item()) and rel < 2e-2, \
-                    "head %d %s (dropout %g): max err %.3e at scale %.3e, relative L2 %.3e" % (h, name, drop_p, err, rr.abs().max().item(), rel)
-            inv = ~valid[0]
+                    "sample %d head %d %s (dropout %g): max err %.3e at scale %.3e, relative L2 %.3e" % (b, h, name, drop_p, err, rr.abs().max().item(), rel)
+            inv = ~valid[b]
             assert gk[:L1][inv].abs().max().item() == 0 and gv[:L1][inv].abs().max().item() == 0
+    return worst
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_attention_bwd_fused_full_length_against_fp64_heads(drop_p):
+    """The fused five-product backward at the benchmark's length (L = 10 132: 27 key blocks of 384, 70 % of the prefix keys
+    visible, 12 decoder keys) against the fp64 gradient of whole heads: dQ of EVERY query over all keys, dK / dV of EVERY key over
+    all queries, for two (sample, head) pairs, both fill paths (rows outside the key list zeroed in the call / by the caller),
+    with and without attention dropout (the exported keep mask, indexed by key-LIST position, enters the fp64 restatement)."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    B = 1
+    keys, valid = _keys_and_mask(B, [0.7], seed=11)
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    kw = dict(drop_p=drop_p, drop_seed=991) if drop_p else {}
+    out, lse = ops.attn_fwd(x, keys, **kw)
+    results = []
+    for kl in (keys, ops.KeyList(keys.idx, keys.cnt, keys.n_dec, keys.dec_q0, None, None)):
+        results.append(ops.attn_bwd(x, out, dout, lse, kl, fused=True, **kw))
+        assert ops.LAST_ATTN_BWD_PRODUCTS == 5
+    _heads_against_fp64(x, dout, keys, valid, 0, (3, 10), drop_p, 991, out, lse, results)
+
+
+@pytest.mark.parametrize("sigma", [1.5, 2.5])
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_heads(drop_p, sigma):
+    """VERDICT r5 #1, the kernel-level twin of the peaky reference fixture: forward AND fused backward at L = 10 132 where the design is
+    hard.  (i) PEAKY scores: Q and K rows ~ N(0, sigma^2) -> score sigma 2.25 nats (sigma 1.5; ranges ~20 nats) / 6.25 nats (sigma 2.5;
+    ranges ~55 nats, mean entropy ~2 nats against ln 7 100 = 8.9).  (ii) TWO DIFFERENT samples in one launch: 70 % and 30 % of the prefix
+    keys visible -> hand-off chains of 19 and 8 key blocks side by side.  (iii) the forward's steady state has NO running maximum (m
+    is fixed by key tile 0): for eight query rows per sample (first / middle / last workgroups, a decoder row) a key LATE in the list
+    is planted whose score lies > 128 log2-units above everything tile 0 holds - exp2 of that overflows fp32, so the steady state
+    CANNOT represent it: the row sum is inf, the wave poisons its rows (LSE = NaN) and only the REPAIR launch can produce the finite,
+    correct rows asserted here (and the rows of the other waves of those workgroups, which the repair recomputes too).  Everything
+    against the fp64 restatement of whole heads: out, LSE, dQ of every query, dK / dV of every key."""
+    _need_gpu()
+    from vitxt_gqa_amd import ops
+    ops.reset_fused_status()
+    B = 2
+    keys, valid = _keys_and_mask(B, [0.7, 0.3], seed=21)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(B, L, 2304, generator=g)
+    x[..., :1536] *= sigma
+    x[..., 1536:] *= 0.7
+    planted = [5, 130, 260, 2600, 5003, 9990, L1 - 1, L1 + 7]
+    gaps = []
+    for b in range(B):
+        cnt = int(keys.cnt[b])
+        assert cnt // 64 > 4
+        for i, r in enumerate(planted):
+            pos = cnt - 200 - 70 * i                                    # a late list position, in a steady-state tile of its own
+            krow = int(keys.idx[b, pos])
+            q = x[b, r, :768].view(12, 64)
+            alpha = 100.0 * 8.0 / q.pow(2).sum(-1, keepdim=True)        # q.k / 8 = +100 nats = 144 log2-units, per head
+            x[b, krow, 768:1536] = (q * alpha).reshape(768)
+    x = x.to(DEV).to(torch.bfloat16)
+    for b in range(B):                                                  # the premise, checked on the rounded operands: gap to tile 0 > 128 log2-units
+        t0 = keys.idx[b, :64].long()
+        for r in planted:
+            q = x[b, r, :768].double().view(12, 64)
+            s_all = torch.einsum("hd,khd->hk", q, x[b, keys.idx[b, :int(keys.cnt[b])].long(), 768:1536].double().view(-1, 12, 64)) * 0.125
+            s_t0 = torch.einsum("hd,khd->hk", q, x[b, t0, 768:1536].double().view(-1, 12, 64)) * 0.125
+            gaps.append(((s_all.max(-1).values - s_t0.max(-1).values) * 1.4426950408889634).min().item())
+    assert min(gaps) > 128, "planted keys must overflow the steady state (2^128 > fp32 max): smallest gap %.1f log2-units" % min(gaps)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    kw = dict(drop_p=drop_p, drop_seed=1777) if drop_p else {}
+    out, lse = ops.attn_fwd(x, keys, **kw)
+    assert torch.isfinite(lse).all() and torch.isfinite(out.float()).all(), "a poisoned row survived: the repair launch did not run"
+    res = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw)
+    assert ops.LAST_ATTN_BWD_PRODUCTS == 5 and ops.fused_handoff_status() == 0
+    again = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw)
+    assert torch.equal(res, again)                                      # unequal chains side by side: still bit-reproducible
+    for b in range(B):
+        w = _heads_against_fp64(x, dout, keys, valid, b, (2, 9), drop_p, 1777, out, lse, [res])
+        print("peaky twin sigma %.1f dropout %.1f sample %d (%d keys): mean entropy %.2f nats, widest score range %.0f nats | max err out %.2e lse %.2e | "
+              "relative L2 dQ %.2e dK %.2e dV %.2e | smallest planted gap %.0f log2-units" % (
+                  sigma, drop_p, b, int(keys.cnt[b]) + D, w["entropy"], w["score_range"], w["out"], w["lse"], w["dQ"], w["dK"], w["dV"], min(gaps)))
 
 
 # ------------------------------------------------------------------------------------------------------------------

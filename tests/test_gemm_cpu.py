@@ -57,3 +57,23 @@ def test_nt_workgroup_map_covers_every_tile_once_and_groups_the_weight_panels():
         first = [G.nt_item(8 * j + x, tiles_m, tiles_n, b) for j in range(32)]      # the first 32 workgroups of XCD x
         assert len({t[1] for t in first}) == 4 and len({t[0] for t in first}) == 8
         assert len({G.nt_item(8 * j + x, tiles_m, tiles_n, b)[0] // ((tiles_m + 7) // 8) for j in range(0, 3000, 97)}) == 1      # one M range per XCD
+
+
+def test_wgrad_supported_mirrors_the_span_limits_of_the_c_side():
+    """`functional._wgrad` sends a shape to t2s_gemm_wgrad only when `wgrad_supported` says so, so the Python rule must hold
+    the same limits as the C side (csrc/gemm_bf16.hip t2s_gemm_wgrad): <= 4096 splits and a row split (padded to 128 rows + one 64-row
+    K-tile of read-ahead) spanning < 2 GB of either operand.  With the automatic split count (one round on 256 CUs: 7 for the FFN
+    weights) ~2.4 M rows at ld = 3072 cross it: the call must be refused HERE (library fallback), not raise inside the C call."""
+    assert G.wgrad_supported(649_984, 768, 3072)                   # the step's FFN shapes (B = 64)
+    assert G.wgrad_supported(649_984, 3072, 768)
+    assert G.wgrad_supported(649_984, 2304, 768) and G.wgrad_supported(649_984, 768, 768)
+    assert not G.wgrad_supported(512, 768, 768)                    # short contraction: library
+    assert not G.wgrad_supported(649_984, 768, 1000)               # not a multiple of 256
+    auto = 7
+    ok_rows = ((1 << 31) // (3072 * 2) - 64) // 128 * 128 * auto - 128
+    assert G.wgrad_supported(ok_rows, 768, 3072, splits=auto)
+    assert not G.wgrad_supported(3_000_000, 768, 3072, splits=auto)        # 428 672-row splits x 6 KB rows = 2.6 GB: refused
+    assert G.wgrad_supported(3_000_000, 768, 3072, splits=16)              # ... unless the caller asks for more splits
+    assert not G.wgrad_supported(3_000_000, 768, 3072, splits=5000)        # > 4096 splits
+    assert not G.wgrad_supported(649_984, 768, 768, ld_dy=1 << 24)         # a wide row stride counts, not the row width
+    assert G.nt_supported(649_984, 3072, 768) and not G.nt_supported(649_984, 3072, 768, lda=1 << 22)

@@ -142,3 +142,57 @@ def test_rows_behind_the_last_sample_are_never_staged(drop_p):
     two = ops.attn_bwd(x, out, dout, lse, keys, fused=False, **kw)
     scale = two.float().abs().max().item()
     assert (got.float() - two.float()).abs().max().item() < 3e-2 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("neighbour", ["gemm", "stream_copy", "both"])
+def test_handoff_chain_under_a_cu_hungry_neighbour_stream(neighbour):
+    """in data-parallel training an RCCL all-reduce of a gradient bucket runs on its own stream UNDER the fused attention
+    backward (two 48 MB buckets are launched with ~146 ms of backward still to run).  The hand-off spin-waits between
+    workgroups, and a collective kernel that takes CUs mid-launch changes which workgroups are resident while others spin - the one
+    situation the single-stream tests never create.  Stand-in on one card: a second stream keeps the CUs busy with library GEMMs
+    (every CU, in rounds) and / or 1 GB element-wise passes (HBM + L2 pressure on the XCD-local running sums) for the WHOLE duration of
+    three fused backward launches at L = 10 132 with two unequal hand-off chains.  Asserted: the two streams really overlapped
+    (events), the status word stays 0 (no bounded spin timed out, no XCD-group misplacement), and dQ / dK / dV are BIT-IDENTICAL to the
+    solo launch - the ticket order guarantees a waiting block's predecessor has started whatever else occupies the card."""
+    from vitxt_gqa_amd import ops
+    ops.reset_fused_status()
+    B, L1, n_dec = 4, 10120, 12
+    L = L1 + n_dec
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(B, L, 2304, generator=g) * 0.7).to(DEV).to(torch.bfloat16)
+    dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
+    keep = torch.tensor([0.7, 0.3, 0.9, 0.5]).view(B, 1)              # chains of 19, 8, 24 and 14 key blocks in one launch
+    valid = (torch.rand(B, L1, generator=g) < keep).to(DEV)
+    valid[:, 0] = True
+    keys = ops.compact_keys(valid, n_dec=n_dec, dec_row0=L1)
+    kw = dict(drop_p=0.1, drop_seed=4242)
+    out, lse = ops.attn_fwd(x, keys, **kw)
+    solo = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw)
+    torch.cuda.synchronize()
+    assert ops.fused_handoff_status() == 0
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    big = torch.zeros(1 << 28, device=DEV, dtype=torch.float32)        # 1 GB
+    base, s0, s1, m0, m1 = (torch.cuda.Event(enable_timing=True) for _ in range(5))
+    base.record()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        s0.record()
+        for i in range(120):                                           # ~150 - 250 ms of neighbour work, enqueued before the backward
+            if neighbour in ("gemm", "both"):
+                torch.mm(a, b)
+            if neighbour in ("stream_copy", "both"):
+                big.add_(1.0)
+        s1.record()
+    m0.record()
+    got = [ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw) for _ in range(3)]
+    m1.record()
+    torch.cuda.synchronize()
+    t = {k: base.elapsed_time(e) for k, e in (("s0", s0), ("s1", s1), ("m0", m0), ("m1", m1))}
+    overlap = min(t["s1"], t["m1"]) - max(t["s0"], t["m0"])
+    print("neighbour %s: side stream %.1f..%.1f ms, fused backward x3 %.1f..%.1f ms, overlap %.1f ms" % (neighbour, t["s0"], t["s1"], t["m0"], t["m1"], overlap))
+    assert overlap > 0.5 * (t["m1"] - t["m0"]), "the neighbour stream did not run under the backward launches: the rehearsal rehearsed nothing"
+    assert ops.fused_handoff_status() == 0, "a hand-off wait timed out or a group was misplaced under the neighbour stream"
+    for r in got:
+        assert torch.equal(r, solo), "the hand-off's summation order (hence dQ) must not depend on what else runs on the card"

@@ -215,3 +215,26 @@ def test_handoff_scope_switch_keeps_the_launch_policy():
     out = subprocess.run([sys.executable, "-c", "from vitxt_gqa_amd import ops; print(ops.ATTN_BWD_DQ_MODE)"], env=env, cwd=ROOT,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.split()[-1] == "0", (out.stdout, out.stderr)
+
+
+def test_status_words_decode_as_an_or_over_devices_and_survive_a_max_over_ranks():
+    """(i) `fused_handoff_status(None)` ORs the per-device words (a sum turned two timeouts into "placement"); (ii) the MAX
+    reduction of `GradBuckets.finish()` over ranks keeps BOTH bits when one rank timed out (1) and another saw a placement violation (2):
+    the bits travel as 0 / 1 flags in words 2 and 3."""
+    import torch
+    from vitxt_gqa_amd import ops
+    assert ops.decode_status_words([0, 5, 0, 0]) == 0
+    assert ops.decode_status_words([1, 5, 1, 0]) == 1 and ops.decode_status_words([2, 5, 0, 1]) == 2
+    rank_a, rank_b = torch.tensor([1, 11, 1, 0]), torch.tensor([2, 11, 0, 1])
+    assert ops.decode_status_words(torch.maximum(rank_a, rank_b).tolist()) == 3          # MAX of the words alone would say 2
+    saved = dict(ops._STICKY)
+    try:
+        ops._STICKY.clear()
+        ops._STICKY[0] = torch.tensor([1, 3, 1, 0], dtype=torch.int32)
+        ops._STICKY[1] = torch.tensor([1, 3, 1, 0], dtype=torch.int32)
+        assert ops.fused_handoff_status() == 1                                            # two timeouts stay a timeout
+        ops._STICKY[1] = torch.tensor([2, 3, 0, 1], dtype=torch.int32)
+        assert ops.fused_handoff_status() == 3
+    finally:
+        ops._STICKY.clear()
+        ops._STICKY.update(saved)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5: ONE parametrised GPU-call script (replaces the per-call r4_run_*.sh files).
-#   gpurun --timeout 1200 -- 'bash tools/r5_run.sh <tag> <step> [<step> ...]'
+# ONE parametrised GPU-call script (round 5: replaced the per-call r4_run_*.sh files; round 6: renamed from r5_run.sh, steps added).
+#   gpurun --timeout 1200 -- 'bash tools/run_gpu.sh <tag> <step> [<step> ...]'
 # steps: fulllen (reference-pinned tests at L = 10 132), suite (whole -m gpu suite), bench (bench line), benchq (bench without cpu baseline),
 #        gemm (own GEMM tests + probe), attn (attention tests + probe), smoke
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -12,6 +12,15 @@ cd $REPO
 for STEP in "$@"; do
   echo "=== step $STEP" | tee -a $OUT/steps.log
   case $STEP in
+    peaky)   # round 6: both reference-pinned full-length fixtures (flat + peaky / unequal samples), every test, no -x: the maxima are the result
+             timeout -k 10 900 python3 -m pytest tests/test_fulllength_reference_gpu.py -m gpu -q -s > $OUT/pytest_fulllen.log 2>&1 || true
+             grep -E "passed|failed|vs the reference|max abs logit|argmax indices|worst comparable|FAILED|Error" $OUT/pytest_fulllen.log | cut -c1-260
+             timeout -k 10 900 python3 -m pytest tests/test_fullsize_gpu.py -m gpu -q -s -k "fp64_heads" > $OUT/pytest_twins.log 2>&1 || true
+             grep -E "passed|failed|peaky twin|FAILED|Error|assert" $OUT/pytest_twins.log | cut -c1-300 ;;
+    budget)  timeout -k 10 900 python3 tools/error_budget.py ${BUDGET_CASES} > $OUT/error_budget.txt 2>&1 || { tail -30 $OUT/error_budget.txt; exit 1; }; cut -c1-220 $OUT/error_budget.txt ;;
+    diag)    # round 6: the multi-GPU diagnosability fields (two gloo ranks on one card) and the neighbour-stream rehearsal of the hand-off
+             timeout -k 10 900 python3 -m pytest tests/test_bench_gpu.py tests/test_handoff_guard_gpu.py tests/test_ddp_gpu.py -m gpu -q -s > $OUT/pytest_diag.log 2>&1 || { grep -E "passed|failed|FAILED|Error|assert" $OUT/pytest_diag.log | cut -c1-300; tail -40 $OUT/pytest_diag.log; exit 1; }
+             grep -E "passed|failed|neighbour" $OUT/pytest_diag.log | cut -c1-250 ;;
     fulllen) timeout -k 10 900 python3 -m pytest tests/test_fulllength_reference_gpu.py -m gpu -x -q -s > $OUT/pytest_fulllen.log 2>&1 || { tail -60 $OUT/pytest_fulllen.log; exit 1; }; tail -30 $OUT/pytest_fulllen.log ;;
     suite)   timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_suite.log 2>&1 || { tail -60 $OUT/pytest_suite.log; exit 1; }; tail -3 $OUT/pytest_suite.log ;;
     smoke)   timeout -k 10 300 python3 __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || { tail -30 $OUT/smoke.log; exit 1; }; tail -1 $OUT/smoke.log ;;

@@ -501,12 +501,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
         {
           // table offsets of two values per packed 16-bit instruction (saturating subtract, min, shift, mad); the derivative is constant
           // outside the table's range (0.5 below 2^-24, 0 or 1 from 16 up), so the clamped offset is exact everywhere
+          // A non-finite pre-activation (magnitude bits >= 0x7f80) must poison its gradient as the standalone gelu_bwd pass does
+          // (erff / expf of NaN; inf * exp(-inf)): the lane tracks its largest magnitude (one packed max per pair) and redoes such
+          // values behind a branch the wave skips - a diverged forward stays visible in du and in the bias-gradient column sums.
           typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
           const char* const tb = reinterpret_cast<const char*>(ltab);
+          u16x2 worst = {0, 0};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const u16x2 b2 = {uv[i][2 * k], uv[i][2 * k + 1]};      // (from the elements: see the dual epilogue)
-            const u16x2 d2 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(b2 & (unsigned short)0x7fff, (u16x2)(unsigned short)G_TAB_LO),
+            const u16x2 mag2 = b2 & (unsigned short)0x7fff;
+            worst = __builtin_elementwise_max(worst, mag2);
+            const u16x2 d2 = __builtin_elementwise_min(__builtin_elementwise_sub_sat(mag2, (u16x2)(unsigned short)G_TAB_LO),
                                                        (u16x2)(unsigned short)(G_TAB_RANGE - 1));
             const u16x2 off2 = ((b2 >> (unsigned short)15) * (unsigned short)G_TAB_RANGE + d2) << (unsigned short)2;       // byte offsets: < 4 * 7168
             const uint32_t ow = __builtin_bit_cast(uint32_t, off2);
@@ -514,6 +520,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
             const float t1 = *reinterpret_cast<const float*>(tb + (ow >> 16));
             d[2 * k] = (k < 2 ? v0[(2 * k) & 3] : v1[(2 * k) & 3]) * t0;
             d[2 * k + 1] = (k < 2 ? v0[(2 * k + 1) & 3] : v1[(2 * k + 1) & 3]) * t1;
+          }
+          if (__builtin_expect(worst[0] >= 0x7f80 || worst[1] >= 0x7f80, 0)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if ((uv[i][j] & 0x7fffu) >= 0x7f80u) d[j] = __builtin_nanf("");
           }
         }
         if (m < p.M && cols_ok) {
@@ -631,14 +642,19 @@ __global__ __launch_bounds__(256) void gelu_tables_kernel(bf16_t* __restrict__ f
   if (grad) grad[i] = g_gelu_grad(x);
 }
 
+// > 64 KB of dynamic LDS needs the opt-in, and the attribute is PER DEVICE: one flag per (kernel form, device ordinal) - the pattern of
+// launch_attn_bwd_fused_bf16 - so that a process driving a second GPU opts in there too (an ordinal outside the table: set it every call)
+struct LdsFlags { bool done[64]; };
 template <typename K>
-int g_reserve_lds(K kernel, bool& done, const char* what, int bytes = G_SMEM) {
-  if (done) return 0;
+int g_reserve_lds(K kernel, LdsFlags& f, const char* what, int bytes = G_SMEM) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev >= 0 && f.done[dev]) return 0;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
     t2s_set_error("%s: cannot reserve %d bytes of LDS per workgroup", what, bytes);
     return 3;
   }
-  done = true;
+  if (dev >= 0) f.done[dev] = true;
   return 0;
 }
 
@@ -679,7 +695,7 @@ extern "C" int t2s_gemm_nt(const void* a, const void* w, const void* bias, void*
   }
   const int64_t grid = (int64_t)G_XCDS * ((p.tiles_m + G_XCDS - 1) / G_XCDS) * p.tiles_n;
   T2S_CHECK_ARG(grid < ((int64_t)1 << 31), "gemm_nt: too many tiles");
-  static bool done[4] = {false, false, false, false};
+  static LdsFlags done[4] = {};
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
   switch (epilogue) {
@@ -753,7 +769,7 @@ extern "C" int t2s_gemm_wgrad(const void* dy, const void* x, float* dw, float* s
   T2S_CHECK_ARG(T <= c ? (G_XCDS * (c / T) >= splits || (int64_t)G_XCDS * (c - (c / T) * T) >= (int64_t)(splits - G_XCDS * (c / T)) * T)
                        : (splits <= G_XCDS && (int64_t)(G_XCDS - splits) * c >= (int64_t)splits * (T - c)),
                 "gemm_wgrad: %d tiles x %d splits do not fit the workgroup map (use t2s_gemm_wgrad_splits)", T, splits);
-  static bool done = false;
+  static LdsFlags done = {};
   int rc = 0;
   if ((rc = g_reserve_lds(gemm_tn_bf16_kernel, done, "gemm_wgrad"))) return rc;
   hipStream_t st = (hipStream_t)stream;

@@ -73,9 +73,13 @@ __global__ void status_accumulate_kernel(const unsigned* __restrict__ word, unsi
   const unsigned v = *word;
   if (v) atomicOr(sticky, v);
   atomicAdd(sticky + 1, 1u);          // launches seen
+  // the two status bits once more as 0 / 1 FLAGS of their own (words 2, 3): a MAX reduction over ranks - the one collective
+  // GradBuckets.finish() spends on the word - is an OR for flags, while the MAX of two OR-ed words (1 on one rank, 2 on another) loses a bit
+  if (v & 1u) atomicOr(sticky + 2, 1u);
+  if (v & 2u) atomicOr(sticky + 3, 1u);
 }
 __global__ void status_gate_kernel(const unsigned* __restrict__ sticky, float* __restrict__ norm_coef) {
-  if (sticky[0] != 0u) {
+  if ((sticky[0] | sticky[2] | sticky[3]) != 0u) {
     norm_coef[0] = __builtin_nanf("");
     norm_coef[1] = -1.f;
   }

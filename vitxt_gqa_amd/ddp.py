@@ -174,9 +174,9 @@ class GradBuckets:
                                "produced no gradient this iteration (candidates: %s)" % (len(missing), len(self.buckets),
                                                                                          sum(self._pending), ", ".join(names[:8])))
         # a hand-off wait that timed out on ONE rank puts NaN rows into the summed gradients of EVERY rank: the sticky status word
-        # (ops.fused_status_tensor) is exchanged too (MAX), so that every rank's optimizer gates the step off and raises (MAX, not OR:
-        # word 1 counts launches; a timeout on one rank and a placement violation on another then show as the larger of the two words -
-        # either way non-zero, i.e. gated and loud, on every rank)
+        # (ops.fused_status_tensor) is exchanged too (MAX), so that every rank's optimizer gates the step off and raises.  MAX because
+        # word 1 counts launches; the two status bits travel as 0 / 1 flags of their own (words 2, 3: MAX = OR for flags), so a timeout on
+        # one rank and a placement violation on another both arrive everywhere (ops.decode_status_words)
         flat0 = self.buckets[0][0] if self.buckets else None
         if self.collective and flat0 is not None and flat0.is_cuda and self.world > 1:
             from . import ops

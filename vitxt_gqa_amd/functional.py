@@ -58,7 +58,7 @@ def _wgrad(dy2, x2, B):
     sample (contraction L) followed by an fp32 sum over the B partial products it runs at 0.8-1.1 PFLOP/s
     (tools/wgrad_probe.py), and the partials are summed in fp32 instead of inside a bf16-output GEMM.  Returns fp32."""
     rows = dy2.size(0)
-    if _own("wgrad", dy2, x2) and own.wgrad_supported(rows, dy2.size(1), x2.size(1)):
+    if _own("wgrad", dy2, x2) and own.wgrad_supported(rows, dy2.size(1), x2.size(1), dy2.stride(0), x2.stride(0)):
         return own.gemm_wgrad(dy2, x2)
     if B < 2 or rows // B < 1024 or dy2.dtype == F32:
         return (dy2.t() @ x2).float()

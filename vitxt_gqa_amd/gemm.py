@@ -29,8 +29,12 @@ def _rows(t):
     return t.stride(0)
 
 
-def nt_supported(M, N, K):
-    return K % 128 == 0 and N % 8 == 0 and M > 0
+def nt_supported(M, N, K, lda=None, ldw=None):
+    """The shape rules of t2s_gemm_nt (csrc/gemm_bf16.hip): K a multiple of 128, N of 8, M < 2^31, and 256 operand rows spanning
+    < 2^31 bytes (lda, ldw * 512 < 2^31)."""
+    lda = K if lda is None else lda
+    ldw = K if ldw is None else ldw
+    return K % 128 == 0 and N % 8 == 0 and 0 < M < 1 << 31 and lda * 512 < 1 << 31 and ldw * 512 < 1 << 31
 
 
 def gemm_nt(a, w, bias=None, out=None, accumulate=False):
@@ -72,18 +76,31 @@ def gemm_nt_gelu_dual(a, w, bias):
     return u, g
 
 
-def wgrad_supported(rows, n_out, n_in):
-    return n_out % 256 == 0 and n_in % 256 == 0 and rows >= 1024
+def wgrad_supported(rows, n_out, n_in, ld_dy=None, ld_x=None, splits=None):
+    """Whether t2s_gemm_wgrad takes the shape: the tile rule AND the limits its host side checks (csrc/gemm_bf16.hip t2s_gemm_wgrad:
+    rows < 2^31, at most 4096 row splits, and a row split - padded to 128 rows, + one 64-row K-tile of read-ahead - spanning < 2 GB of
+    each operand, whose offsets are 32-bit).  ``splits`` None = the automatic count (one round of workgroups on the card); a shape that
+    fails here goes to the library's batched GEMM (functional._wgrad) instead of raising inside the call."""
+    if n_out % 256 or n_in % 256 or rows < 1024 or rows >= 1 << 31:
+        return False
+    if splits is None:
+        splits = int(X.lib().t2s_gemm_wgrad_splits(rows, n_out, n_in))
+    if not 1 <= splits <= 4096:
+        return False
+    chunk = -(-rows // splits)
+    chunk = -(-chunk // 128) * 128
+    ld_dy = n_out if ld_dy is None else ld_dy
+    ld_x = n_in if ld_x is None else ld_x
+    return (chunk + 64) * ld_dy * 2 < 1 << 31 and (chunk + 64) * ld_x * 2 < 1 << 31
 
 
 def gemm_wgrad(dy, x, out=None, accumulate=False, splits=None):
     """dW [n_out, n_in] fp32 = dy[rows, n_out]^T @ x[rows, n_in] (bf16 operands): deterministic split-K over row groups."""
     rows, n_out = dy.shape
     n_in = x.shape[1]
-    assert x.shape[0] == rows and wgrad_supported(rows, n_out, n_in)
     if splits is None:
         splits = X.lib().t2s_gemm_wgrad_splits(rows, n_out, n_in)
-    assert splits >= 1
+    assert x.shape[0] == rows and wgrad_supported(rows, n_out, n_in, _rows(dy), _rows(x), splits)
     if out is None:
         assert not accumulate
         out = torch.empty(n_out, n_in, dtype=torch.float32, device=dy.device)

@@ -135,7 +135,7 @@ if ATTN_BWD_DQ_MODE == 1 and os.environ.get("T2S_FB_HANDOFF_SCOPE", "xcd") == "a
 _KEEP_DQ32 = os.environ.get("T2S_KEEP_DQ32", "0") == "1"     # tools/fused_stamps.py: keep the workspace, whose tail holds the diagnostic
 _LAST_DQ32 = None                                             # build's cycle stamps (otherwise it is freed with the call: 2 GB at B=64)
 FUSED_CTRL_STATUS_WORD = 24                                   # include/t2s_hip.h: uint32 word of the workspace, bit 0 = a hand-off spin timed out, bit 1 = an XCD group ran on two XCDs
-_STICKY = {}                                                  # device index -> int32 [4]: (OR of every fused launch's status word, launches seen, -, -)
+_STICKY = {}                                                  # device index -> int32 [4]: (OR of every fused launch's status word, launches seen, bit 0 as a 0/1 flag, bit 1 as a 0/1 flag)
 
 
 class HandoffError(RuntimeError):
@@ -171,8 +171,18 @@ def fused_handoff_status(device=None):
     if not _STICKY:
         return 0
     if device is None:
-        return int(sum(int(t[0].item()) for t in _STICKY.values()))
-    return int(fused_status_tensor(device)[0].item())
+        st = 0
+        for t in _STICKY.values():          # OR over the devices of this process (a sum would turn two timeouts into "placement")
+            st |= decode_status_words(t.tolist())
+        return st
+    return decode_status_words(fused_status_tensor(device).tolist())
+
+
+def decode_status_words(w):
+    """The status bits from the four sticky words: word 0 is the OR of the launches' status words on THIS device; words 2 and 3 carry
+    bit 0 and bit 1 once more as 0 / 1 flags, which survive the MAX reduction over ranks of ``GradBuckets.finish()`` (the MAX of the
+    OR-ed words of two ranks - a timeout here, a placement violation there - would keep only the larger)."""
+    return (int(w[0]) | int(w[2]) | (int(w[3]) << 1)) & 3
 
 
 def fused_launches_seen(device):

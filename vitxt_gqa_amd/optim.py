@@ -170,7 +170,14 @@ class FusedClipAdam(torch.optim.Adam):
         host, ev, dev, _ = pr
         ev.synchronize()          # recorded a whole step ago: complete unless the host runs more than a step ahead
         pr[3] = False
-        if int(host[0]) != 0:
+        from . import ops
+        if ops.decode_status_words(host.tolist()) != 0:
+            # the step behind this word was gated off on the device (no parameter, moment or gradient touched), but the host had
+            # already advanced the step counts: take that step back, so that a trainer which catches the error and carries on gets
+            # the bias correction of the updates that were really applied (a LambdaLR stepped by the trainer is the trainer's to rewind)
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] = st["step"] - 1
             raise_if_handoff_failed(dev)
 
     def step(self, closure=None):

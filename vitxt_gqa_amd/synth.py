@@ -12,7 +12,10 @@ T_MAX = 20
 DEC_STEPS = 12
 
 
-def make_batch(B, F, P, V=5000, seed=0, text_vocab=30522, ocr_keep=0.7, bos_idx=1, full_targets=True, ocr_prev_frac=0.0):
+def make_batch(B, F, P, V=5000, seed=0, text_vocab=30522, ocr_keep=0.7, bos_idx=1, full_targets=True, ocr_prev_frac=0.0,
+               text_len=None):
+    """``ocr_keep``: density of ``ocr_mask`` - a number, or one per sample (samples with different key counts in one batch);
+    ``text_len``: per-sample question lengths instead of the drawn ones.  Neither changes the random stream of the other fields."""
     g = torch.Generator().manual_seed(seed)
     N = F * P
     s = {}
@@ -27,7 +30,10 @@ def make_batch(B, F, P, V=5000, seed=0, text_vocab=30522, ocr_keep=0.7, bos_idx=
     s["track_id"] = torch.randint(0, 50, (B, N), generator=g)
     bb = torch.rand(B, N, 2, 2, generator=g).sort(dim=2).values        # x1<=x2, y1<=y2
     s["ocr_bbox_coordinates"] = torch.stack([bb[:, :, 0, 0], bb[:, :, 0, 1], bb[:, :, 1, 0], bb[:, :, 1, 1]], -1)
-    s["ocr_mask"] = (torch.rand(B, N, generator=g) < ocr_keep).long()
+    keep = torch.as_tensor(ocr_keep, dtype=torch.float32).reshape(-1, 1)          # [1, 1] or [B, 1]
+    s["ocr_mask"] = (torch.rand(B, N, generator=g) < keep).long()
+    if text_len is not None:
+        s["text_len"] = torch.as_tensor(text_len, dtype=torch.long).reshape(B)
     s["train_prev_inds"] = torch.randint(0, V, (B, DEC_STEPS), generator=g)
     s["train_prev_inds"][:, 0] = bos_idx
     if full_targets:
