@@ -233,10 +233,14 @@ def test_attn_bwd_fill_equals_zero_fill_path_full_length():
     assert (fa[..., :768].float() - fc[..., :768].float()).abs().max().item() < 1e-2 * sc
 
 
-def _heads_against_fp64(x, dout, keys, valid, b, heads, drop_p, drop_seed, out, lse, results, tol_out=3e-2, tol_lse=4e-2):
+def _heads_against_fp64(x, dout, keys, valid, b, heads, drop_p, drop_seed, out, lse, results, tol_out=3e-2, tol_lse=4e-2, tol_max=None,
+                        tol_rel=2e-2):
     """fp64 restatement of WHOLE heads of sample ``b`` (every query over every visible key: [L, L] matrices) against the forward
     (``out``, ``lse``) and each backward result in ``results``: dQ of every query, dK / dV of every key; the exported dropout keep
-    mask (indexed by key-LIST position) enters the restatement.  Returns the worst deviations seen."""
+    mask (indexed by key-LIST position) enters the restatement.  ``tol_out`` x scale bounds EVERY element - or, with ``tol_max``
+    (peaky scores), 99.9 % of the elements, while ``tol_max`` x scale bounds the rest: the kernels round the pre-scaled operand
+    (Q scale log2 e in the forward, K scale log2 e in the backward) to bf16 once more, which moves a score S by up to 2^-9 |S| - 0.2 nats
+    at |S| = 100 - i.e. near-tied probabilities of such rows by that fraction.  Returns the worst deviations seen."""
     from vitxt_gqa_amd import ops
     B = x.shape[0]
     cnt = int(keys.cnt[b])
@@ -279,9 +283,14 @@ def _heads_against_fp64(x, dout, keys, valid, b, heads, drop_p, drop_seed, out, 
         dk = (ds.t() @ q) * 0.125
         del ds, pr, m
         # the forward the kernel's delta comes from is this head too
-        e_out = (out[b, :, h * 64:(h + 1) * 64].double() - o).abs().max().item()
+        d_out = (out[b, :, h * 64:(h + 1) * 64].double() - o).abs()
+        e_out, sc_o = d_out.max().item(), max(1.0, o.abs().max().item())
         e_lse = (lse[b, h].double() - rlse).abs().max().item()
-        assert e_out < tol_out * max(1.0, o.abs().max().item()), "sample %d head %d: forward output max err %.3e" % (b, h, e_out)
+        if tol_max is None:
+            assert e_out < tol_out * sc_o, "sample %d head %d: forward output max err %.3e" % (b, h, e_out)
+        else:
+            frac = (d_out >= tol_out * sc_o).double().mean().item()
+            assert frac <= 1e-3 and e_out < tol_max * sc_o, "sample %d head %d: forward output max err %.3e, %.4f %% of the elements beyond %.1e" % (b, h, e_out, 100 * frac, tol_out * sc_o)
         assert e_lse < tol_lse, "sample %d head %d: LSE max err %.3e" % (b, h, e_lse)
         worst["out"], worst["lse"] = max(worst["out"], e_out), max(worst["lse"], e_lse)
         for got in results:
@@ -290,7 +299,7 @@ def _heads_against_fp64(x, dout, keys, valid, b, heads, drop_p, drop_seed, out, 
                 err = (gg - rr).abs().max().item()
                 rel = (gg - rr).norm().item() / rr.norm().item()
                 worst[name] = max(worst[name], rel)
-                assert err < 3e-2 * max(1.0, rr.abs().max().item()) and rel < 2e-2, \
+                assert err < (tol_max or 3e-2) * max(1.0, rr.abs().max().item()) and rel < tol_rel, \
                     "sample %d head %d %s (dropout %g): max err %.3e at scale %.3e, relative L2 %.3e" % (b, h, name, drop_p, err, rr.abs().max().item(), rel)
             inv = ~valid[b]
             assert gk[:L1][inv].abs().max().item() == 0 and gv[:L1][inv].abs().max().item() == 0
@@ -349,7 +358,7 @@ def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_
             pos = cnt - 200 - 70 * i                                    # a late list position, in a steady-state tile of its own
             krow = int(keys.idx[b, pos])
             q = x[b, r, :768].view(12, 64)
-            alpha = 100.0 * 8.0 / q.pow(2).sum(-1, keepdim=True)        # q.k / 8 = +100 nats = 144 log2-units, per head
+            alpha = 160.0 * 8.0 / q.pow(2).sum(-1, keepdim=True)        # q.k / 8 = +160 nats = 230 log2-units, per head
             x[b, krow, 768:1536] = (q * alpha).reshape(768)
     x = x.to(DEV).to(torch.bfloat16)
     for b in range(B):                                                  # the premise, checked on the rounded operands: gap to tile 0 > 128 log2-units
@@ -369,7 +378,7 @@ def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_
     again = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw)
     assert torch.equal(res, again)                                      # unequal chains side by side: still bit-reproducible
     for b in range(B):
-        w = _heads_against_fp64(x, dout, keys, valid, b, (2, 9), drop_p, 1777, out, lse, [res])
+        w = _heads_against_fp64(x, dout, keys, valid, b, (2, 9), drop_p, 1777, out, lse, [res], tol_max=0.15, tol_lse=0.3, tol_rel=5e-2)
         print("peaky twin sigma %.1f dropout %.1f sample %d (%d keys): mean entropy %.2f nats, widest score range %.0f nats | max err out %.2e lse %.2e | "
               "relative L2 dQ %.2e dK %.2e dV %.2e | smallest planted gap %.0f log2-units" % (
                   sigma, drop_p, b, int(keys.cnt[b]) + D, w["entropy"], w["score_range"], w["out"], w["lse"], w["dQ"], w["dK"], w["dV"], min(gaps)))

@@ -15,7 +15,9 @@ WHICH = sys.argv[1] if len(sys.argv) > 2 else "ilv256"
 OUT = sys.argv[-1]
 assert len(sys.argv) >= 2 and OUT.endswith(".hip"), "usage: make_fb_diag.py [ilv256|ilv384] OUT.hip"
 # "product" = the shipped kernel (since the interleaved 384-key form took over: the ilv384 schedule with XCD-local running sums)
-src = open(os.path.join(ROOT, "tools", "ablate", "attn_bwd_fused_bf16_ilv256.hip") if WHICH == "ilv256" else
+# a path to a .hip file = that source, stamped like the product (round 6: timing-only ablations of the shipped sweep, tools/ablate/make_fb_ablation.py)
+src = open(WHICH if WHICH.endswith(".hip") else
+           os.path.join(ROOT, "tools", "ablate", "attn_bwd_fused_bf16_ilv256.hip") if WHICH == "ilv256" else
            os.path.join(ROOT, "vitxt_gqa_amd", "csrc", "attn_bwd_fused_bf16.hip") if WHICH == "product" else
            os.path.join(ROOT, "tools", "ablate", "variants", "attn_bwd_fused_bf16_ilv384.hip")).read()
 

@@ -85,7 +85,8 @@ def run(fx, dtype, **sw):
     V = fx.V
     for k in ("ref_scores", "pos_scores", "neg_scores"):
         err = (out[k].float().cpu() - fx[k]).abs()
-        res[k] = (err[..., :V].max().item(), err[..., V:].max().item(), int((out[k].float().cpu().argmax(-1) != fx[k].argmax(-1)).sum()))
+        res[k] = (err[..., :V].max().item(), err[..., V:].max().item(), int((out[k].float().cpu().argmax(-1) != fx[k].argmax(-1)).sum()),
+                  err.pow(2).mean().sqrt().item())
     f = model._last_fwd
     res["mmt_dec"] = max((f[p + "_mmt_dec"].float().cpu() - fx[p + "_mmt_dec"]).abs().max().item() for p in ("ref", "pos", "neg"))
     res["qtv_ocr"] = (f["ocr_mmt_in"].float().cpu()[:, ::fx.meta["row_stride"]] - fx["ocr_in"]).abs().max().item()
@@ -107,11 +108,12 @@ def main():
         st = fx.meta.get("attention_stats") or {}
         print("== %s  (B = %d, attn_gain %g%s)" % (case, fx.B, fx.meta["attn_gain"],
               "; reference attention entropy %s nats" % ", ".join("%s %.2f" % (k, v["entropy_mean"]) for k, v in st.items()) if st else ""))
-        print("%-20s | %-23s | %-23s | %-23s | mmt_dec  | qtv ocr  | flips" % ("stage", "ref  vocab / pointer", "pos  vocab / pointer", "neg  vocab / pointer"))
+        print("%-20s | %-23s | %-23s | %-23s | mmt_dec  | qtv ocr  | flips | RMS ref / pos / neg" % ("stage", "ref  vocab / pointer", "pos  vocab / pointer", "neg  vocab / pointer"))
         for name, dt, sw in stages:
             r = run(fx, dt, **sw)
             cells = " | ".join("%.3e / %.3e  " % r[k][:2] for k in ("ref_scores", "pos_scores", "neg_scores"))
-            print("%-20s | %s | %.2e | %.2e | %d" % (name, cells, r["mmt_dec"], r["qtv_ocr"], sum(r[k][2] for k in ("ref_scores", "pos_scores", "neg_scores"))), flush=True)
+            print("%-20s | %s | %.2e | %.2e | %d | %s" % (name, cells, r["mmt_dec"], r["qtv_ocr"], sum(r[k][2] for k in ("ref_scores", "pos_scores", "neg_scores")),
+                                                          " / ".join("%.2e" % r[k][3] for k in ("ref_scores", "pos_scores", "neg_scores"))), flush=True)
 
 
 if __name__ == "__main__":

@@ -15,10 +15,14 @@ os.makedirs(out, exist_ok=True)
 from vitxt_gqa_amd import build as Bld  # noqa: E402
 lib = os.path.join(out, "libt2s_stamp2.so")
 diag = os.path.join(out, "attn_bwd_fused_bf16_stamp.hip")
-WHICH = os.environ.get("FB_SRC", "ilv256")       # "ilv256": the 256-key variant; "ilv384": the 384-key interleaved variant
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ablate", "make_fb_diag.py"), WHICH, diag])
-srcs = [s for s in Bld.sources() if not s.endswith("attn_bwd_fused_bf16.hip")] + [diag]
-subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-w", "-o", lib] + srcs)
+WHICH = os.environ.get("FB_SRC", "ilv256")       # "ilv256": the 256-key variant; "ilv384": the 384-key interleaved variant; "product"; or a .hip path
+if os.environ.get("FB_LIB"):                     # a stamped library built beforehand (tools/ablate/build_fb_libs.sh): no compile on the GPU box
+    lib = os.environ["FB_LIB"]
+    WHICH = os.environ.get("FB_SRC", "product")
+else:
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ablate", "make_fb_diag.py"), WHICH, diag])
+    srcs = [s for s in Bld.sources() if not s.endswith("attn_bwd_fused_bf16.hip")] + [diag]
+    subprocess.check_call([Bld.HIPCC] + Bld.FLAGS + ["-w", "-o", lib] + srcs)
 os.environ["T2S_HIP_LIB"] = lib
 os.environ["T2S_KEEP_DQ32"] = "1"
 import torch  # noqa: E402

@@ -21,6 +21,14 @@ for STEP in "$@"; do
     diag)    # round 6: the multi-GPU diagnosability fields (two gloo ranks on one card) and the neighbour-stream rehearsal of the hand-off
              timeout -k 10 900 python3 -m pytest tests/test_bench_gpu.py tests/test_handoff_guard_gpu.py tests/test_ddp_gpu.py -m gpu -q -s > $OUT/pytest_diag.log 2>&1 || { grep -E "passed|failed|FAILED|Error|assert" $OUT/pytest_diag.log | cut -c1-300; tail -40 $OUT/pytest_diag.log; exit 1; }
              grep -E "passed|failed|neighbour" $OUT/pytest_diag.log | cut -c1-250 ;;
+    fbabl)   # round 6: cycle stamps of the product and of its timing-only ablations (tools/ablate/make_fb_ablation.py), libraries prebuilt by
+             # tools/ablate/build_fb_libs.sh stamp_<what>=tools/ablate/_build/src/stamp_<what>.hip (they travel with the snapshot)
+             rm -f $OUT/fb_ablation_stamps.txt
+             for w in ${FB_ABLS:-product noreads nodq nofinal nopin}; do
+               echo "=== $w" >> $OUT/fb_ablation_stamps.txt
+               FB_LIB=$REPO/tools/ablate/_build/libt2s_fb_stamp_$w.so FB_SRC=product timeout -k 10 300 python3 tools/fused_stamps2.py 8 0.7 0.1 >> $OUT/fb_ablation_stamps.txt 2>&1 || { tail -20 $OUT/fb_ablation_stamps.txt; exit 1; }
+             done
+             cat $OUT/fb_ablation_stamps.txt ;;
     fulllen) timeout -k 10 900 python3 -m pytest tests/test_fulllength_reference_gpu.py -m gpu -x -q -s > $OUT/pytest_fulllen.log 2>&1 || { tail -60 $OUT/pytest_fulllen.log; exit 1; }; tail -30 $OUT/pytest_fulllen.log ;;
     suite)   timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_suite.log 2>&1 || { tail -60 $OUT/pytest_suite.log; exit 1; }; tail -3 $OUT/pytest_suite.log ;;
     smoke)   timeout -k 10 300 python3 __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || { tail -30 $OUT/smoke.log; exit 1; }; tail -1 $OUT/smoke.log ;;
@@ -50,7 +58,8 @@ PYEOF
     fwdstamps) timeout -k 10 600 python3 tools/fwd_stamps.py 8 0.7 0.1 > $OUT/fwd_stamps.txt 2>&1 || { tail -30 $OUT/fwd_stamps.txt; exit 1; }
              timeout -k 10 600 python3 tools/fwd_stamps.py 8 0.7 0.0 >> $OUT/fwd_stamps.txt 2>&1 || { tail -30 $OUT/fwd_stamps.txt; exit 1; }; cat $OUT/fwd_stamps.txt ;;
     fwdab)   # same box, interleaved: the product forward vs a variant source (FWD_VARIANT=name, tools/ablate/variants/attn_fwd_<name>.hip)
-             bash tools/ablate/fwd_variant.sh ${FWD_VARIANT} tools/ablate/variants/attn_fwd_${FWD_VARIANT}.hip > $OUT/fwd_variant_build.log 2>&1 || { tail -20 $OUT/fwd_variant_build.log; exit 1; }
+             # (built beforehand in the authoring container when possible: the .so travels with the snapshot and no GPU-minute goes into hipcc)
+             [ tools/ablate/_build/libt2s_fwd_${FWD_VARIANT}.so -nt tools/ablate/variants/attn_fwd_${FWD_VARIANT}.hip ] || bash tools/ablate/fwd_variant.sh ${FWD_VARIANT} tools/ablate/variants/attn_fwd_${FWD_VARIANT}.hip > $OUT/fwd_variant_build.log 2>&1 || { tail -20 $OUT/fwd_variant_build.log; exit 1; }
              T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fwd_${FWD_VARIANT}.so timeout -k 10 600 python3 -m pytest tests/test_kernels_gpu.py tests/test_dropout_gpu.py -m gpu -x -q -k "fwd or forward or dropout or attention" > $OUT/pytest_fwd_variant.log 2>&1 || { tail -30 $OUT/pytest_fwd_variant.log; exit 1; }; tail -2 $OUT/pytest_fwd_variant.log
              rm -f $OUT/fwd_ab.txt
              for rep in 1 2 3; do
