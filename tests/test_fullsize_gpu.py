@@ -234,7 +234,7 @@ def test_attn_bwd_fill_equals_zero_fill_path_full_length():
 
 
 def _heads_against_fp64(x, dout, keys, valid, b, heads, drop_p, drop_seed, out, lse, results, tol_out=3e-2, tol_lse=4e-2, tol_max=None,
-                        tol_rel=2e-2):
+                        tol_rel=2e-2, scale=0.125):
     """fp64 restatement of WHOLE heads of sample ``b`` (every query over every visible key: [L, L] matrices) against the forward
     (``out``, ``lse``) and each backward result in ``results``: dQ of every query, dK / dV of every key; the exported dropout keep
     mask (indexed by key-LIST position) enters the restatement.  ``tol_out`` x scale bounds EVERY element - or, with ``tol_max``
@@ -257,7 +257,7 @@ def _heads_against_fp64(x, dout, keys, valid, b, heads, drop_p, drop_seed, out, 
     for h in heads:
         q, k, v = [x[b, :, c * 768 + h * 64:c * 768 + (h + 1) * 64].double() for c in range(3)]     # [L, 64]
         do = dout[b, :, h * 64:(h + 1) * 64].double()
-        sc = (q @ k.t()) * 0.125
+        sc = (q @ k.t()) * scale
         worst["score_range"] = max(worst["score_range"], (sc.masked_fill(~vis, float("-inf")).max(-1).values
                                                            - sc.masked_fill(~vis, float("inf")).min(-1).values).max().item())
         sc.masked_fill_(~vis, float("-inf"))
@@ -279,8 +279,8 @@ def _heads_against_fp64(x, dout, keys, valid, b, heads, drop_p, drop_seed, out, 
         delta = (do * o).sum(-1, keepdim=True)
         ds = pr * (dp - delta)
         del dp, a
-        dq = (ds @ k) * 0.125
-        dk = (ds.t() @ q) * 0.125
+        dq = (ds @ k) * scale
+        dk = (ds.t() @ q) * scale
         del ds, pr, m
         # the forward the kernel's delta comes from is this head too
         d_out = (out[b, :, h * 64:(h + 1) * 64].double() - o).abs()
@@ -360,25 +360,32 @@ def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_
             q = x[b, r, :768].view(12, 64)
             alpha = 160.0 * 8.0 / q.pow(2).sum(-1, keepdim=True)        # q.k / 8 = +160 nats = 230 log2-units, per head
             x[b, krow, 768:1536] = (q * alpha).reshape(768)
+    # the kernels as the PRODUCT calls them in the bf16 mode (functional.FOLD_QSCALE): the query projection carries scale * log2(e), rounded
+    # once, and the kernels run with scale' = 1 / log2(e) - their own operand pre-scaling is then exact and forward and backward see the
+    # same scores.  (Called with raw Q and scale = 1/8 they round the pre-scaled operand a second time - Q in the forward, K in the
+    # backward: at |S| = 160 nats the two exponents differ by up to 0.45 and the planted rows' gradients by 30 %.)
+    LOG2E = 1.4426950408889634
+    x[..., :768] *= 0.125 * LOG2E
+    scale = 1.0 / LOG2E
     x = x.to(DEV).to(torch.bfloat16)
     for b in range(B):                                                  # the premise, checked on the rounded operands: gap to tile 0 > 128 log2-units
         t0 = keys.idx[b, :64].long()
         for r in planted:
             q = x[b, r, :768].double().view(12, 64)
-            s_all = torch.einsum("hd,khd->hk", q, x[b, keys.idx[b, :int(keys.cnt[b])].long(), 768:1536].double().view(-1, 12, 64)) * 0.125
-            s_t0 = torch.einsum("hd,khd->hk", q, x[b, t0, 768:1536].double().view(-1, 12, 64)) * 0.125
+            s_all = torch.einsum("hd,khd->hk", q, x[b, keys.idx[b, :int(keys.cnt[b])].long(), 768:1536].double().view(-1, 12, 64)) * scale
+            s_t0 = torch.einsum("hd,khd->hk", q, x[b, t0, 768:1536].double().view(-1, 12, 64)) * scale
             gaps.append(((s_all.max(-1).values - s_t0.max(-1).values) * 1.4426950408889634).min().item())
     assert min(gaps) > 128, "planted keys must overflow the steady state (2^128 > fp32 max): smallest gap %.1f log2-units" % min(gaps)
     dout = torch.randn(B, L, 768, generator=g).to(DEV).to(torch.bfloat16)
     kw = dict(drop_p=drop_p, drop_seed=1777) if drop_p else {}
-    out, lse = ops.attn_fwd(x, keys, **kw)
+    out, lse = ops.attn_fwd(x, keys, scale=scale, **kw)
     assert torch.isfinite(lse).all() and torch.isfinite(out.float()).all(), "a poisoned row survived: the repair launch did not run"
-    res = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw)
+    res = ops.attn_bwd(x, out, dout, lse, keys, scale=scale, fused=True, dq_mode=1, **kw)
     assert ops.LAST_ATTN_BWD_PRODUCTS == 5 and ops.fused_handoff_status() == 0
-    again = ops.attn_bwd(x, out, dout, lse, keys, fused=True, dq_mode=1, **kw)
+    again = ops.attn_bwd(x, out, dout, lse, keys, scale=scale, fused=True, dq_mode=1, **kw)
     assert torch.equal(res, again)                                      # unequal chains side by side: still bit-reproducible
     for b in range(B):
-        w = _heads_against_fp64(x, dout, keys, valid, b, (2, 9), drop_p, 1777, out, lse, [res], tol_max=0.15, tol_lse=0.3, tol_rel=5e-2)
+        w = _heads_against_fp64(x, dout, keys, valid, b, (2, 9), drop_p, 1777, out, lse, [res], tol_max=0.1, tol_lse=4e-2, tol_rel=3e-2, scale=scale)
         print("peaky twin sigma %.1f dropout %.1f sample %d (%d keys): mean entropy %.2f nats, widest score range %.0f nats | max err out %.2e lse %.2e | "
               "relative L2 dQ %.2e dK %.2e dV %.2e | smallest planted gap %.0f log2-units" % (
                   sigma, drop_p, b, int(keys.cnt[b]) + D, w["entropy"], w["score_range"], w["out"], w["lse"], w["dQ"], w["dK"], w["dV"], min(gaps)))

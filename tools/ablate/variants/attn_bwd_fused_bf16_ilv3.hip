@@ -716,8 +716,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
           FB_G1(1, 7); FB_E(0, 7); FB_FENCE(); FB_DQ_STEP(15);
           // slot 2 = G2(b0) + M(b0) with the last eight dQ steps in its first four groups; the barrier that retires the readers of the
           // dS^T image stands in front of the slot's dS^T store (group 6) instead of in front of the slot
-          FB_LD_QT(0);
-          FB_LD_KF(2); FB_FENCE();
+          FB_LD_QT(0); FB_FENCE();
           FB_LD_DL(0);
           FB_G2(0, 0); FB_M(0, 0); FB_M(0, 1); FB_FENCE(); FB_DQ_STEP(16); FB_DQ_STEP(17);
           FB_G2(0, 1); FB_M(0, 2); FB_M(0, 3); FB_FENCE(); FB_DQ_STEP(18); FB_DQ_STEP(19);
@@ -738,6 +737,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
           FB_G2(0, 5); FB_LD_SEEDS(lse_s, del_s, 2); FB_FENCE();
           asm volatile("s_barrier" ::: "memory");             // every wave is done reading the dS^T image of the previous tile
           FB_G2(0, 6); FB_ST_DS(0); FB_FENCE(); FB_G2(0, 7); FB_FENCE();
+          // the row fragments of sub-block 0 and the K fragments of key block 2 are (re)fetched HERE, behind the dQ steps: held across
+          // slot 2 they are 48 registers the interleaved product needs (qf / dof were kept from the top of the tile: one more LDS read each)
+          FB_LD_QF(qb_, dob_, 0); FB_LD_KF(2); FB_FENCE();
         } else {
         FB_G1(0, 0); FB_LD_QT(0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_G1(0, 1); FB_FENCE(); FB_G1(0, 2); FB_FENCE(); FB_G1(0, 3); FB_FENCE();
         FB_G1(0, 4); FB_FENCE(); FB_G1(0, 5); FB_FENCE(); FB_G1(0, 6); FB_FENCE(); FB_G1(0, 7); FB_FENCE();

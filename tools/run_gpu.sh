@@ -70,7 +70,9 @@ PYEOF
              done
              cat $OUT/fwd_ab.txt | cut -c1-150 ;;
     fbab)    # same box, interleaved: the product fused backward vs a variant source (FB_VARIANT=name, tools/ablate/variants/attn_bwd_fused_bf16_<name>.hip)
-             bash tools/ablate/fb_variant.sh ${FB_VARIANT} tools/ablate/variants/attn_bwd_fused_bf16_${FB_VARIANT}.hip > $OUT/fb_variant_build.log 2>&1 || { tail -20 $OUT/fb_variant_build.log; exit 1; }
+             [ tools/ablate/_build/libt2s_fbv_${FB_VARIANT}.so -nt tools/ablate/variants/attn_bwd_fused_bf16_${FB_VARIANT}.hip ] || bash tools/ablate/fb_variant.sh ${FB_VARIANT} tools/ablate/variants/attn_bwd_fused_bf16_${FB_VARIANT}.hip > $OUT/fb_variant_build.log 2>&1 || { tail -20 $OUT/fb_variant_build.log; exit 1; }
+             # the variant must be CORRECT before its time means anything: every attention / dropout / hand-off test on the variant library
+             T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_${FB_VARIANT}.so timeout -k 10 900 python3 -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_dropout_gpu.py tests/test_handoff_guard_gpu.py -m gpu -x -q -k "attention or attn or fused or dropout or handoff or bwd or backward" > $OUT/pytest_fb_variant.log 2>&1 || { tail -40 $OUT/pytest_fb_variant.log; exit 1; }; tail -2 $OUT/pytest_fb_variant.log
              rm -f $OUT/fb_ab.txt
              for dp in 0.1 0.0; do for rep in 1 2 3; do
                echo "== product, dropout $dp" >> $OUT/fb_ab.txt
