@@ -328,9 +328,10 @@ def test_attention_bwd_fused_full_length_against_fp64_heads(drop_p):
     _heads_against_fp64(x, dout, keys, valid, 0, (3, 10), drop_p, 991, out, lse, results)
 
 
+@pytest.mark.parametrize("regime", ["product", "prescaled_q"])
 @pytest.mark.parametrize("sigma", [1.5, 2.5])
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
-def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_heads(drop_p, sigma):
+def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_heads(drop_p, sigma, regime):
     """VERDICT r5 #1, the kernel-level twin of the peaky reference fixture: forward AND fused backward at L = 10 132 where the design is
     hard.  (i) PEAKY scores: Q and K rows ~ N(0, sigma^2) -> score sigma 2.25 nats (sigma 1.5; ranges ~20 nats) / 6.25 nats (sigma 2.5;
     ranges ~55 nats, mean entropy ~2 nats against ln 7 100 = 8.9).  (ii) TWO DIFFERENT samples in one launch: 70 % and 30 % of the prefix
@@ -339,7 +340,15 @@ def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_
     is planted whose score lies > 128 log2-units above everything tile 0 holds - exp2 of that overflows fp32, so the steady state
     CANNOT represent it: the row sum is inf, the wave poisons its rows (LSE = NaN) and only the REPAIR launch can produce the finite,
     correct rows asserted here (and the rows of the other waves of those workgroups, which the repair recomputes too).  Everything
-    against the fp64 restatement of whole heads: out, LSE, dQ of every query, dK / dV of every key."""
+    against the fp64 restatement of whole heads: out, LSE, dQ of every query, dK / dV of every key.
+    Two regimes of the C ABI's ``scale`` argument.  "product": raw Q, scale 1/8, as functional.py calls the kernels - they round the
+    pre-scaled operand a SECOND time (Q scale log2 e in the forward, K scale log2 e in the backward), which moves a score by up to
+    2^-9 |S| log2 e = 0.45 in the exponent at the planted |S| = 160 nats, differently in the two directions: the bounds are loose and say
+    so (out 0.2 x scale, LSE 0.3, gradients 8 % relative L2; measured 0.12 / 0.19 / 5.3 %).  "prescaled_q": Q arrives multiplied by
+    scale log2 e (rounded once) and scale = 1 / log2 e, so the kernels' own pre-scaling is exact and forward and backward see identical
+    scores: every element within the usual 3e-2, LSE 2e-5, gradients ~1 % (measured).  Folding the factor into the query projection was
+    built and measured (tools/ablate/variants/fold_qscale_into_projection.patch): at the model level it did NOT bring the bf16 mode closer to
+    the reference's fp32 gradients (HISTORY.md, round 6), so the product keeps the raw-Q call."""
     _need_gpu()
     from vitxt_gqa_amd import ops
     ops.reset_fused_status()
@@ -360,13 +369,11 @@ def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_
             q = x[b, r, :768].view(12, 64)
             alpha = 160.0 * 8.0 / q.pow(2).sum(-1, keepdim=True)        # q.k / 8 = +160 nats = 230 log2-units, per head
             x[b, krow, 768:1536] = (q * alpha).reshape(768)
-    # the kernels as the PRODUCT calls them in the bf16 mode (functional.FOLD_QSCALE): the query projection carries scale * log2(e), rounded
-    # once, and the kernels run with scale' = 1 / log2(e) - their own operand pre-scaling is then exact and forward and backward see the
-    # same scores.  (Called with raw Q and scale = 1/8 they round the pre-scaled operand a second time - Q in the forward, K in the
-    # backward: at |S| = 160 nats the two exponents differ by up to 0.45 and the planted rows' gradients by 30 %.)
     LOG2E = 1.4426950408889634
-    x[..., :768] *= 0.125 * LOG2E
-    scale = 1.0 / LOG2E
+    scale = 0.125
+    if regime == "prescaled_q":
+        x[..., :768] *= 0.125 * LOG2E
+        scale = 1.0 / LOG2E
     x = x.to(DEV).to(torch.bfloat16)
     for b in range(B):                                                  # the premise, checked on the rounded operands: gap to tile 0 > 128 log2-units
         t0 = keys.idx[b, :64].long()
@@ -385,10 +392,11 @@ def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_
     again = ops.attn_bwd(x, out, dout, lse, keys, scale=scale, fused=True, dq_mode=1, **kw)
     assert torch.equal(res, again)                                      # unequal chains side by side: still bit-reproducible
     for b in range(B):
-        w = _heads_against_fp64(x, dout, keys, valid, b, (2, 9), drop_p, 1777, out, lse, [res], tol_max=0.1, tol_lse=4e-2, tol_rel=3e-2, scale=scale)
-        print("peaky twin sigma %.1f dropout %.1f sample %d (%d keys): mean entropy %.2f nats, widest score range %.0f nats | max err out %.2e lse %.2e | "
+        tol = dict(tol_max=0.2, tol_lse=0.3, tol_rel=8e-2) if regime == "product" else dict(tol_lse=4e-2, tol_rel=3e-2)
+        w = _heads_against_fp64(x, dout, keys, valid, b, (2, 9), drop_p, 1777, out, lse, [res], scale=scale, **tol)
+        print("peaky twin [%s] sigma %.1f dropout %.1f sample %d (%d keys): mean entropy %.2f nats, widest score range %.0f nats | max err out %.2e lse %.2e | "
               "relative L2 dQ %.2e dK %.2e dV %.2e | smallest planted gap %.0f log2-units" % (
-                  sigma, drop_p, b, int(keys.cnt[b]) + D, w["entropy"], w["score_range"], w["out"], w["lse"], w["dQ"], w["dK"], w["dV"], min(gaps)))
+                  regime, sigma, drop_p, b, int(keys.cnt[b]) + D, w["entropy"], w["score_range"], w["out"], w["lse"], w["dQ"], w["dK"], w["dV"], min(gaps)))
 
 
 # ------------------------------------------------------------------------------------------------------------------

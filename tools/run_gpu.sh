@@ -29,6 +29,9 @@ for STEP in "$@"; do
                FB_LIB=$REPO/tools/ablate/_build/libt2s_fb_stamp_$w.so FB_SRC=product timeout -k 10 300 python3 tools/fused_stamps2.py 8 0.7 0.1 >> $OUT/fb_ablation_stamps.txt 2>&1 || { tail -20 $OUT/fb_ablation_stamps.txt; exit 1; }
              done
              cat $OUT/fb_ablation_stamps.txt ;;
+    forcedist) # the RCCL process-group path with ONE rank (communicator, bucket all-reduces, all_gather of the rank report, MAX reduction) on a 1-GPU box
+             T2S_BENCH_FORCE_DIST=1 timeout -k 10 600 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dropout0 > $OUT/bench_forcedist.json 2> $OUT/bench_forcedist.err || { tail -30 $OUT/bench_forcedist.err; exit 1; }
+             python3 -c "import json,sys; d=json.loads(open('$OUT/bench_forcedist.json').read().strip().splitlines()[-1]); print('force-dist:', d['backend'], d['ms_per_step'], 'ms/step; multi_gpu:', json.dumps(d['multi_gpu'])[:900])" ;;
     fulllen) timeout -k 10 900 python3 -m pytest tests/test_fulllength_reference_gpu.py -m gpu -x -q -s > $OUT/pytest_fulllen.log 2>&1 || { tail -60 $OUT/pytest_fulllen.log; exit 1; }; tail -30 $OUT/pytest_fulllen.log ;;
     suite)   timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_suite.log 2>&1 || { tail -60 $OUT/pytest_suite.log; exit 1; }; tail -3 $OUT/pytest_suite.log ;;
     smoke)   timeout -k 10 300 python3 __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || { tail -30 $OUT/smoke.log; exit 1; }; tail -1 $OUT/smoke.log ;;

@@ -18,9 +18,15 @@
 //  * Tile 0 (which fixes m) and the masked edge tiles run first through a general path (S from zero, masks, true
 //    maximum, rescale); softmax does not care about the order of the keys.  The unmasked tiles [1, nfast) then run
 //    the steady-state loop, which has no branch and no masking code in it.
-//  * A steady-state tile whose row sum is not < BIG (inf / NaN included; needs a score 80 log2-units above the
+//  * A row whose steady-state sum is not < BIG (inf / NaN included; needs a score 80 log2-units above the
 //    reference, i.e. e^55 times the largest probability seen so far) poisons the wave: its rows get LSE = NaN and the
 //    REPAIR launch (same kernel, every tile through the general path) recomputes exactly those workgroups.
+//  * The steady state's row sums run on the MATRIX pipe (round 6): one v_mfma_f32_16x16x32_bf16 with a 0 / 1 A operand per P
+//    fragment accumulates the denominator of the lane's own query over all tiles (see `lacc` below): 66 v_add per tile
+//    leave the vector-issue port (loop: 502 -> 420 instructions, VALU 339 -> 271), and the sum is over the very rounded
+//    probabilities the numerator multiplies.  Measured, same box, interleaved (profiles/r06_fwd_rowsum_ab.txt):
+//    7.80 vs 7.97 ms at B = 32, L = 10 132, dropout 0.1 (-2.2 %) with the 1 MFMA : 8 VALU interleave pattern below (1 : 10
+//    before: -1.8 %; 12 groups of 1 : 11: -1.6 %).
 //  * The tile body is written as a wavefront - S(key block 0) | S(key block 1) + exp(block 0) | PV(block 0) +
 //    exp(block 1) | PV(block 1) - with scheduling fences between the stages and an MFMA:VALU interleave pattern
 //    inside them.
@@ -165,6 +171,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   bf16x8 pf[QB][2][2];
   float m_run[QB], l_run[QB];
   bool poisoned = false;
+  // Row sums on the matrix pipe: in the steady state the denominator of a query row is accumulated by an MFMA with a 0 / 1
+  // A operand on the very bf16 P fragment that goes into P.V - v_mfma_f32_16x16x32_bf16, D[m, n] = sum_k A[m, k] B[k, n] with B = the
+  // fragment as it stands (lane l: column n = l & 15, k block l >> 4: query (n + 16 (kblock & 1)), key half kblock >> 1) and
+  // A[m][kblock] = 1 iff (kblock & 1) == ((m >> 2) & 1): lane l's four result registers (rows 4 (l >> 4) .. + 3 of column l & 15) then all
+  // hold the sum over BOTH key halves of the lane's OWN query l & 31.  Replaces 66 v_add per tile on the saturated vector-issue port by
+  // 8 four-pass MFMAs on a pipe that is 60 % idle, needs no cross-half exchange, and the denominator sums exactly the rounded
+  // probabilities the numerator multiplies.
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  f32x4_t lacc[QB];
+  bf16x8 ones_a;
+  {
+    const bf16_t one = (bf16_t)((((lane >> 4) & 1) == (((lane & 15) >> 2) & 1)) ? 1.f : 0.f);
+    ones_a = bf16x8{one, one, one, one, one, one, one, one};
+  }
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) lacc[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
@@ -174,9 +196,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   }
 
   // P of (query block, key block, k-step pair s) -> bf16 operand fragment, dropout mask applied
-#define PACK_P(qb_, kbk_, s_, cbuf_)                                                                \
+#define PACK_P(qb_, kbk_, s_, cbuf_) PACK_P_(qb_, kbk_, s_, cbuf_, false)
+#define PACK_P_(qb_, kbk_, s_, cbuf_, rowsum_)                                                      \
   {                                                                                                 \
     bf16x8 f_ = acc_to_frag(sacc[qb_][kbk_], s_);                                                   \
+    if (rowsum_) lacc[qb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, f_, lacc[qb_], 0, 0, 0);   /* (the UNdropped probabilities) */ \
     if (DROP) { /* word i of the fragment = key pair kbk*16 + 8s + 4(i>>1) + (i&1) + 2lh of the tile, this lane's query row */ \
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));                                   \
       u32x4 w_ = __builtin_bit_cast(u32x4, f_);                                                     \
@@ -287,11 +311,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
   {                                                                                                 \
     f32x16& sa_ = sacc[qb_][kbk_];                                                                  \
     _Pragma("unroll") for (int j = 0; j < 16; ++j) sa_[j] = fast_exp2(sa_[j]);                      \
-    const float a0_ = (sa_[0] + sa_[4]) + (sa_[8] + sa_[12]), a1_ = (sa_[1] + sa_[5]) + (sa_[9] + sa_[13]);   \
-    const float a2_ = (sa_[2] + sa_[6]) + (sa_[10] + sa_[14]), a3_ = (sa_[3] + sa_[7]) + (sa_[11] + sa_[15]); \
-    lsum[qb_] += (a0_ + a1_) + (a2_ + a3_);                                                         \
-    PACK_P(qb_, kbk_, 0, buf);                                                                      \
-    PACK_P(qb_, kbk_, 1, buf);                                                                      \
+    PACK_P_(qb_, kbk_, 0, buf, true);                                                               \
+    PACK_P_(qb_, kbk_, 1, buf, true);                                                               \
   }
     for (int t = 1; t < nfast; ++t) {
       const int buf = t & 1;
@@ -303,9 +324,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) rk2[qb] = attn_drop_rowkey16w(rh[qb], (t * BK) / ATTN_DROP_KWIN) * 0x10001u;
       }
-      float lsum[QB];
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) lsum[qb] = 0.f;
       __builtin_amdgcn_sched_barrier(0);
       // stage A: S(key block 0), seeded
 #pragma unroll
@@ -327,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #pragma unroll
       for (int i = 0; i < 4 * QB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);     // 10 VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // 8 VALU
       }
       __builtin_amdgcn_sched_barrier(0);
       // stage C: PV(key block 0) beside the softmax of key block 1
@@ -337,22 +355,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #pragma unroll
       for (int i = 0; i < 4 * QB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       // stage D: PV(key block 1)
       PV_MFMAS(vb, 1);
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        l_run[qb] += lsum[qb];
-        poisoned |= !(lsum[qb] < BIG);
-      }
       STAGE_WRITE(buf ^ 1);
       __syncthreads();
     }
 #undef SOFTMAX_BLOCK
   }
 #undef PACK_P
+#undef PACK_P_
 #undef PV_MFMAS
 #undef ROW_FRAG
 #undef Q_FRAG
@@ -364,13 +378,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 
   // ---- epilogue: normalise, stage O through LDS (per-wave 32 x 64 tile, 144-B rows), store whole rows
   __syncthreads();
+  // the steady state's row sums (both key halves of the lane's query, see lacc): every P >= 0, so the TOTAL < BIG bounds every tile's
+  // sum and every single P, as the per-tile test did; inf / NaN included
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) poisoned |= !(lacc[qb][0] < BIG);
   const bool wave_poisoned = __any(poisoned);     // both lane halves of a row, and simplest: the whole wave
   char* ob = smem + wave * (32 * 144);
   bf16_t* __restrict__ O = reinterpret_cast<bf16_t*>(p.out) + (int64_t)b * p.o_bs + h * 64;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int qrow = q0 + qb * 32 + lr;
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float l_tot = (l_run[qb] + __shfl_xor(l_run[qb], 32, 64)) + lacc[qb][0];      // general tiles (per half) + steady state (whole row)
     const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (DROP ? p.drop_inv : 1.f);   // normaliser uses the UNdropped sum
 #pragma unroll
     for (int db = 0; db < 2; ++db)
