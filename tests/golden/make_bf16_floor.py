@@ -76,6 +76,14 @@ def run(case):
                 sq += g * g
                 rel[n] = abs(g - r) / (r + 1e-6 * total)
             live = {n: v for n, v in rel.items() if not n.endswith("attention.self.key.bias")}      # (mathematically zero gradients: noise both sides)
+            # the gradient SLICES the fixture stores element by element: relative L2 distance under autocast
+            slices = {}
+            for k, v in fx.arr.items():
+                if k.startswith("grad:"):
+                    n = k[5:]
+                    g = params[n[:-1].split("[:")[0]].grad[:int(n[:-1].split("[:")[1])] if n.endswith("]") else params[n].grad
+                    slices[n] = float((g.float() - v).norm() / (v.norm() + 1e-12))
+            rec["grad_slices_rel_l2"] = slices
             rec["grad"] = {"worst_rel": max(live.values()), "worst_name": max(live, key=live.get), "total_rel": abs(sq ** 0.5 - total) / total,
                            "key_bias_max_over_total": max(float(params[n].grad.double().norm()) for n in names if n.endswith("attention.self.key.bias")) / total,
                            "rel": rel}

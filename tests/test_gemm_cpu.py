@@ -77,3 +77,22 @@ def test_wgrad_supported_mirrors_the_span_limits_of_the_c_side():
     assert not G.wgrad_supported(3_000_000, 768, 3072, splits=5000)        # > 4096 splits
     assert not G.wgrad_supported(649_984, 768, 768, ld_dy=1 << 24)         # a wide row stride counts, not the row width
     assert G.nt_supported(649_984, 3072, 768) and not G.nt_supported(649_984, 3072, 768, lda=1 << 22)
+
+
+def test_persistent_nt_walk_takes_every_tile_exactly_once():
+    """Round 6: the NT kernel is persistent - one workgroup per CU (cus / 8 per XCD) walks the items of its XCD's range (slot, slot +
+    per_xcd, ...) and stops at the first id without an item.  Every tile exactly once for ragged shapes, group widths and card sizes; a
+    workgroup's walk stays inside its XCD's M-range; consecutive slots hold consecutive items (the L2 locality of the one-tile dispatch)."""
+    for tiles_m, tiles_n in ((1, 3), (7, 12), (9, 9), (64, 12), (2539, 12), (2539, 3)):
+        for b in sorted({1, 4, tiles_n}):
+            for per_xcd in (1, 5, 32, 38):
+                seen = {}
+                for x in range(8):
+                    for slot in range(per_xcd):
+                        for t in G.nt_walk(x, slot, per_xcd, tiles_m, tiles_n, b):
+                            assert t not in seen, (tiles_m, tiles_n, b, per_xcd, t, seen[t], (x, slot))
+                            seen[t] = (x, slot)
+                            assert t[0] // ((tiles_m + 7) // 8) == x
+                assert len(seen) == tiles_m * tiles_n, (tiles_m, tiles_n, b, per_xcd, len(seen))
+    first = [G.nt_walk(0, s, 32, 2539, 12, 12)[0] for s in range(32)]
+    assert first == [G.nt_item(8 * s, 2539, 12, 12) for s in range(32)]

@@ -79,7 +79,9 @@ def test_cls_features_match_hf_vit(hidden, heads, layers, ffn, img):
     assert got32.shape == want.shape
     assert (got32 - want).abs().max().item() < 2e-3, (got32 - want).abs().max().item()
     got16 = ViTFeatureExtractor(ref.state_dict(), dtype=torch.bfloat16, **kw)(x).cpu()
-    assert (got16 - want).abs().max().item() < 6e-2, (got16 - want).abs().max().item()
+    e16 = (got16 - want).abs().max().item()
+    print("ViT %d x %d heads, bf16 operands vs transformers.ViTModel fp32: max abs err %.4f (fp32 mode %.2e)" % (hidden, heads, e16, (got32 - want).abs().max().item()))
+    assert e16 < 6e-2, e16
 
 
 def test_preprocess_and_npy_files(tmp_path):

@@ -1,3 +1,5 @@
+// ONE TILE PER WORKGROUP (round 5 form + round 6's ADVICE fixes): kept for A/B runs against the shipped persistent tile walk
+// (GEMM_VARIANT=onetile tools/run_gpu.sh <tag> gemmab; profiles/r06_gemm_persist_ab.txt).
 // Own bf16 MFMA GEMM family for gfx950 (round 5): the linear layers of the third-party BERT block
 // the reference calls at pythia/models/t2s.py:423-427,538-542,622-626 (BertSelfOutput / BertIntermediate / BertOutput dense layers) and
 // their gradients (autograd of the same calls, stepped by pythia/trainers/base_trainer.py:262-272), with the epilogues a library GEMM
@@ -31,12 +33,6 @@
 //     or 1 phase after when the reads were retired ahead of the reading phase's first barrier (B0: read first in phase 4t+1 and retired by
 //     lgkmcnt(8) in front of the barrier, filled in 4t+2).  K-tiles past the end are "filled" through a zero-record descriptor (no memory
 //     access, zeros land): the vmcnt arithmetic is the same in every iteration.
-//   * PERSISTENT tile walk of the NT kernel (round 6): one workgroup per CU walks its XCD's work items; K-tile 0 of the NEXT tile is
-//     fetched into LDS buffer 0 under the epilogue of the current one, which stages through buffer 1 only (8 KB per wave: two rounds of
-//     64 rows, four of 32 for the fp32-staged gelu' form); behind the epilogue ONE s_waitcnt vmcnt(0) + barrier (loads and stores do not
-//     retire in order with respect to each other, so no counted wait there), then the lead of K-tile 1 and the unchanged steady state.
-//     The GELU tables are fetched once per workgroup instead of once per tile.  Same box, interleaved (profiles/r06_gemm_persist_ab.txt):
-//     dgrad + gelu' 3.63 vs 3.76 ms (-3.6 %), FFN-in + GELU 3.74 vs 3.79 (-1.3 %), plain NT at K = 768 -2.3 ... -3.7 %, at K >= 2304 +-0.4 %.
 #include <stdlib.h>
 
 #include "common.h"
@@ -253,26 +249,22 @@ struct LoaderTN {
 // += over K-tiles 0 .. KT-1 (KT even).  On return every DMA has landed, every wave has passed a common barrier: LDS is free.
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <class Loader>
-__device__ __forceinline__ void gemm_mainloop(Loader& ld, f32x4 (&acc)[8][4], int KT, int wave_row, bool prefetched = false) {
+__device__ __forceinline__ void gemm_mainloop(Loader& ld, f32x4 (&acc)[8][4], int KT, int wave_row) {
   gfrag xf[4][2], wa[2][2], wb[2][2];
 #define G_MMA(xf_, wf_, mh_, nh_)                                                                                                  \
   __builtin_amdgcn_s_setprio(1);                                                                                                   \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
     acc[(mh_) * 4 + mt][(nh_) * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_[nt][ks], xf_[mt][ks], acc[(mh_) * 4 + mt][(nh_) * 2 + nt], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);
-  // prologue: K-tile 0 whole, then B0 A0 B1 of K-tile 1 (the steady-state lead); K-tile 0 has landed behind vmcnt(6).
-  // PERSISTENT tile walk (round 6): `prefetched` = K-tile 0 of this tile was issued under the previous tile's epilogue and has landed
-  // (the caller's vmcnt(0) + barrier): only the lead of K-tile 1 is issued here, and nothing is waited for
-  if (!prefetched) {
-    ld.template stage<0>(0, 0);
-    ld.template stage<2>(0, 0);
-    ld.template stage<3>(0, 0);
-    ld.template stage<1>(0, 0);
-  }
+  // prologue: K-tile 0 whole, then B0 A0 B1 of K-tile 1 (the steady-state lead); K-tile 0 has landed behind vmcnt(6)
+  ld.template stage<0>(0, 0);
+  ld.template stage<2>(0, 0);
+  ld.template stage<3>(0, 0);
+  ld.template stage<1>(0, 0);
   ld.template stage<2>(1, 1);
   ld.template stage<0>(1, 1);
   ld.template stage<3>(1, 1);
-  if (!prefetched) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   G_BAR();
   if (wave_row == 1) G_BAR();                         // the stagger: waves 4-7 run one barrier behind
   for (int kt = 0; kt < KT; kt += 2) {
@@ -367,20 +359,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, lq = lane >> 4;
-  // PERSISTENT tile walk (round 6): one workgroup per CU; the workgroups of XCD x (blockIdx % 8) take the items of that XCD's
-  // range in turn (item j = slot, slot + per_xcd, ...: at any time the XCD's CUs hold consecutive items, as the one-tile-per-workgroup
-  // dispatch did), and K-tile 0 of the NEXT tile is fetched into LDS buffer 0 while the epilogue of the current one drains through
-  // buffer 1 - the 7-half-tile prologue no longer stands alone in front of every 12-K-tile main loop.
-  const int xcd = (int)(blockIdx.x % G_XCDS), per_xcd = (int)(gridDim.x / G_XCDS);
-  int item = (int)(blockIdx.x / G_XCDS);
   int tm, tn;
-  if (!nt_item(item * G_XCDS + xcd, p.tiles_m, p.tiles_n, p.ngroup, tm, tn)) return;      // workgroup-uniform
+  if (!nt_item((int)blockIdx.x, p.tiles_m, p.tiles_n, p.ngroup, tm, tn)) return;      // workgroup-uniform
   tm = __builtin_amdgcn_readfirstlane(tm);
   tn = __builtin_amdgcn_readfirstlane(tn);
+  const int m0 = tm * 256, n0 = tn * 256;
 
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (EPI == EPI_GELU_GRAD || EPI == EPI_GELU_DUAL) {
-    // the compact table: [sign][G_TAB_RANGE] entries behind the tile buffers; 1 KB pieces round the waves, ONCE per workgroup.  These
-    // DMAs are OLDER than every tile DMA, so the first main loop's counted waits cover them, and its barriers publish them
+    // the compact table: [sign][G_TAB_RANGE] entries behind the tile buffers; 1 KB pieces round the waves.  These DMAs are OLDER than
+    // every tile DMA, so the main loop's counted waits cover them, and its barriers publish them
     constexpr int ES = EPI == EPI_GELU_GRAD ? 4 : 2, HALF = G_TAB_RANGE * ES, PIECES = 2 * HALF / 1024;
     const u32x4 rs = g_rsrc(p.table, 65536u * ES);
     const uint32_t dst = __builtin_amdgcn_readfirstlane(g_lds_addr(smem + G_SMEM));
@@ -390,35 +382,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
     }
   }
   LoaderNT ld;
-  ld.init(p, smem, tm * 256, tn * 256, wave, lane);
-  bool prefetched = false;
-  for (;;) {
-  const int m0 = tm * 256, n0 = tn * 256;
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_mainloop(ld, acc, p.K / 64, wr, prefetched);
-  // the next item of this workgroup; its K-tile 0 goes out NOW, into buffer 0 (on return from the main loop every DMA has landed and
-  // every wave has passed a common barrier: LDS is free), under the epilogue below, which stages through buffer 1 only
-  item += per_xcd;
-  int tm2 = 0, tn2 = 0;
-  const bool more = nt_item(item * G_XCDS + xcd, p.tiles_m, p.tiles_n, p.ngroup, tm2, tn2);       // workgroup-uniform
-  if (more) {
-    tm = __builtin_amdgcn_readfirstlane(tm2);
-    tn = __builtin_amdgcn_readfirstlane(tn2);
-    ld.init(p, smem, tm * 256, tn * 256, wave, lane);
-    ld.template stage<0>(0, 0);
-    ld.template stage<2>(0, 0);
-    ld.template stage<3>(0, 0);
-    ld.template stage<1>(0, 0);
-  }
+  ld.init(p, smem, m0, n0, wave, lane);
+  gemm_mainloop(ld, acc, p.K / 64, wr);
 
-  // ---- epilogue.  The wave's 128 x 64 outputs go through its own 8 KB of LDS in BUFFER 1 (buffer 0 is receiving the next tile's K-tile 0):
-  // bf16 forms: two rounds of 64 rows x 128 B (16-byte chunk c of row r at c ^ (r & 7)); the gelu' form stages fp32: four rounds of 32
-  // rows x 256 B.  Whole 128-byte row segments leave: 8 rows per wave-instruction.
-  char* const cw = smem + G_BUF + wave * 8192;
+  // ---- epilogue.  The wave's 128 x 64 outputs go through its own 16 KB of LDS (rows of 128 B, 16-byte chunk c of row r at c ^ (r & 7))
+  // and leave as whole 128-byte row segments: 8 rows per wave-instruction.
+  char* const cw = smem + wave * 16384;
   const int mw = m0 + wr * 128, nw = n0 + wc * 64;                     // first row / column of this wave's outputs
   const int er = lane >> 3, ec = lane & 7;                             // read-back: row er of every 8-row group, chunk ec (columns 8 ec .. 8 ec + 7)
   if constexpr (EPI == EPI_STORE || EPI == EPI_ACCUM || EPI == EPI_GELU_DUAL) {
@@ -429,26 +398,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) b4[nt][j] = (p.bias && n + j < p.N) ? (float)p.bias[n + j] : 0.f;
     }
-    const bool cols_ok = nw + ec * 8 + 7 < p.N;
-    const unsigned short* ltab = reinterpret_cast<const unsigned short*>(smem + G_SMEM);
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int row = mt * 16 + l15;
-        const f32x4 v = acc[round * 4 + mt][nt];
+        const f32x4 v = acc[mt][nt];
         const bf16x4 o = {(bf16_t)(v[0] + b4[nt][0]), (bf16_t)(v[1] + b4[nt][1]), (bf16_t)(v[2] + b4[nt][2]), (bf16_t)(v[3] + b4[nt][3])};
         *reinterpret_cast<bf16x4*>(cw + row * 128 + (((nt * 2 + (lq >> 1)) ^ (row & 7)) << 4) + (lq & 1) * 8) = o;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (own region only: no workgroup barrier)
+    const bool cols_ok = nw + ec * 8 + 7 < p.N;
+    const unsigned short* ltab = reinterpret_cast<const unsigned short*>(smem + G_SMEM);
 #pragma unroll 4
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 16; ++i) {
       const int row = i * 8 + er;
       typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
       u16x8 v = *reinterpret_cast<const u16x8*>(cw + row * 128 + ((ec ^ (row & 7)) << 4));
-      const int m = mw + round * 64 + row;
+      const int m = mw + row;
       if (m < p.M && cols_ok) {
         bf16_t* dst = p.C + (int64_t)m * p.ldc + nw + ec * 8;
         if constexpr (EPI == EPI_ACCUM) {
@@ -463,9 +430,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
         }
         if constexpr (EPI == EPI_GELU_DUAL) {
           // g = gelu(u) of the ROUNDED pre-activation: bit-equal to gelu_fwd_kernel on the same u (table values are that kernel's
-          // arithmetic; below 2^-24 it yields x / 2 exactly, from 16 up x * (1 + erff) = x or x * 0).  Table offsets of TWO values per
-          // packed 16-bit instruction; values outside the table's range are recognised by the largest unclamped offset of the lane's 8
-          // values and redone by the per-value arithmetic behind a branch the wave skips.
+          // arithmetic; below 2^-24 it yields x / 2 exactly, from 16 up x * (1 + erff) = x or x * 0)
+          // The table offsets of TWO values per packed 16-bit instruction (and / sub / min / shift / add on both halves of a word): ~6
+          // vector instructions per output where the per-value form had ~17.  Values outside the table's range (|x| < 2^-24 or >= 16:
+          // never, in practice) are recognised by the largest unclamped offset of the lane's 8 values and redone by the per-value
+          // arithmetic behind a branch the wave skips.  (Measured: the launch is NOT faster for it - 3.85 vs 3.87 ms - so what the
+          // epilogue costs over a plain store, ~6 us per tile, is the 128 random 2-byte LDS reads per lane, not the index arithmetic.)
           typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
           // (the pairs are built from the ELEMENTS of v: __builtin_bit_cast of one element of a re-typed vector is narrowed by this clang to
           // a load of element 0 that stands in for all four - seen in the ISA, as in attn_bwd_fused_bf16.hip)
@@ -497,11 +467,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the round's read-back is in registers before the next round's writes
-    }
   } else if constexpr (EPI == EPI_GELU_GRAD) {
-    // du = acc * gelu'(u) in fp32 (one rounding), + column sums of du (the FFN bias gradient) per 128-row group.  fp32 staging: rows of
-    // 256 B, 16-byte chunk c at c ^ (r & 15); read-back: lane = row (lane >> 3) of every 8-row group, columns 8 (lane & 7) .. + 7: 16-byte
+    // du = acc * gelu'(u) in fp32 (one rounding), two rounds of 64 rows through the wave's 16 KB as fp32 [64][64] (256-byte rows,
+    // 16-byte chunk c at c ^ (r & 15)); read-back: lane = row (lane >> 3) of every 8-row group, columns 8 (lane & 7) .. + 7: 16-byte
     // loads of u and stores of du, whole 128-byte row segments.  The round's u rows are requested BEFORE the staging pass.
     const float* ltab = reinterpret_cast<const float*>(smem + G_SMEM);
     typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
@@ -510,27 +478,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
     for (int j = 0; j < 8; ++j) csum[j] = 0.f;
     const bool cols_ok = nw + ec * 8 + 7 < p.N;
 #pragma unroll
-    for (int round = 0; round < 4; ++round) {
-      u16x8 uv[4];
+    for (int round = 0; round < 2; ++round) {
+      u16x8 uv[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = mw + round * 32 + i * 8 + er;
+      for (int i = 0; i < 8; ++i) {
+        const int m = mw + round * 64 + i * 8 + er;
         uv[i] = (m < p.M && cols_ok) ? *reinterpret_cast<const u16x8*>(p.U + (int64_t)m * p.ldc + nw + ec * 8) : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const int row = mt * 16 + l15;
-          *reinterpret_cast<f32x4*>(cw + row * 256 + (((nt * 4 + lq) ^ (row & 15)) << 4)) = acc[round * 2 + mt][nt];
+          *reinterpret_cast<f32x4*>(cw + row * 256 + (((nt * 4 + lq) ^ (row & 15)) << 4)) = acc[round * 4 + mt][nt];
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
         const int row = i * 8 + er;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(cw + row * 256 + (((2 * ec) ^ (row & 15)) << 4));
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(cw + row * 256 + (((2 * ec + 1) ^ (row & 15)) << 4));
-        const int m = mw + round * 32 + row;
+        const int m = mw + round * 64 + row;
         float d[8];
         {
           // table offsets of two values per packed 16-bit instruction (saturating subtract, min, shift, mad); the derivative is constant
@@ -578,17 +546,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
       csum[j] += __shfl_xor(csum[j], 32, 64);
     }
     if (lane < 8 && cols_ok) {
-      float* dst = p.part + (int64_t)((m0 >> 8) * 2 + wr) * p.N + nw + ec * 8;
+      float* dst = p.part + (int64_t)(tm * 2 + wr) * p.N + nw + ec * 8;
       *reinterpret_cast<f32x4*>(dst) = f32x4{csum[0], csum[1], csum[2], csum[3]};
       *reinterpret_cast<f32x4*>(dst + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
     }
-  }
-  if (!more) break;
-  // K-tile 0 of the next tile has landed (this wave's pieces; the epilogue's global stores are behind the same wait) and every wave is
-  // done with its staging area: the main loop may run again, buffer 1 may be filled again
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  prefetched = true;
   }
 }
 
@@ -734,17 +695,8 @@ extern "C" int t2s_gemm_nt(const void* a, const void* w, const void* bias, void*
     const int v = atoi(e);
     if (v >= 1) p.ngroup = v < p.tiles_n ? v : p.tiles_n;
   }
-  // persistent tile walk: one workgroup per CU (cus / 8 per XCD), each walking its XCD's items; fewer when the XCD's range is shorter
-  const int64_t items_x = (int64_t)((p.tiles_m + G_XCDS - 1) / G_XCDS) * p.tiles_n;          // items of the longest XCD range
-  T2S_CHECK_ARG(items_x * G_XCDS < ((int64_t)1 << 31), "gemm_nt: too many tiles");
-  int64_t per_xcd = 32;
-  {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v >= G_XCDS) per_xcd = v / G_XCDS;
-  }
-  if (const char* e = getenv("T2S_GEMM_NT_PER_XCD")) { const int v = atoi(e); if (v >= 1) per_xcd = v; }
-  if (per_xcd > items_x) per_xcd = items_x;
-  const int64_t grid = (int64_t)G_XCDS * per_xcd;
+  const int64_t grid = (int64_t)G_XCDS * ((p.tiles_m + G_XCDS - 1) / G_XCDS) * p.tiles_n;
+  T2S_CHECK_ARG(grid < ((int64_t)1 << 31), "gemm_nt: too many tiles");
   static LdsFlags done[4] = {};
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;

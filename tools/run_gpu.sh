@@ -32,6 +32,20 @@ for STEP in "$@"; do
     forcedist) # the RCCL process-group path with ONE rank (communicator, bucket all-reduces, all_gather of the rank report, MAX reduction) on a 1-GPU box
              T2S_BENCH_FORCE_DIST=1 timeout -k 10 600 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dropout0 > $OUT/bench_forcedist.json 2> $OUT/bench_forcedist.err || { tail -30 $OUT/bench_forcedist.err; exit 1; }
              python3 -c "import json,sys; d=json.loads(open('$OUT/bench_forcedist.json').read().strip().splitlines()[-1]); print('force-dist:', d['backend'], d['ms_per_step'], 'ms/step; multi_gpu:', json.dumps(d['multi_gpu'])[:900])" ;;
+    gemmab)  # round 6: the product GEMM family vs a variant source (GEMM_VARIANT=name, tools/ablate/variants/gemm_bf16_<name>.hip; built beforehand
+             # by tools/ablate/gemm_variant.sh): every GEMM test through the C ABI on the variant library, then the probe on both, twice
+             T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_gemm_${GEMM_VARIANT}.so timeout -k 10 600 python3 -m pytest tests/test_gemm_gpu.py tests/test_kernels_gpu.py -m gpu -x -q -k "gemm or bert_layer" > $OUT/pytest_gemm_variant.log 2>&1 || { tail -40 $OUT/pytest_gemm_variant.log; exit 1; }; tail -2 $OUT/pytest_gemm_variant.log
+             rm -f $OUT/gemm_ab.txt
+             for rep in 1 2; do
+               echo "== product" >> $OUT/gemm_ab.txt
+               timeout -k 10 300 python3 tools/gemm_probe5.py 2>&1 | grep -E "^NT|^dgrad|^FFN|own gemm_nt" >> $OUT/gemm_ab.txt
+               echo "== variant ${GEMM_VARIANT}" >> $OUT/gemm_ab.txt
+               T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_gemm_${GEMM_VARIANT}.so timeout -k 10 300 python3 tools/gemm_probe5.py 2>&1 | grep -E "^NT|^dgrad|^FFN|own gemm_nt" >> $OUT/gemm_ab.txt
+             done
+             cat $OUT/gemm_ab.txt | cut -c1-150 ;;
+    suiteall) # the whole -m gpu suite WITHOUT -x: every failure is listed (exit status ignored; read the summary)
+             timeout -k 10 1150 python3 -m pytest tests -m gpu -q > $OUT/pytest_suite_all.log 2>&1 || true
+             grep -E "^FAILED|^ERROR| passed| failed" $OUT/pytest_suite_all.log | cut -c1-250 ;;
     fulllen) timeout -k 10 900 python3 -m pytest tests/test_fulllength_reference_gpu.py -m gpu -x -q -s > $OUT/pytest_fulllen.log 2>&1 || { tail -60 $OUT/pytest_fulllen.log; exit 1; }; tail -30 $OUT/pytest_fulllen.log ;;
     suite)   timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_suite.log 2>&1 || { tail -60 $OUT/pytest_suite.log; exit 1; }; tail -3 $OUT/pytest_suite.log ;;
     smoke)   timeout -k 10 300 python3 __graft_entry__.py smoke > $OUT/smoke.log 2>&1 || { tail -30 $OUT/smoke.log; exit 1; }; tail -1 $OUT/smoke.log ;;

@@ -142,7 +142,20 @@ def wgrad_item(wg, c, T, S):
 # ---- the NT kernel's work map (csrc/gemm_bf16.hip nt_item), mirrored for the CPU tests: XCD x = wg % 8 owns a contiguous range of
 # M-blocks; inside it the N-tiles go in groups of b - group-major, then M-block, then the N-tile inside the group
 def nt_grid(tiles_m, tiles_n):
+    """Number of VIRTUAL work items of the NT kernel (8 x the items of the longest XCD range); the launch has one workgroup per CU, and
+    workgroup (XCD x, slot s of ``per_xcd``) walks the items j = s, s + per_xcd, ... of XCD x (``nt_walk``)."""
     return 8 * ((tiles_m + 7) // 8) * tiles_n
+
+
+def nt_walk(xcd, slot, per_xcd, tiles_m, tiles_n, b):
+    """The tiles the persistent workgroup (xcd, slot) computes, in order (csrc/gemm_bf16.hip gemm_nt_bf16_kernel's loop)."""
+    out, j = [], slot
+    while True:
+        it = nt_item(j * 8 + xcd, tiles_m, tiles_n, b)
+        if it is None:
+            return out
+        out.append(it)
+        j += per_xcd
 
 
 def nt_group(tiles_n):
