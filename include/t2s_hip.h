@@ -333,7 +333,8 @@ int t2s_adam_step(const int64_t* desc, const int32_t* chunks, int n_chunks, cons
  * Replace the torch.nn.Linear calls inside the third-party BertSelfOutput / BertIntermediate / BertOutput the reference runs at
  * pythia/models/t2s.py:423-427, 538-542, 622-626 - and their autograd gradients, stepped by
  * pythia/trainers/base_trainer.py:262-272 - where an epilogue a library GEMM cannot fuse pays: bf16 operands, fp32 accumulation,
- * 256 x 256 x 64 tiles on the 8-phase LDS-DMA pipeline.
+ * 256 x 256 x 64 tiles on the 8-phase LDS-DMA pipeline; t2s_gemm_nt launches one PERSISTENT workgroup per CU that
+ * walks its XCD's tiles and fetches the next tile's first K-tile under the current tile's epilogue (round 6).
  *
  * t2s_gemm_nt:  C[M, N] = A[M, K] W[N, K]^T, row strides lda / ldw / ldc (elements; multiples of 8), K a multiple of 128, N of 8.
  *   epilogue 0  C = bf16(acc + bias)                  (bias [N] bf16 or NULL)                       nn.Linear forward / dgrad
