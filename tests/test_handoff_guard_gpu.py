@@ -73,11 +73,16 @@ def test_the_optimizer_step_behind_a_timed_out_handoff_is_a_noop_and_the_next_on
     assert torch.isnan(norm), "the reported norm of a gated step is NaN"
     assert torch.equal(w.detach(), w1) and torch.equal(opt.state[w]["exp_avg"], m1), "the gated step must not touch parameters or moments"
     assert torch.isnan(w.grad).all()
+    assert float(opt.state[w]["step"]) == 2.0               # (the host counted the gated step: it learns of the gate one step later)
     w.grad = torch.randn_like(w)
     with pytest.raises(ops.HandoffTimeout):
         opt.step_clipped(0.25)                               # the previous step's status word has reached the host
     assert ops.fused_handoff_status() == 0
+    # the gated step applied nothing, so its count is taken back before the exception leaves - a trainer that catches the
+    # error and carries on gets the bias correction of the updates that were really applied
+    assert float(opt.state[w]["step"]) == 1.0
     opt.step_clipped(0.25)                                   # training could go on (from a checkpoint) once the cause is gone
+    assert float(opt.state[w]["step"]) == 2.0
     torch.cuda.synchronize()
     assert not torch.equal(w.detach(), w1) and torch.isfinite(w).all()
 
