@@ -174,3 +174,40 @@ def test_bert_layer_with_own_gemms_equals_the_library_form(monkeypatch):
         if "key.bias" in n:
             continue
         assert rel < 2e-2, "%s: own vs library GEMMs rel %.3e" % (n, rel)
+
+
+@pytest.mark.parametrize("per_xcd", ["1", "2", "5"])
+def test_persistent_nt_walk_long_walks_are_exact(per_xcd, monkeypatch):
+    """Round 6: the NT kernel is persistent (one workgroup per CU walks its XCD's tiles; K-tile 0 of the next tile is fetched under the
+    current tile's epilogue; the epilogue stages through LDS buffer 1 only).  On a 256-CU card the unit tests' shapes give most workgroups a
+    single tile - here the probe knob T2S_GEMM_NT_PER_XCD (read per call) shrinks the grid to 8 / 16 / 40 workgroups, so EVERY workgroup
+    walks many tiles through the prefetched continuation, for all four epilogues; exact-integer operands make a stale LDS buffer, a tile
+    computed twice or skipped, or a wrong row of the staging rounds show as a wrong integer."""
+    from vitxt_gqa_amd import gemm as G
+    monkeypatch.setenv("T2S_GEMM_NT_PER_XCD", per_xcd)
+    M, N, K = 9 * 256 + 77, 1280, 384                      # 10 x 5 tiles, ragged last M-block; 6 K-tiles
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ai = torch.randint(-3, 4, (M, K), device="cuda", generator=g).to(torch.bfloat16)
+    wi = torch.randint(-3, 4, (N, K), device="cuda", generator=g).to(torch.bfloat16)
+    bi = torch.randint(-2, 3, (N,), device="cuda", generator=g).to(torch.bfloat16)
+    want = _ref(ai, wi) + bi.double()                      # |values| <= 9 * 384 + 2: exact in fp32, rounded once to bf16
+    out = G.gemm_nt(ai, wi, bi)
+    assert torch.equal(out.double(), want.to(torch.bfloat16).double())
+    c0 = torch.randint(-4, 5, (M, N), device="cuda", generator=g).to(torch.bfloat16)
+    c = c0.clone()
+    G.gemm_nt(ai, wi, out=c, accumulate=True)
+    assert torch.equal(c.double(), (c0.double() + _ref(ai, wi).to(torch.bfloat16).double()).to(torch.bfloat16).double())
+    # the two GELU forms against the standalone kernels on the same pre-activation / product
+    from vitxt_gqa_amd import ops
+    a, w = _mk(M, N, K, 7)
+    w = (w.float() * 0.05).to(torch.bfloat16)
+    bias = (torch.randn(N, device="cuda") * 0.1).to(torch.bfloat16)
+    u, gact = G.gemm_nt_gelu_dual(a, w, bias)
+    u_ref = G.gemm_nt(a, w, bias)
+    assert torch.equal(u, u_ref) and torch.equal(gact, ops.gelu_fwd(u_ref))
+    du, db = G.gemm_nt_gelu_grad(a, w, u)
+    prod = _ref(a, w)
+    x = u.double()
+    gp = 0.5 * (1 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+    _check_bf16(du, prod * gp, "persistent walk, gelu' epilogue, per_xcd %s" % per_xcd)
+    assert (db.double() - (prod * gp).sum(0)).abs().max().item() < 2e-3 * (prod * gp).abs().sum(0).max().item() + 1e-2
