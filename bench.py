@@ -243,19 +243,52 @@ def gather_rank_report(local, device=None, group=None):
                     "GradBuckets.finish(); handoff_status = the rank's sticky status word of the fused attention backward (0 = clean)"}
 
 
+RCCL_LOG = None          # rank 0: file RCCL's INFO log of the communicator set-up goes to (request_rccl_init_log), parsed by comm_environment
+
+
+def request_rccl_init_log():
+    """Rank 0, before the process group exists: have RCCL write its INFO log of the INIT subsystem to a private file (NCCL_DEBUG_FILE), so
+    that the bench line can say how many channels the communicator really got and over which transport the ring runs - not only whether
+    the environment pinned them.  An NCCL_DEBUG the user set is left alone (its output then goes where the user sent it)."""
+    global RCCL_LOG
+    if "NCCL_DEBUG" in os.environ:
+        return
+    import tempfile
+    RCCL_LOG = os.path.join(tempfile.gettempdir(), "t2s_bench_rccl_init.%d.log" % os.getpid())
+    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=RCCL_LOG)
+
+
+def _parse_rccl_log(path):
+    """-> {"coll_channels": n, "p2p_channels": n, "lines": [the channel / ring / transport summary lines]} or None."""
+    import re
+    try:
+        text = open(path, errors="replace").read()
+    except OSError:
+        return None
+    keep = [ln.split("NCCL INFO", 1)[-1].strip() for ln in text.splitlines()
+            if re.search(r"coll channels|Channel 00|Connected all rings|Connected all trees|nRanks|via P2P|via SHM|via NET|Ring 00", ln)]
+    out = {"lines": keep[:12]}
+    m = re.search(r"(\d+) coll channels.*?(\d+) p2p channels", text)
+    if m:
+        out["coll_channels"], out["p2p_channels"] = int(m.group(1)), int(m.group(2))
+    return out
+
+
 def comm_environment():
-    """The communication-side settings a scaling post-mortem asks for first: RCCL version and every NCCL_* / RCCL_* / HSA_* / HIP_* /
-    GPU_* / ROCR_* variable of the process (channel counts are RCCL's to choose unless NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS pin
-    them; this records whether they were pinned)."""
+    """The communication-side settings a scaling post-mortem asks for first: RCCL version, every NCCL_* / RCCL_* / HSA_* / HIP_* /
+    GPU_* / ROCR_* variable of the process, whether NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS pinned the channel counts, and - parsed from
+    RCCL's own INIT log of this run (request_rccl_init_log) - the number of collective / p2p channels the communicator got."""
     env = {k: v for k, v in sorted(os.environ.items()) if k.split("_")[0] in ("NCCL", "RCCL", "HSA", "HIP", "GPU", "ROCR")}
     ver = None
     try:
         ver = ".".join(str(x) for x in torch.cuda.nccl.version())
     except Exception:          # a build without the binding: not fatal for a report field
         pass
+    log = _parse_rccl_log(RCCL_LOG) if RCCL_LOG else None
     return {"rccl_version": ver, "env": env,
             "channels": {"NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
-                         "pinned": "NCCL_MIN_NCHANNELS" in os.environ or "NCCL_MAX_NCHANNELS" in os.environ}}
+                         "pinned": "NCCL_MIN_NCHANNELS" in os.environ or "NCCL_MAX_NCHANNELS" in os.environ,
+                         "from_rccl_init_log": log}}
 
 
 def spawn_ranks(n):
@@ -341,6 +374,8 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
+            if rank == 0:
+                request_rccl_init_log()
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
