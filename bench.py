@@ -251,7 +251,9 @@ def request_rccl_init_log():
     that the bench line can say how many channels the communicator really got and over which transport the ring runs - not only whether
     the environment pinned them.  An NCCL_DEBUG the user set is left alone (its output then goes where the user sent it)."""
     global RCCL_LOG
-    if "NCCL_DEBUG" in os.environ:
+    # (a bare NCCL_DEBUG=VERSION / WARN - what this image exports - prints next to nothing and is raised to INFO into the private file;
+    # a user's INFO / TRACE setting or an NCCL_DEBUG_FILE of their own is left alone)
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() not in ("VERSION", "WARN") or "NCCL_DEBUG_FILE" in os.environ:
         return
     import tempfile
     RCCL_LOG = os.path.join(tempfile.gettempdir(), "t2s_bench_rccl_init.%d.log" % os.getpid())
@@ -271,6 +273,10 @@ def _parse_rccl_log(path):
     m = re.search(r"(\d+) coll channels.*?(\d+) p2p channels", text)
     if m:
         out["coll_channels"], out["p2p_channels"] = int(m.group(1)), int(m.group(2))
+    m = re.search(r"Channel \d+/(\d+)", text)
+    if m:
+        out["channels_listed"] = int(m.group(1))
+    out["lines"] = [ln for ln in out["lines"] if not re.match(r"Channel (?!00)", ln)][:12]          # one "Channel 00/NN" line stands for the list
     return out
 
 
@@ -288,7 +294,7 @@ def comm_environment():
     return {"rccl_version": ver, "env": env,
             "channels": {"NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"), "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
                          "pinned": "NCCL_MIN_NCHANNELS" in os.environ or "NCCL_MAX_NCHANNELS" in os.environ,
-                         "from_rccl_init_log": log}}
+                         "from_rccl_init_log": log, "rccl_init_log_requested_by_bench": RCCL_LOG is not None}}
 
 
 def spawn_ranks(n):
