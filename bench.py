@@ -268,7 +268,7 @@ def _parse_rccl_log(path):
     except OSError:
         return None
     keep = [ln.split("NCCL INFO", 1)[-1].strip() for ln in text.splitlines()
-            if re.search(r"coll channels|Channel 00|Connected all rings|Connected all trees|nRanks|via P2P|via SHM|via NET|Ring 00", ln)]
+            if re.search(r"coll channels|Channel 00/|Connected all rings|Connected all trees|nNodes|Ring 0+ :|00/0+ .*via ", ln)]
     out = {"lines": keep[:12]}
     m = re.search(r"(\d+) coll channels.*?(\d+) p2p channels", text)
     if m:
@@ -276,7 +276,7 @@ def _parse_rccl_log(path):
     m = re.search(r"Channel \d+/(\d+)", text)
     if m:
         out["channels_listed"] = int(m.group(1))
-    out["lines"] = [ln for ln in out["lines"] if not re.match(r"Channel (?!00)", ln)][:12]          # one "Channel 00/NN" line stands for the list
+    # (one "Channel 00/NN" / "Ring 0" line stands for its list)
     return out
 
 
