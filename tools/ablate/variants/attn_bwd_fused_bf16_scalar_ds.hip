@@ -186,17 +186,6 @@ __device__ __forceinline__ bf16x8 fb_tr(const char* base, const int (&va2)[2]) {
   return __builtin_bit_cast(bf16x8, c);
 }
 
-// the same from two ABSOLUTE LDS byte addresses held in vector registers plus a compile-time offset: the offset rides in the instruction's
-// 16-bit offset field (base + constant in a scalar register, as the compiler forms it for fb_tr, costs a v_add_u32 per read)
-__device__ __forceinline__ bf16x8 fb_tr_abs(const int (&abs2)[2], const int off) {
-  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uint32_t)(abs2[0] + off));
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(uint32_t)(abs2[1] + off));
-  const s16x8 c = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, c);
-}
-
 __device__ __forceinline__ uint32_t fb_pack2(float a, float b) {
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(uint32_t, bf16x2_t{(__bf16)a, (__bf16)b});
@@ -255,36 +244,17 @@ __device__ __forceinline__ void fb_ve(f32x16 (&sacc)[2], uint32_t (&pfw)[8], con
     pfw[M] = fb_pack2(p0, p1);
   }
 }
-// chunks m, m + 1 of dS of block I: P * dP' (dP' = dP - delta from the seeded chain), or with dropout P * (dP * M / (1-p) - delta).
-// The two scores of a chunk sit in an even-aligned register pair (accumulator registers 2m, 2m + 1), and so do their row constants:
-// the fp32 arithmetic runs as PACKED instructions (v_pk_fma_f32 / v_pk_mul_f32: two fp32 lanes per issue slot, the same IEEE results
-// as the scalar forms) - one VALU slot per score instead of two (round 6: one wave per SIMD issues in order, every slot counts).
-// A packed instruction right behind the one it depends on costs a wait state (the compiler pads an s_nop), so the chunks go through
-// in PAIRS, stage by stage - mask, mask, fma, fma, mul, mul, cvt, cvt - and the pair may be cut in two (HEAD: up to the fma; TAIL:
-// the rest) so that a slot's single-chunk MFMA groups carry half a pair each.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int I, int M, bool DROP, bool HEAD, bool TAIL_>
-__device__ __forceinline__ void fb_vm2(const f32x16 (&sacc)[2], const f32x16 (&dpacc)[2], uint32_t (&dsw)[8], const uint32_t (&mw)[8], const f32x4 (&dl)[4],
-                                       const float inv, f32x2 (&t)[2]) {
+// chunk m of dS of block I: P * dP' (dP' = dP - delta from the seeded chain), or with dropout P * (dP * M / (1-p) - delta)
+template <int I, int M, bool DROP>
+__device__ __forceinline__ void fb_vm(const f32x16 (&sacc)[2], const f32x16 (&dpacc)[2], uint32_t (&dsw)[8], const uint32_t (&mw)[8], const float nd0,
+                                      const float nd1, const float inv) {
   constexpr int par = I & 1;
-  static_assert((M & 1) == 0, "chunk pairs");
-  if constexpr (HEAD) {
-    if (DROP) {
-      // (one v_and_b32_sdwa per score: the kept-half word, sign-extended by the operand selector, is the fp32 mask)
-      const f32x2 d0 = {attn_drop_keep_lo(dpacc[par][2 * M], mw[M]), attn_drop_keep_hi(dpacc[par][2 * M + 1], mw[M])};
-      const f32x2 d1 = {attn_drop_keep_lo(dpacc[par][2 * M + 2], mw[M + 1]), attn_drop_keep_hi(dpacc[par][2 * M + 3], mw[M + 1])};
-      t[0] = __builtin_elementwise_fma(d0, f32x2{inv, inv}, f32x2{dl[M >> 1][0], dl[M >> 1][1]});
-      t[1] = __builtin_elementwise_fma(d1, f32x2{inv, inv}, f32x2{dl[M >> 1][2], dl[M >> 1][3]});
-    } else {
-      t[0] = f32x2{dpacc[par][2 * M], dpacc[par][2 * M + 1]};
-      t[1] = f32x2{dpacc[par][2 * M + 2], dpacc[par][2 * M + 3]};
-    }
-  }
-  if constexpr (TAIL_) {
-    const f32x2 r0 = f32x2{sacc[par][2 * M], sacc[par][2 * M + 1]} * t[0];
-    const f32x2 r1 = f32x2{sacc[par][2 * M + 2], sacc[par][2 * M + 3]} * t[1];
-    dsw[M] = fb_pack2(r0[0], r0[1]);
-    dsw[M + 1] = fb_pack2(r1[0], r1[1]);
+  if (DROP) {
+    // (one v_and_b32_sdwa per score: the kept-half word, sign-extended by the operand selector, is the fp32 mask)
+    const float d0 = attn_drop_keep_lo(dpacc[par][2 * M], mw[M]), d1 = attn_drop_keep_hi(dpacc[par][2 * M + 1], mw[M]);
+    dsw[M] = fb_pack2(sacc[par][2 * M] * __builtin_fmaf(d0, inv, nd0), sacc[par][2 * M + 1] * __builtin_fmaf(d1, inv, nd1));
+  } else {
+    dsw[M] = fb_pack2(sacc[par][2 * M] * dpacc[par][2 * M], sacc[par][2 * M + 1] * dpacc[par][2 * M + 1]);
   }
 }
 
@@ -518,14 +488,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int dq_qb = wave_u >> 1, dq_db = wave_u & 1;          // this wave's 32 x 32 tile of dQ (provably wave-uniform)
-    // this wave's two operand address pairs of the dQ product, as ABSOLUTE LDS byte addresses (dS^T image / K image + the lane's offsets):
-    // a step's constant then rides in the read's 16-bit offset field (scalar base + constant and a vector offset: one v_add_u32 per read).
-    // FB_ABS_HERE() re-defines them, as far as the compiler can tell, in the basic block that reads through them: "address + constant" is
-    // loop-invariant, and hoisted out of the sweep (or merely out of the block: instruction selection folds offsets per block) the 84
-    // sums of a tile's dQ reads take registers this kernel does not have - they came back as one v_add_u32 per read, or from scratch.
-#define FB_ABS_HERE() asm("" : "+v"(vaq_abs[0]), "+v"(vaq_abs[1]), "+v"(vad_abs[0]), "+v"(vad_abs[1]))
-    int vaq_abs[2] = {(int)fb_lds_addr(dsimg) + (dq_qb ? vads[1][0] : vads[0][0]), (int)fb_lds_addr(dsimg) + (dq_qb ? vads[1][1] : vads[0][1])};
-    int vad_abs[2] = {(int)fb_lds_addr(kimg) + (dq_db ? va[1][0] : va[0][0]), (int)fb_lds_addr(kimg) + (dq_db ? va[1][1] : va[0][1])};
+    const int vaq[2] = {dq_qb ? vads[1][0] : vads[0][0], dq_qb ? vads[1][1] : vads[0][1]};
+    const int vad[2] = {dq_db ? va[1][0] : va[0][0], dq_db ? va[1][1] : va[0][1]};
     // EDGE: first tile row that sees this lane's key of block kb (prefix keys: every row; keys past the list: none)
     int qmin[FB_KB];
 #pragma unroll
@@ -681,7 +645,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         const int rowb = qt * FB_QROWS + 4 * lh;
 #define FB_THR(i_) if (EDGE) thr[(i_) & 1] = qmin[(i_) % 3] - rowb - ((i_) / 3) * 32;
         uint32_t pfw[8], dsw[8];
-        f32x2 dst[2];                 // the chunk pair of dS in flight between two MFMA groups
         // 8-byte stores of rows lr and lr + 1 would hit the same LDS banks (the chunk swizzle ignores bit 0 of the row, and an
         // 8-byte store spans half a chunk): odd rows take the other half of the chunk - 10 % of this kernel's LDS cycles were
         // bank conflicts of these stores (profiles/mfma_busy.json, round 2 / 3)
@@ -700,9 +663,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #define FB_G1(i_, m_) fb_g1<i_, m_, DROP>(sacc, dpacc, qf, dof, kf, vf)
 #define FB_G2(i_, m_) fb_g2<i_, m_>(dvacc, dkacc, doT, qT, pfw, dsw)
 #define FB_E(i_, m_) fb_ve<i_, m_, EDGE, DROP>(sacc, pfw, thr[(i_) & 1], mw, rkw, ck2[(i_) % 3], th2)
-#define FB_M2(i_, m_) fb_vm2<i_, m_, DROP, true, true>(sacc, dpacc, dsw, mw, dl, drop_inv, dst)
-#define FB_M2H(i_, m_) fb_vm2<i_, m_, DROP, true, false>(sacc, dpacc, dsw, mw, dl, drop_inv, dst)
-#define FB_M2T(i_, m_) fb_vm2<i_, m_, DROP, false, true>(sacc, dpacc, dsw, mw, dl, drop_inv, dst)
+#define FB_M(i_, m_) fb_vm<i_, m_, DROP>(sacc, dpacc, dsw, mw, dl[(m_) >> 1][2 * ((m_) & 1)], dl[(m_) >> 1][2 * ((m_) & 1) + 1], drop_inv)
         // slot "G1(n) + E(e)": eight groups of one MFMA of G1(b_n) and one chunk of E(b_e)
 #define FB_SLOT_G1E(n_, e_)                                                                         \
   FB_THR(e_); FB_LD_RK(e_);                                                                         \
@@ -712,12 +673,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // slot "G2(i) + M(i)": dV^T MFMAs with two chunks of M each, then the dK^T MFMAs beside the dS^T stores
 #define FB_SLOT_G2M(i_)                                                                             \
   FB_LD_DL(i_);                                                                                     \
-  FB_G2(i_, 0); FB_M2(i_, 0); FB_FENCE(); FB_G2(i_, 1); FB_M2(i_, 2); FB_FENCE();                                                \
-  FB_G2(i_, 2); FB_M2H(i_, 4); FB_FENCE(); FB_G2(i_, 3); FB_M2T(i_, 4); FB_FENCE();                                               \
+  FB_G2(i_, 0); FB_M(i_, 0); FB_M(i_, 1); FB_FENCE(); FB_G2(i_, 1); FB_M(i_, 2); FB_M(i_, 3); FB_FENCE();                        \
+  FB_G2(i_, 2); FB_M(i_, 4); FB_FENCE(); FB_G2(i_, 3); FB_M(i_, 5); FB_FENCE();                                                   \
   /* the dK^T MFMAs of s = 0 need chunks 0..3 only: chunks 6, 7 of dS are formed beside the first of them (an MFMA group ahead of */   \
   /* the s = 1 MFMAs that read them: the asm MFMAs get no hazard nops), the seeds of block i + 2 are fetched once the last chunk */     \
   /* has read this block's accumulators, the dS^T stores follow */                                                                   \
-  FB_G2(i_, 4); FB_M2(i_, 6); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE(); \
+  FB_G2(i_, 4); FB_M(i_, 6); FB_M(i_, 7); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE(); \
   FB_G2(i_, 6); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
         if (!PREF) { FB_LD_QF(qb_, dob_, 0); FB_LD_SEEDS(lse_s, del_s, 0); FB_LD_KF(0); }
         FB_FENCE();
@@ -729,11 +690,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   if ((k_) == 0) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dqacc) : "v"(FB_U4(afA[0])), "v"(FB_U4(bfA[0])));           \
   else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(afA[(k_) % 3])), "v"(FB_U4(bfA[(k_) % 3])));        \
   if ((k_) + 3 < FB_KEYS / 16) {                                                                    \
-    afA[(k_) % 3] = fb_tr_abs(vaq_abs, (16 * ((k_) + 3)) * 128);                                    \
-    bfA[(k_) % 3] = fb_tr_abs(vad_abs, (16 * ((k_) + 3)) * 128);                                    \
+    afA[(k_) % 3] = fb_tr(dsimg + (16 * ((k_) + 3)) * 128, vaq);                                    \
+    bfA[(k_) % 3] = fb_tr(kimg + (16 * ((k_) + 3)) * 128, vad);                                     \
   }                                                                                                 \
   FB_FENCE();
-          FB_ABS_HERE();
           FB_G1(0, 0); FB_LD_SEEDS(lse_s, del_s, 1); FB_FENCE(); FB_DQ_STEP(0); FB_DQ_STEP(1);
           FB_G1(0, 1); FB_FENCE(); FB_DQ_STEP(2); FB_DQ_STEP(3);
           FB_G1(0, 2); FB_FENCE(); FB_DQ_STEP(4); FB_DQ_STEP(5);
@@ -790,8 +750,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         FB_SLOT_G2M(3);
         FB_SLOT_G1E(5, 4);
         // slot "G2(b4) + M(b4) + E(b5)": E(b5) only behind the dV^T MFMAs of b4, which still read the operand words of P(b4)
-        FB_G2(4, 0); FB_M2(4, 0); FB_FENCE(); FB_G2(4, 1); FB_M2(4, 2); FB_FENCE();
-        FB_G2(4, 2); FB_M2(4, 4); FB_FENCE(); FB_G2(4, 3); FB_M2(4, 6); FB_FENCE();
+        FB_G2(4, 0); FB_M(4, 0); FB_M(4, 1); FB_FENCE(); FB_G2(4, 1); FB_M(4, 2); FB_M(4, 3); FB_FENCE();
+        FB_G2(4, 2); FB_M(4, 4); FB_M(4, 5); FB_FENCE(); FB_G2(4, 3); FB_M(4, 6); FB_M(4, 7); FB_FENCE();
         FB_THR(5); FB_LD_RK(5);
         FB_G2(4, 4); FB_ST_DS(4); FB_E(5, 0); FB_E(5, 1); FB_FENCE(); FB_G2(4, 5); FB_E(5, 2); FB_E(5, 3); FB_FENCE();
         FB_G2(4, 6); FB_E(5, 4); FB_E(5, 5); FB_FENCE(); FB_G2(4, 7); FB_E(5, 6); FB_E(5, 7); FB_FENCE();
@@ -804,9 +764,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_G1
 #undef FB_G2
 #undef FB_E
-#undef FB_M2
-#undef FB_M2H
-#undef FB_M2T
+#undef FB_M
 #undef FB_SLOT_G1E
 #undef FB_SLOT_G2M
         }
@@ -892,9 +850,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       // K^T fragments of the first steps of the dQ product: they do not depend on this tile, so they are fetched ahead of the barrier
       // (their registers were the transposed Q / dO fragments until a moment ago)
       if constexpr (ILV) {
-        FB_ABS_HERE();
 #pragma unroll
-        for (int u = 0; u < 3; ++u) bfA[u] = fb_tr_abs(vad_abs, (16 * u) * 128);
+        for (int u = 0; u < 3; ++u) bfA[u] = fb_tr(kimg + (16 * u) * 128, vad);
       }
       if constexpr (HO) {
         // every wave: its running-sum stores of the PREVIOUS tile have landed (the flag below is stored behind this wait and the
@@ -921,9 +878,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       if constexpr (ILV) {
         // the dQ product of this tile runs in slots 0 and 1 of the next one (or in the drain behind the loop): its first dS^T fragments and
         // the next tile's first operands (its stage buffer was published by the barrier above) are fetched here
-        FB_ABS_HERE();
+        const char* dsc_ = dsimg;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) afA[k] = fb_tr_abs(vaq_abs, (16 * k) * 128);
+        for (int k = 0; k < 3; ++k) afA[k] = fb_tr(dsc_ + (16 * k) * 128, vaq);
         const char* nq_ = stage + (buf ^ 1) * FB_STAGE;
         FB_LD_QF(nq_, nq_ + FB_TILE, 0);
         FB_LD_SEEDS(reinterpret_cast<const float*>(nq_ + 2 * FB_TILE), reinterpret_cast<const float*>(nq_ + 2 * FB_TILE) + FB_QROWS, 0);
@@ -934,8 +891,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqacc[i] = 0.f;
         // steps of 16 keys in groups of 4, the steps that hold valid keys (rows past them may never have been written)
-#define FB_DQ_LOAD_A(af_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) af_[u] = fb_tr_abs(vaq_abs, (16 * (4 * (g_) + u)) * 128);
-#define FB_DQ_LOAD_B(bf_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) bf_[u] = fb_tr_abs(vad_abs, (16 * (4 * (g_) + u)) * 128);
+#define FB_DQ_LOAD_A(af_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) af_[u] = fb_tr(dsimg + (16 * (4 * (g_) + u)) * 128, vaq);
+#define FB_DQ_LOAD_B(bf_, g_) _Pragma("unroll") for (int u = 0; u < 4; ++u) bf_[u] = fb_tr(kimg + (16 * (4 * (g_) + u)) * 128, vad);
 #define FB_DQ_LOAD(af_, bf_, g_) FB_DQ_LOAD_A(af_, g_) FB_DQ_LOAD_B(bf_, g_)
 #define FB_DQ_MFMA(af_, bf_)                                                                        \
   asm("s_nop 1\n\t"                                                                                \
@@ -955,7 +912,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
             FB_DQ_MFMA(af, bfr);
           }
           for (; k4 < nsteps; ++k4) {
-            const bf16x8 a1 = fb_tr_abs(vaq_abs, (16 * k4) * 128), b1 = fb_tr_abs(vad_abs, (16 * k4) * 128);
+            const bf16x8 a1 = fb_tr(dsimg + (16 * k4) * 128, vaq), b1 = fb_tr(kimg + (16 * k4) * 128, vad);
             asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(a1)), "v"(FB_U4(b1)));
           }
         }
