@@ -57,6 +57,11 @@ constexpr int G_XCDS = 8;
 // in global memory costs the tile ~26 us (64 distinct lines per wave-instruction); erff per element is ~60 VALU instructions.
 constexpr int G_TAB_LO = 103 * 128, G_TAB_HI = 131 * 128, G_TAB_RANGE = G_TAB_HI - G_TAB_LO;      // bf16 magnitudes [2^-24, 16)
 constexpr int G_SMEM_GRAD = G_SMEM + 2 * G_TAB_RANGE * 4, G_SMEM_DUAL = G_SMEM + 2 * G_TAB_RANGE * 2;
+// The bias of a tile's 256 columns goes through LDS as well (round 6): 2 tiles (current / next) x 4 wave columns x 256 B behind the tables,
+// one 4-byte-per-lane LDS-DMA per wave and tile, issued with the NEXT tile's K-tile 0.  As 16 conditional global loads per lane at the
+// head of the epilogue (the compiled form of `bias ? bias[n + j] : 0`) every one of them stood behind its own s_waitcnt vmcnt(0) - which
+// also waited for the K-tile 0 just requested: ~4 us of a 25 us tile at K = 768 (profiles/r06_gemm_bias_lds.txt).
+constexpr int G_BIAS_BYTES = 2048;
 
 enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_GELU_GRAD = 2, EPI_GELU_DUAL = 3, EPI_SLAB = 4 };
 
@@ -91,6 +96,9 @@ __device__ __forceinline__ uint32_t g_lds_addr(const char* p) { return (uint32_t
 // VMEM instruction to put its own vmcnt(0) behind, nor re-orders it (volatile + memory clobber); the waits are counted by hand.
 __device__ __forceinline__ void g_dma16(u32x4 rs, uint32_t lds, int voff, int soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void g_dma4(u32x4 rs, uint32_t lds, int voff, int soff) {       // 256 B: lane l lands at M0 + 4 l
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
 }
 #define G_BAR() asm volatile("s_barrier" ::: "memory")
 #define G_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -389,6 +397,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
       g_dma16(rs, dst + (uint32_t)pc * 1024u, lane * 16, (half * 0x8000 + G_TAB_LO) * ES + (pc - half * (PIECES / 2)) * 1024);
     }
   }
+  // bias of the tile's columns: wave column wc's 64 values (+ the 64 behind them, unused) into slot [tile parity][wc]; columns >= N and a
+  // null bias read as zeros (descriptor range).  The first tile's DMA is older than every tile DMA: the main loop's waits and barriers cover it
+  constexpr bool HAS_BIAS = EPI != EPI_GELU_GRAD;
+  constexpr int BIAS_OFF = EPI == EPI_GELU_DUAL ? G_SMEM_DUAL : G_SMEM;
+  const u32x4 rs_bias = g_rsrc(p.bias, p.bias ? (uint32_t)p.N * 2u : 0u);
+  const uint32_t bias_lds = __builtin_amdgcn_readfirstlane(g_lds_addr(smem + BIAS_OFF) + (uint32_t)wc * 256u);
+  int bias_buf = 0;
+  if constexpr (HAS_BIAS) g_dma4(rs_bias, bias_lds, (tn * 256 + wc * 64) * 2 + lane * 4, 0);     // (the VECTOR offset is the range-checked one)
   LoaderNT ld;
   ld.init(p, smem, tm * 256, tn * 256, wave, lane);
   bool prefetched = false;
@@ -413,6 +429,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
     ld.template stage<2>(0, 0);
     ld.template stage<3>(0, 0);
     ld.template stage<1>(0, 0);
+    if constexpr (HAS_BIAS) g_dma4(rs_bias, bias_lds + (uint32_t)(bias_buf ^ 1) * 1024u, (tn * 256 + wc * 64) * 2 + lane * 4, 0);
   }
 
   // ---- epilogue.  The wave's 128 x 64 outputs go through its own 8 KB of LDS in BUFFER 1 (buffer 0 is receiving the next tile's K-tile 0):
@@ -425,9 +442,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
     float b4[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const int n = nw + nt * 16 + 4 * lq;
+      const bf16x4 bb = *reinterpret_cast<const bf16x4*>(smem + BIAS_OFF + bias_buf * 1024 + wc * 256 + (nt * 16 + 4 * lq) * 2);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b4[nt][j] = (p.bias && n + j < p.N) ? (float)p.bias[n + j] : 0.f;
+      for (int j = 0; j < 4; ++j) b4[nt][j] = (float)bb[j];
     }
     const bool cols_ok = nw + ec * 8 + 7 < p.N;
     const unsigned short* ltab = reinterpret_cast<const unsigned short*>(smem + G_SMEM);
@@ -584,11 +601,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
     }
   }
   if (!more) break;
-  // K-tile 0 of the next tile has landed (this wave's pieces; the epilogue's global stores are behind the same wait) and every wave is
-  // done with its staging area: the main loop may run again, buffer 1 may be filled again
+  // K-tile 0 of the next tile and its bias have landed (this wave's pieces; the epilogue's global stores are behind the same wait) and every
+  // wave is done with its staging area: the main loop may run again, buffer 1 may be filled again.  (Vector-memory operations retire in issue
+  // order and the next tile's DMAs are OLDER than the epilogue's accesses, so a counted wait - vmcnt(16 / 32 / 34) on interior tiles - would
+  // leave the stores in flight under the next K-tile 0: measured, same box, no difference at any shape - 2.861 vs 2.869 ms at N = 3072,
+  // K = 768 (profiles/r06_gemm_bias_lds.txt) - the store drain is not what a tile waits for; the plain wait stays.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   prefetched = true;
+  bias_buf ^= 1;
   }
 }
 
@@ -750,20 +771,20 @@ extern "C" int t2s_gemm_nt(const void* a, const void* w, const void* bias, void*
   int rc = 0;
   switch (epilogue) {
     case EPI_STORE:
-      if ((rc = g_reserve_lds(gemm_nt_bf16_kernel<EPI_STORE>, done[0], "gemm_nt"))) return rc;
-      hipLaunchKernelGGL(gemm_nt_bf16_kernel<EPI_STORE>, dim3((unsigned)grid), dim3(512), G_SMEM, st, p);
+      if ((rc = g_reserve_lds(gemm_nt_bf16_kernel<EPI_STORE>, done[0], "gemm_nt", G_SMEM + G_BIAS_BYTES))) return rc;
+      hipLaunchKernelGGL(gemm_nt_bf16_kernel<EPI_STORE>, dim3((unsigned)grid), dim3(512), G_SMEM + G_BIAS_BYTES, st, p);
       break;
     case EPI_ACCUM:
-      if ((rc = g_reserve_lds(gemm_nt_bf16_kernel<EPI_ACCUM>, done[1], "gemm_nt"))) return rc;
-      hipLaunchKernelGGL(gemm_nt_bf16_kernel<EPI_ACCUM>, dim3((unsigned)grid), dim3(512), G_SMEM, st, p);
+      if ((rc = g_reserve_lds(gemm_nt_bf16_kernel<EPI_ACCUM>, done[1], "gemm_nt", G_SMEM + G_BIAS_BYTES))) return rc;
+      hipLaunchKernelGGL(gemm_nt_bf16_kernel<EPI_ACCUM>, dim3((unsigned)grid), dim3(512), G_SMEM + G_BIAS_BYTES, st, p);
       break;
     case EPI_GELU_GRAD:
       if ((rc = g_reserve_lds(gemm_nt_bf16_kernel<EPI_GELU_GRAD>, done[2], "gemm_nt", G_SMEM_GRAD))) return rc;
       hipLaunchKernelGGL(gemm_nt_bf16_kernel<EPI_GELU_GRAD>, dim3((unsigned)grid), dim3(512), G_SMEM_GRAD, st, p);
       break;
     default:
-      if ((rc = g_reserve_lds(gemm_nt_bf16_kernel<EPI_GELU_DUAL>, done[3], "gemm_nt", G_SMEM_DUAL))) return rc;
-      hipLaunchKernelGGL(gemm_nt_bf16_kernel<EPI_GELU_DUAL>, dim3((unsigned)grid), dim3(512), G_SMEM_DUAL, st, p);
+      if ((rc = g_reserve_lds(gemm_nt_bf16_kernel<EPI_GELU_DUAL>, done[3], "gemm_nt", G_SMEM_DUAL + G_BIAS_BYTES))) return rc;
+      hipLaunchKernelGGL(gemm_nt_bf16_kernel<EPI_GELU_DUAL>, dim3((unsigned)grid), dim3(512), G_SMEM_DUAL + G_BIAS_BYTES, st, p);
       break;
   }
   T2S_CHECK_LAUNCH("gemm_nt");
