@@ -98,6 +98,22 @@ PYEOF
                T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_${FB_VARIANT}.so timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 $dp 2>&1 | grep "bwd fused/handoff  " >> $OUT/fb_ab.txt
              done; done
              cat $OUT/fb_ab.txt | cut -c1-150 ;;
+    fbabm)   # several fused-backward variants (FB_VARIANTS="a b c", libraries prebuilt by tools/ablate/fb_variant.sh) against the product, same box,
+             # interleaved, dropout 0.1 (FB_DPS overrides): the fused-backward tests on each variant first, then FB_REPS (2) rounds of the probe
+             rm -f $OUT/fb_abm.txt
+             for v in ${FB_VARIANTS}; do
+               T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_$v.so timeout -k 10 600 python3 -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_dropout_gpu.py -m gpu -x -q -k "fused or handoff" > $OUT/pytest_fbv_$v.log 2>&1 || { tail -30 $OUT/pytest_fbv_$v.log; exit 1; }
+               echo "variant $v: $(tail -1 $OUT/pytest_fbv_$v.log)" | tee -a $OUT/fb_abm.txt
+             done
+             for dp in ${FB_DPS:-0.1}; do for rep in $(seq 1 ${FB_REPS:-2}); do
+               echo "== product, dropout $dp" >> $OUT/fb_abm.txt
+               T2S_PROBE_FORMS=shipped timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 $dp 2>&1 | grep "bwd fused/handoff  " >> $OUT/fb_abm.txt
+               for v in ${FB_VARIANTS}; do
+                 echo "== variant $v, dropout $dp" >> $OUT/fb_abm.txt
+                 T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_$v.so timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 $dp 2>&1 | grep "bwd fused/handoff  " >> $OUT/fb_abm.txt
+               done
+             done; done
+             cat $OUT/fb_abm.txt | cut -c1-150 ;;
     scope)   # hand-off cache-scope variants (SCOPE_VARIANTS="name:ld:st ..."): correctness subset, interleaved timing, HBM counters
              rm -f $OUT/scope.txt
              for v in ${SCOPE_VARIANTS:-st0:16:0}; do

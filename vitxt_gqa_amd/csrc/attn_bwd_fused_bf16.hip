@@ -31,6 +31,9 @@
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef FB_DQ_DEPTH
+#define FB_DQ_DEPTH 3                             // 16-key steps the operand reads of the interleaved dQ product run ahead of their MFMA (see afA / bfA)
+#endif
 constexpr int FB_KB = 3;                          // 32-key blocks per wave
 constexpr int FB_WKEYS = 32 * FB_KB;              // 96 keys per wave
 constexpr int FB_KEYS = 4 * FB_WKEYS;             // 384 keys per workgroup
@@ -555,7 +558,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     constexpr bool CAN_LAST = EDGE || !FULL;                 // hand-off: only an edge block (or the tail launch) can end a pair's chain
     bf16x8 qf[4], dof[4], kf[4];
     f32x16 sacc[2], dpacc[2];
-    bf16x8 afA[3], bfA[3];                         // operands of the dQ product in flight (three 16-key steps ahead: registers are tight)
+    // operands of the dQ product in flight, FB_DQ_DEPTH 16-key steps ahead.  3: measured against 5, 6 and 8 in round 6 (-DFB_DQ_DEPTH=n, same box,
+    // interleaved: 20.43 | 20.40 | 20.43 | 21.03 ms at B = 32; 8 spills) - the reads' cost in slots 0 / 1 is LDS occupancy, not their latency
+    bf16x8 afA[FB_DQ_DEPTH], bfA[FB_DQ_DEPTH];
     u32x4 pin[4];                                  // hand-off: the predecessor's running sum of the tile whose dQ is being formed
     f32x16 dqacc;
     const char* kw_ = kimg + wave * (FB_WKEYS * 128);
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
     }
     if constexpr (ILV) {   // (slots 0 / 1 of tile 0 multiply operands of a tile that does not exist: defined values, result dropped)
 #pragma unroll
-      for (int u = 0; u < 3; ++u) { afA[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; bfA[u] = afA[u]; }
+      for (int u = 0; u < FB_DQ_DEPTH; ++u) { afA[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; bfA[u] = afA[u]; }
 #pragma unroll
       for (int g = 0; g < 4; ++g) pin[g] = u32x4{0u, 0u, 0u, 0u};
     }
@@ -727,10 +732,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         if constexpr (ILV) {
 #define FB_DQ_STEP(k_)                                                                              \
   if ((k_) == 0) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dqacc) : "v"(FB_U4(afA[0])), "v"(FB_U4(bfA[0])));           \
-  else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(afA[(k_) % 3])), "v"(FB_U4(bfA[(k_) % 3])));        \
-  if ((k_) + 3 < FB_KEYS / 16) {                                                                    \
-    afA[(k_) % 3] = fb_tr_abs(vaq_abs, (16 * ((k_) + 3)) * 128);                                    \
-    bfA[(k_) % 3] = fb_tr_abs(vad_abs, (16 * ((k_) + 3)) * 128);                                    \
+  else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqacc) : "v"(FB_U4(afA[(k_) % FB_DQ_DEPTH])), "v"(FB_U4(bfA[(k_) % FB_DQ_DEPTH])));        \
+  if ((k_) + FB_DQ_DEPTH < FB_KEYS / 16) {                                                                    \
+    afA[(k_) % FB_DQ_DEPTH] = fb_tr_abs(vaq_abs, (16 * ((k_) + FB_DQ_DEPTH)) * 128);                                    \
+    bfA[(k_) % FB_DQ_DEPTH] = fb_tr_abs(vad_abs, (16 * ((k_) + FB_DQ_DEPTH)) * 128);                                    \
   }                                                                                                 \
   FB_FENCE();
           FB_ABS_HERE();
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       if constexpr (ILV) {
         FB_ABS_HERE();
 #pragma unroll
-        for (int u = 0; u < 3; ++u) bfA[u] = fb_tr_abs(vad_abs, (16 * u) * 128);
+        for (int u = 0; u < FB_DQ_DEPTH; ++u) bfA[u] = fb_tr_abs(vad_abs, (16 * u) * 128);
       }
       if constexpr (HO) {
         // every wave: its running-sum stores of the PREVIOUS tile have landed (the flag below is stored behind this wait and the
@@ -923,7 +928,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // the next tile's first operands (its stage buffer was published by the barrier above) are fetched here
         FB_ABS_HERE();
 #pragma unroll
-        for (int k = 0; k < 3; ++k) afA[k] = fb_tr_abs(vaq_abs, (16 * k) * 128);
+        for (int k = 0; k < FB_DQ_DEPTH; ++k) afA[k] = fb_tr_abs(vaq_abs, (16 * k) * 128);
         const char* nq_ = stage + (buf ^ 1) * FB_STAGE;
         FB_LD_QF(nq_, nq_ + FB_TILE, 0);
         FB_LD_SEEDS(reinterpret_cast<const float*>(nq_ + 2 * FB_TILE), reinterpret_cast<const float*>(nq_ + 2 * FB_TILE) + FB_QROWS, 0);
