@@ -98,6 +98,21 @@ PYEOF
                T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fbv_${FB_VARIANT}.so timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 $dp 2>&1 | grep "bwd fused/handoff  " >> $OUT/fb_ab.txt
              done; done
              cat $OUT/fb_ab.txt | cut -c1-150 ;;
+    fwdabm)  # several forward variants (FWD_VARIANTS="a b c", libraries prebuilt by tools/ablate/fwd_variant.sh) against the product, same box, interleaved
+             rm -f $OUT/fwd_abm.txt
+             for v in ${FWD_VARIANTS}; do
+               T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fwd_$v.so timeout -k 10 600 python3 -m pytest tests/test_kernels_gpu.py tests/test_dropout_gpu.py -m gpu -x -q -k "fwd or forward or dropout or attention" > $OUT/pytest_fwdv_$v.log 2>&1 || { tail -30 $OUT/pytest_fwdv_$v.log; exit 1; }
+               echo "variant $v: $(tail -1 $OUT/pytest_fwdv_$v.log)" | tee -a $OUT/fwd_abm.txt
+             done
+             for dp in ${FWD_DPS:-0.1}; do for rep in $(seq 1 ${FWD_REPS:-3}); do
+               echo "== product, dropout $dp" >> $OUT/fwd_abm.txt
+               T2S_PROBE_FORMS=shipped timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 $dp 2>&1 | grep "fwd " | sed -E 's/ \| bwd.*$//' >> $OUT/fwd_abm.txt
+               for v in ${FWD_VARIANTS}; do
+                 echo "== variant $v, dropout $dp" >> $OUT/fwd_abm.txt
+                 T2S_PROBE_FORMS=shipped T2S_HIP_LIB=$REPO/tools/ablate/_build/libt2s_fwd_$v.so timeout -k 10 300 python3 tools/attn_probe.py 32 10120 0.7 12 10 $dp 2>&1 | grep "fwd " | sed -E 's/ \| bwd.*$//' >> $OUT/fwd_abm.txt
+               done
+             done; done
+             cat $OUT/fwd_abm.txt | cut -c1-150 ;;
     fbabm)   # several fused-backward variants (FB_VARIANTS="a b c", libraries prebuilt by tools/ablate/fb_variant.sh) against the product, same box,
              # interleaved, dropout 0.1 (FB_DPS overrides): the fused-backward tests on each variant first, then FB_REPS (2) rounds of the probe
              rm -f $OUT/fb_abm.txt

@@ -36,6 +36,15 @@
 
 namespace {
 
+// FWD_PRIO_MODE (probe builds only, -DFWD_PRIO_MODE=n through tools/ablate/fwd_variant.sh): wave priority by stage of the steady-state tile -
+// 1: the MFMA-only stages A and D at s_setprio 1; 2: the softmax-carrying stages B and C at 1; 3: the whole tile at 1 in the waves of every
+// second workgroup (the two co-resident workgroups of a CU at different priorities).  0 (the product): no s_setprio; all three measured
+// in round 6 (profiles/r06_fwd_prio_ab.txt).
+#ifndef FWD_PRIO_MODE
+#define FWD_PRIO_MODE 0
+#endif
+#define FWD_PRIO(stage_ad_, v_)                                                                     \
+  if constexpr ((FWD_PRIO_MODE == 1 && (stage_ad_)) || (FWD_PRIO_MODE == 2 && !(stage_ad_))) __builtin_amdgcn_s_setprio(v_);
 constexpr int BK = 64;                     // keys per tile
 constexpr int TILE_BYTES = BK * 128;       // one 64-row bf16 tile image
 constexpr float BIG = 1.2089258e24f;       // 2^80
@@ -314,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     PACK_P_(qb_, kbk_, 0, buf, true);                                                               \
     PACK_P_(qb_, kbk_, 1, buf, true);                                                               \
   }
+    if constexpr (FWD_PRIO_MODE == 3) { if (blockIdx.x & 8) __builtin_amdgcn_s_setprio(1); }
     for (int t = 1; t < nfast; ++t) {
       const int buf = t & 1;
       STAGE_LOAD_ROWS();                                 // tile t+1 (after the last fast tile: an unused, harmless load)
@@ -325,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
         for (int qb = 0; qb < QB; ++qb) rk2[qb] = attn_drop_rowkey16w(rh[qb], (t * BK) / ATTN_DROP_KWIN) * 0x10001u;
       }
       __builtin_amdgcn_sched_barrier(0);
+      FWD_PRIO(true, 1);
       // stage A: S(key block 0), seeded
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -332,7 +343,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) sacc[qb][0] = mfma_bf16(kf, Q_FRAG(qb, s), s == 0 ? negm[qb] : sacc[qb][0]);
       }
+      FWD_PRIO(true, 0);
       __builtin_amdgcn_sched_barrier(0);
+      FWD_PRIO(false, 1);
       // stage B: S(key block 1) beside the softmax of key block 0
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -357,9 +370,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
       }
+      FWD_PRIO(false, 0);
       __builtin_amdgcn_sched_barrier(0);
+      FWD_PRIO(true, 1);
       // stage D: PV(key block 1)
       PV_MFMAS(vb, 1);
+      FWD_PRIO(true, 0);
       STAGE_WRITE(buf ^ 1);
       __syncthreads();
     }
