@@ -435,7 +435,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 
 template <bool DROP, bool REPAIR>
 void launch_fwd(const AttnParams& p, hipStream_t st) {
-  const bool wide = p.Lq > 256;       // 64 rows per wave once there is more than one workgroup of queries
+  // 64 rows per wave once there is more than one workgroup of queries.  (T2S_ATTN_FWD_QB1=1, probe runs: 32 rows per wave at every length -
+  // 157 registers and 48 KB of LDS per workgroup = THREE workgroups per CU instead of two, every K / V fragment feeding one MFMA instead of two:
+  // measured in round 6, profiles/r06_fwd_qb1_ab.txt)
+  static const bool force_qb1 = [] { const char* e = getenv("T2S_ATTN_FWD_QB1"); return e && atoi(e) != 0; }();
+  const bool wide = p.Lq > 256 && !force_qb1;
   dim3 block(256);
   if (wide) {
     dim3 grid(attn_xcd_grid((p.Lq + 255) / 256, p.H, p.B));
