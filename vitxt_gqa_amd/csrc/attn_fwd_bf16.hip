@@ -43,6 +43,9 @@ namespace {
 #ifndef FWD_PRIO_MODE
 #define FWD_PRIO_MODE 0
 #endif
+#ifndef FWD_ABL_QREG
+#define FWD_ABL_QREG 0     // 1: timing-only ablation of the steady state's Q fragment reads (tools/ablate; results wrong)
+#endif
 #define FWD_PRIO(stage_ad_, v_)                                                                     \
   if constexpr ((FWD_PRIO_MODE == 1 && (stage_ad_)) || (FWD_PRIO_MODE == 2 && !(stage_ad_))) __builtin_amdgcn_s_setprio(v_);
 constexpr int BK = 64;                     // keys per tile
@@ -324,6 +327,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     PACK_P_(qb_, kbk_, 1, buf, true);                                                               \
   }
     if constexpr (FWD_PRIO_MODE == 3) { if (blockIdx.x & 8) __builtin_amdgcn_s_setprio(1); }
+#if FWD_ABL_QREG      // TIMING-ONLY ablation (results wrong): the steady state's 16 Q fragment reads per tile replaced by ONE register fragment
+    const bf16x8 q_abl_ = Q_FRAG(0, 0);
+#define Q_FRAG_SS(qb_, s_) q_abl_
+#else
+#define Q_FRAG_SS(qb_, s_) Q_FRAG(qb_, s_)
+#endif
     for (int t = 1; t < nfast; ++t) {
       const int buf = t & 1;
       STAGE_LOAD_ROWS();                                 // tile t+1 (after the last fast tile: an unused, harmless load)
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       for (int s = 0; s < 4; ++s) {
         const bf16x8 kf = ROW_FRAG(kb, 0, s);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) sacc[qb][0] = mfma_bf16(kf, Q_FRAG(qb, s), s == 0 ? negm[qb] : sacc[qb][0]);
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][0] = mfma_bf16(kf, Q_FRAG_SS(qb, s), s == 0 ? negm[qb] : sacc[qb][0]);
       }
       FWD_PRIO(true, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       for (int s = 0; s < 4; ++s) {
         const bf16x8 kf = ROW_FRAG(kb, 1, s);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) sacc[qb][1] = mfma_bf16(kf, Q_FRAG(qb, s), s == 0 ? negm[qb] : sacc[qb][1]);
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][1] = mfma_bf16(kf, Q_FRAG_SS(qb, s), s == 0 ? negm[qb] : sacc[qb][1]);
       }
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) SOFTMAX_BLOCK(qb, 0, t);
@@ -386,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #undef PV_MFMAS
 #undef ROW_FRAG
 #undef Q_FRAG
+#undef Q_FRAG_SS
 #undef STAGE_LOAD
 #undef STAGE_LOAD_ROWS
 #undef IDX_LOAD
