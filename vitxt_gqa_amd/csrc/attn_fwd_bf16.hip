@@ -43,8 +43,8 @@ namespace {
 #ifndef FWD_PRIO_MODE
 #define FWD_PRIO_MODE 0
 #endif
-#ifndef FWD_ABL_QREG
-#define FWD_ABL_QREG 0     // 1: timing-only ablation of the steady state's Q fragment reads (tools/ablate; results wrong)
+#ifndef FWD_ABL
+#define FWD_ABL 0          // TIMING-ONLY ablations of the steady state (tools/ablate; results wrong): 1 no Q fragment reads, 2 no barrier, 4 no K / V staging, 8 K / V rows loaded and waited for but not written to LDS, 16 LDS writes without the loads, 32 every tile loads the SAME rows (cache-hot loads)
 #endif
 #define FWD_PRIO(stage_ad_, v_)                                                                     \
   if constexpr ((FWD_PRIO_MODE == 1 && (stage_ad_)) || (FWD_PRIO_MODE == 2 && !(stage_ad_))) __builtin_amdgcn_s_setprio(v_);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     PACK_P_(qb_, kbk_, 1, buf, true);                                                               \
   }
     if constexpr (FWD_PRIO_MODE == 3) { if (blockIdx.x & 8) __builtin_amdgcn_s_setprio(1); }
-#if FWD_ABL_QREG      // TIMING-ONLY ablation (results wrong): the steady state's 16 Q fragment reads per tile replaced by ONE register fragment
+#if FWD_ABL & 1       // TIMING-ONLY ablation (results wrong): the steady state's 16 Q fragment reads per tile replaced by ONE register fragment
     const bf16x8 q_abl_ = Q_FRAG(0, 0);
 #define Q_FRAG_SS(qb_, s_) q_abl_
 #else
@@ -335,8 +335,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #endif
     for (int t = 1; t < nfast; ++t) {
       const int buf = t & 1;
+#if !(FWD_ABL & (4 | 16))
       STAGE_LOAD_ROWS();                                 // tile t+1 (after the last fast tile: an unused, harmless load)
+#if !(FWD_ABL & 32)
       IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
+#endif
+#endif
       CK_LOAD(t + 1);
       const int kb = buf * 2 * TILE_BYTES, vb = kb + TILE_BYTES;
       if (DROP) {                                       // (one multiply + shift + or per query block and tile)
@@ -385,8 +389,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       // stage D: PV(key block 1)
       PV_MFMAS(vb, 1);
       FWD_PRIO(true, 0);
+#if FWD_ABL & 8
+      asm volatile("" ::"v"(kr0.x ^ vr0.y), "v"(kr1.z ^ vr1.w), "v"(kr0.w ^ kr1.x), "v"(vr0.z ^ vr1.y));
+#elif !(FWD_ABL & 4)
       STAGE_WRITE(buf ^ 1);
+#endif
+#if !(FWD_ABL & 2)
       __syncthreads();
+#endif
     }
 #undef SOFTMAX_BLOCK
   }
