@@ -590,23 +590,25 @@ def main():
         res["seed"] = args.seed
     # HBM traffic per launch from the PMC counters is a property of ONE configuration: profiles/traffic.json is keyed by
     # (B, F, P, dropout) and anything else reports null
-    traffic = {}
+    traffic, traffic_round = {}, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("B%d_F%d_P%d_drop%g" % (B, F, P, args.dropout), {})
+        tfile = json.load(open(tpath))
+        traffic, traffic_round = tfile.get("B%d_F%d_P%d_drop%g" % (B, F, P, args.dropout), {}), tfile.get("_round")
     # MFMA-busy of the attention kernels (SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle, tools/pmc_attn.sh on the kernels alone) - a
     # property of the kernel build, read from profiles/mfma_busy.json when the dropout setting matches
-    busy = {}
+    busy, busy_round = {}, None
     bpath = os.path.join(ROOT, "profiles", "mfma_busy.json")
     if os.path.exists(bpath):
-        busy = json.load(open(bpath)).get("drop%g" % args.dropout, {})
+        bfile = json.load(open(bpath))
+        busy, busy_round = bfile.get("drop%g" % args.dropout, {}), bfile.get("_round")
     # provenance of the two figures that are NOT measured in this run (they need rocprofv3 --pmc passes): file, configuration
     # and round they were taken at, carried in the line itself
     tkey = "B%d_F%d_P%d_drop%g" % (B, F, P, args.dropout)
     traffic_source = ("profiles/traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench command (%s), NOT measured "
-                      "in this run" % (tkey, traffic.get("_round", "round 3 kernels"))) if traffic else None
+                      "in this run" % (tkey, traffic_round or "the build the file was committed with")) if traffic else None
     busy_source = ("profiles/mfma_busy.json[drop%g]: SQ_VALU_MFMA_BUSY_CYCLES of the kernel ALONE in tools/attn_probe.py at B=8, L=10132, "
-                   "70 %% of the keys visible (%s), NOT measured in this run" % (args.dropout, busy.get("_round", "round 3 kernels"))) if busy else None
+                   "70 %% of the keys visible (%s), NOT measured in this run" % (args.dropout, busy_round or "the build the file was committed with")) if busy else None
     L_seq = T_Q + F + F * P + (3 * DEC if not args.forward_only else DEC)
     alg_fwd = 4.0 * B * L_seq * HID * 2            # Q, K, V read + O written once, bf16 (dense upper bound: every key visible)
     alg_bwd = 8.0 * B * L_seq * HID * 2            # Q, K, V, O, dO read + dQ, dK, dV written once

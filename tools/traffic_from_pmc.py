@@ -12,6 +12,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 out = sys.argv[1]
@@ -46,4 +47,6 @@ for key, pats in fam.items():
                                   "kernels": {k[:70]: {"dispatches_per_step": nf.get(k, 0) / STEPS_PROFILED,
                                                        "fetch_kb_per_step": fetch.get(k, 0.0) / STEPS_PROFILED,
                                                        "write_kb_per_step": write.get(k, 0.0) / STEPS_PROFILED} for k in sorted(names)}}
-print(json.dumps({"B%d_F%d_P%d_drop%g" % (64, 100, 100, bench["config"]["dropout"]): res}, indent=1))
+# "_round": which build / call the passes ran on - bench.py quotes it beside the figure it reads from this file
+print(json.dumps({"_round": "profile tag " + os.path.basename(os.path.normpath(out)),
+                  "B%d_F%d_P%d_drop%g" % (64, 100, 100, bench["config"]["dropout"]): res}, indent=1))
