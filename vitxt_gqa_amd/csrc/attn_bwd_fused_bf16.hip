@@ -31,6 +31,9 @@
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef FB_ABL_NOBAR
+#define FB_ABL_NOBAR 0                            // TIMING-ONLY ablation (results wrong, tools/ablate): 1 no barrier behind slot 1, 2 no barrier at the end of the tile
+#endif
 #ifndef FB_DQ_DEPTH
 #define FB_DQ_DEPTH 3                             // 16-key steps the operand reads of the interleaved dQ product run ahead of their MFMA (see afA / bfA)
 #endif
@@ -778,7 +781,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // store of this tile, instead of behind the atomics: a wave that got its atomics out early starts the next tile.  A bare
         // s_barrier: it orders later LDS writes behind earlier LDS reads whose data has long been consumed by MFMAs - nothing
         // to wait for (__syncthreads would drain the LDS loads in flight here)
+#if !(FB_ABL_NOBAR & 1)
         asm volatile("s_barrier" ::: "memory");
+#endif
         if constexpr (ILV) { FB_LD_QT(0); }                  // (ILV: the transposed Q / dO fragments of sub-block 0, first used right below)
         FB_LD_KF(2); FB_FENCE();
         FB_SLOT_G2M(0);
@@ -917,7 +922,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #pragma unroll
         for (int g = 0; g < 4; ++g) pin[g] = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ho_ld + g * 1024, 0, 16 /* sc1 */);
       }
+#if !(FB_ABL_NOBAR & 2)
       __syncthreads();                                       // the dS^T image of this query tile is complete
+#else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
       if constexpr (HO && !TAIL) {
         // publish the previous tile's running sum: every wave drained its stores before the barrier above
         if ((!CAN_LAST || !ho_last) && tid == 0 && qt > 0 && !w.never_publish)
