@@ -34,6 +34,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef FB_ABL_NOBAR
 #define FB_ABL_NOBAR 0                            // TIMING-ONLY ablation (results wrong, tools/ablate): 1 no barrier behind slot 1, 2 no barrier at the end of the tile
 #endif
+// FB_SOFT_SYNC: in the interleaved sweep the dS^T image's readers (the dQ steps of slots 0 / 1) are retired ahead of the tile's first dS^T
+// store by an LDS COUNTER instead of the workgroup barrier behind slot 1: every wave adds 1 when its slot 1 is through, and a wave waits
+// for 4 (tile + 1) only where it needs it - in front of its first dS^T store, which moves from inside slot 2 to just behind it.  The
+// barrier made every wave wait for the slowest one's slot 1 before its own slot 2; the counter gives the waves a slot of slack
+// (removing the barrier outright, results wrong, measured -2.2 %: profiles/r06_fb_ablation_stamps.txt).
+#ifndef FB_SOFT_SYNC
+#define FB_SOFT_SYNC 0
+#endif
 #ifndef FB_DQ_DEPTH
 #define FB_DQ_DEPTH 3                             // 16-key steps the operand reads of the interleaved dQ product run ahead of their MFMA (see afA / bfA)
 #endif
@@ -45,7 +53,8 @@ constexpr int FB_QROWS = 64;
 constexpr int FB_TILE = FB_QROWS * 128;           // bytes of a 64-row bf16 tile
 constexpr int FB_STAGE = 2 * FB_TILE + 2 * FB_QROWS * 4 + (FB_QROWS / 2) * 4;   // Q | dO | -lse*log2e | -delta | dropout row keys (pairs)
 constexpr int FB_KIMG = FB_KEYS * 128;
-constexpr int FB_SMEM = 2 * FB_KIMG + 2 * FB_STAGE;
+constexpr int FB_SMEM_IMG = 2 * FB_KIMG + 2 * FB_STAGE;
+constexpr int FB_SMEM = FB_SMEM_IMG + 16;         // + the readers' counter (FB_SOFT_SYNC)
 
 // ---- dQ across the key blocks of a (sample, head): two forms, chosen per launch (FbWork::handoff).
 // ATOMIC (rounds 2-3): every key block adds its [64 x 64] tile to an fp32 [B Lq, H 64] buffer with float atomics (memory-side,
@@ -518,6 +527,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
       } while (fvs_ < ho_wait);                                                                 \
     }                                                                                           \
   }
+    unsigned* const rd_cnt = reinterpret_cast<unsigned*>(smem + FB_SMEM_IMG);       // FB_SOFT_SYNC: waves through slot 1, over all tiles so far
+    if (tid == 0) *rd_cnt = 0u;
     FB_STAGE_LOAD();
     FB_STAGE_WRITE(0);
     __syncthreads();
@@ -718,7 +729,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   FB_G1(n_, 3); FB_E(e_, 3); FB_FENCE(); FB_G1(n_, 4); FB_E(e_, 4); FB_FENCE(); FB_G1(n_, 5); FB_E(e_, 5); FB_FENCE();            \
   FB_G1(n_, 6); FB_E(e_, 6); FB_FENCE(); FB_G1(n_, 7); FB_E(e_, 7); FB_FENCE();
         // slot "G2(i) + M(i)": dV^T MFMAs with two chunks of M each, then the dK^T MFMAs beside the dS^T stores
-#define FB_SLOT_G2M(i_)                                                                             \
+#define FB_SLOT_G2M(i_) FB_SLOT_G2M_(i_, true)
+#define FB_SLOT_G2M_(i_, st_)                                                                       \
   FB_LD_DL(i_);                                                                                     \
   FB_G2(i_, 0); FB_M2(i_, 0); FB_FENCE(); FB_G2(i_, 1); FB_M2(i_, 2); FB_FENCE();                                                \
   FB_G2(i_, 2); FB_M2H(i_, 4); FB_FENCE(); FB_G2(i_, 3); FB_M2T(i_, 4); FB_FENCE();                                               \
@@ -726,7 +738,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
   /* the s = 1 MFMAs that read them: the asm MFMAs get no hazard nops), the seeds of block i + 2 are fetched once the last chunk */     \
   /* has read this block's accumulators, the dS^T stores follow */                                                                   \
   FB_G2(i_, 4); FB_M2(i_, 6); FB_FENCE(); FB_G2(i_, 5); if ((i_) + 2 < 6) { FB_LD_SEEDS(lse_s, del_s, (i_) + 2); } FB_FENCE(); \
-  FB_G2(i_, 6); FB_ST_DS(i_); FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
+  FB_G2(i_, 6); if (st_) { FB_ST_DS(i_); } FB_FENCE(); FB_G2(i_, 7); FB_FENCE();
         if (!PREF) { FB_LD_QF(qb_, dob_, 0); FB_LD_SEEDS(lse_s, del_s, 0); FB_LD_KF(0); }
         FB_FENCE();
         // slot 0: G1(b0), no VALU work of this tile to pair yet; the transposed fragments of sub-block 0 arrive meanwhile.  ILV: twelve of
@@ -781,12 +793,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
         // store of this tile, instead of behind the atomics: a wave that got its atomics out early starts the next tile.  A bare
         // s_barrier: it orders later LDS writes behind earlier LDS reads whose data has long been consumed by MFMAs - nothing
         // to wait for (__syncthreads would drain the LDS loads in flight here)
+        constexpr bool SOFT = ILV && FB_SOFT_SYNC;
+        if constexpr (SOFT) {
+          // this wave's reads of the dS^T image are done (their data went into MFMAs that have issued; LDS operations of a wave execute in order)
+          if (lane == 0) __hip_atomic_fetch_add(rd_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
 #if !(FB_ABL_NOBAR & 1)
-        asm volatile("s_barrier" ::: "memory");
+          asm volatile("s_barrier" ::: "memory");
 #endif
+        }
         if constexpr (ILV) { FB_LD_QT(0); }                  // (ILV: the transposed Q / dO fragments of sub-block 0, first used right below)
         FB_LD_KF(2); FB_FENCE();
-        FB_SLOT_G2M(0);
+        if constexpr (SOFT) {
+          FB_SLOT_G2M_(0, false);
+          // every wave's slot 1 of this tile is through: the image may be written.  (Between two slots: a branch here splits no slot.)
+          const unsigned rd_target = 4u * (unsigned)(qt + 1);
+          while (__hip_atomic_load(rd_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rd_target) __builtin_amdgcn_s_sleep(1);
+          FB_ST_DS(0); FB_FENCE();
+        } else {
+          FB_SLOT_G2M(0);
+        }
         FB_SLOT_G1E(2, 1);                                   // last use of sub-block 0's row fragments and row constants
         FB_LD_QF(qb_, dob_, 1); FB_LD_KF(0); FB_FENCE();
         FB_SLOT_G2M(1);
@@ -819,6 +845,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_bf16_kernel(AttnParams 
 #undef FB_M2T
 #undef FB_SLOT_G1E
 #undef FB_SLOT_G2M
+#undef FB_SLOT_G2M_
         }
       } else {
 #pragma unroll
