@@ -43,6 +43,9 @@ namespace {
 #ifndef FWD_PRIO_MODE
 #define FWD_PRIO_MODE 0
 #endif
+#ifndef FWD_RK_EVERY_TILE
+#define FWD_RK_EVERY_TILE 0   // 1: the dropout row key recomputed on every tile (the form until round 6; 7.89 vs 7.83 ms at B = 32: profiles/r06_fwd_prio_ab.txt)
+#endif
 #ifndef FWD_ABL
 #define FWD_ABL 0          // TIMING-ONLY ablations of the steady state (tools/ablate; results wrong): 1 no Q fragment reads, 2 no barrier, 4 no K / V staging, 8 K / V rows loaded and waited for but not written to LDS, 16 LDS writes without the loads, 32 every tile loads the SAME rows (cache-hot loads)
 #endif
@@ -343,7 +346,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 #endif
       CK_LOAD(t + 1);
       const int kb = buf * 2 * TILE_BYTES, vb = kb + TILE_BYTES;
+#if FWD_RK_EVERY_TILE
       if (DROP) {                                       // (one multiply + shift + or per query block and tile)
+#else
+      // the row key changes with the KEY WINDOW (ATTN_DROP_KWIN = 6 tiles): recomputed behind a scalar branch on the window's first tile only
+      // (a quarter-rate multiply + two more instructions per query block: 12 of the tile's ~335 vector issue slots)
+      if (DROP && (t == 1 || (t * BK) % ATTN_DROP_KWIN == 0)) {
+#endif
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) rk2[qb] = attn_drop_rowkey16w(rh[qb], (t * BK) / ATTN_DROP_KWIN) * 0x10001u;
       }
