@@ -47,7 +47,7 @@ namespace {
 #define FWD_RK_EVERY_TILE 0   // 1: the dropout row key recomputed on every tile (the form until round 6; 7.89 vs 7.83 ms at B = 32: profiles/r06_fwd_prio_ab.txt)
 #endif
 #ifndef FWD_ABL
-#define FWD_ABL 0          // TIMING-ONLY ablations of the steady state (tools/ablate; results wrong): 1 no Q fragment reads, 2 no barrier, 4 no K / V staging, 8 K / V rows loaded and waited for but not written to LDS, 16 LDS writes without the loads, 32 every tile loads the SAME rows (cache-hot loads)
+#define FWD_ABL 0          // TIMING-ONLY ablations of the steady state (tools/ablate; results wrong): 1 no Q fragment reads, 2 no barrier, 4 no K / V staging, 8 K / V rows loaded and waited for but not written to LDS, 16 LDS writes without the loads, 32 every tile loads the SAME rows (cache-hot loads), 64 no column-key hashing in the steady state
 #endif
 #define FWD_PRIO(stage_ad_, v_)                                                                     \
   if constexpr ((FWD_PRIO_MODE == 1 && (stage_ad_)) || (FWD_PRIO_MODE == 2 && !(stage_ad_))) __builtin_amdgcn_s_setprio(v_);
@@ -344,7 +344,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
       IDX_LOAD(t + 2);                                   // its indices are not needed before the next iteration
 #endif
 #endif
+#if !(FWD_ABL & 64)
       CK_LOAD(t + 1);
+#endif
       const int kb = buf * 2 * TILE_BYTES, vb = kb + TILE_BYTES;
 #if FWD_RK_EVERY_TILE
       if (DROP) {                                       // (one multiply + shift + or per query block and tile)
