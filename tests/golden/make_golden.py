@@ -356,6 +356,12 @@ def main():
         run_case("full_peaky_b2_f100_p100", B=2, F_=100, P=100, V=5000, text_vocab=30522, seed=23, attn_gain=PEAKY_GAIN,
                  store_inputs=False, ocr_keep=[0.7, 0.3], text_len=[20, 7], attn_stats=True)
         return
+    if "peaky2" in only:
+        # a SECOND seed at an operating point between the two above (late round 6: "one seed" was half of VERDICT r5 #1): seed 29, query / key
+        # weights x 4 (score sigma ~ 5 nats), ocr_mask densities 0.9 / 0.5, question lengths 13 / 20 -> ~9 100 and ~5 100 visible keys
+        run_case("full_peaky_s29_b2_f100_p100", B=2, F_=100, P=100, V=5000, text_vocab=30522, seed=29, attn_gain=4.0,
+                 store_inputs=False, ocr_keep=[0.9, 0.5], text_len=[13, 20], attn_stats=True)
+        return
     # tiny: P >= ocr_topk, F >= frame_topk (Appendix E); peaky attention (attn_gain) so that the
     # softmax is far from uniform and a wrong mask / wrong scale shows up
     run_case("tiny_b2_f6_p8", B=2, F_=6, P=8, V=64, text_vocab=1000, seed=3, attn_gain=6.0, store_inputs=True)

@@ -293,18 +293,25 @@ def test_oracle_gradients_at_the_metric_length_match_reference():
     assert abs(total - fx["grad_total_norm"].item()) / fx["grad_total_norm"].item() < 1e-3
 
 
-@pytest.mark.parametrize("samples", [(1,)] + ([(0, 1)] if __import__("os").environ.get("T2S_SLOW_TESTS", "0") == "1" else []))
-def test_oracle_under_peaky_attention_at_the_metric_length_matches_reference(samples):
+_SLOW = __import__("os").environ.get("T2S_SLOW_TESTS", "0") == "1"
+
+
+@pytest.mark.parametrize("case,samples", [("full_peaky_b2_f100_p100", (1,)), ("full_peaky_s29_b2_f100_p100", (1,))] + ([("full_peaky_b2_f100_p100", (0, 1)), ("full_peaky_s29_b2_f100_p100", (0, 1))] if _SLOW else []))
+def test_oracle_under_peaky_attention_at_the_metric_length_matches_reference(case, samples):
     """Round 6: the oracle against the reference's outputs at L = 10 132 under PEAKY attention - fixture
     full_peaky_b2_f100_p100: query / key weights x 6 (the reference's own attention entropy 0.3 - 1.2 nats against 8.5 uniform, score
     ranges of 37 - 316 nats per row: the fixture's meta), two different samples (7 136 / 3 064 visible keys).  The default suite runs the
     SHORT-list sample alone (sample 1: ~70 s on 8 cores; what no other full-length fixture has), T2S_SLOW_TESTS=1 the whole batch with
     the batch-mean losses.  Same tolerances as at the reference init (logits 2e-4, intermediates 2e-5 ... 1e-4; measured: logits 9e-6,
     MMT outputs 2e-5) and the SAME argmax indices."""
-    fx, sd, s, res = _full_length_oracle(False, "full_peaky_b2_f100_p100", samples)
+    fx, sd, s, res = _full_length_oracle(False, case, samples)
     st_ = fx.meta["attention_stats"]
-    assert max(v["entropy_mean"] for v in st_.values()) < 3.0 and min(v["range_min"] for v in st_.values()) > 20.0      # peaky, by the reference's own numbers
-    assert fx.meta["ocr_keep"] == [0.7, 0.3] and fx.meta["text_len"] == [20, 7]
+    if case == "full_peaky_b2_f100_p100":
+        assert max(v["entropy_mean"] for v in st_.values()) < 3.0 and min(v["range_min"] for v in st_.values()) > 20.0      # peaky, by the reference's own numbers
+        assert fx.meta["ocr_keep"] == [0.7, 0.3] and fx.meta["text_len"] == [20, 7]
+    else:        # the second seed (late round 6; sample 1: ~45 s on 8 cores): seed 29, gain 4, densities 0.9 / 0.5
+        assert max(v["entropy_mean"] for v in st_.values()) < 4.5 and min(v["range_min"] for v in st_.values()) > 15.0
+        assert fx.meta["ocr_keep"] == [0.9, 0.5] and fx.meta["text_len"] == [13, 20] and fx.meta["seed"] == 29
     idx = list(samples)
     it, st = res["_inter"], fx.meta["row_stride"]
     worst = {}
@@ -322,7 +329,7 @@ def test_oracle_under_peaky_attention_at_the_metric_length_matches_reference(sam
         assert worst[name] < tol, (name, worst[name], tol)
     assert torch.equal(res["ground_frame"], fx["ground_frame"][idx])
     assert torch.equal(res["ground_box"].float(), fx["ground_box"][idx])
-    print("oracle vs reference, peaky fixture, samples %s: " % (samples,) + ", ".join("%s %.1e" % kv for kv in worst.items()))
+    print("oracle vs reference, %s, samples %s: " % (case, samples) + ", ".join("%s %.1e" % kv for kv in worst.items()))
     if len(idx) == fx.B:
         loss, a, b = O.total_loss(res, s["targets"], s["train_loss_mask"])
         _close(a, fx["loss_bce"], 1e-3, what="bce")
