@@ -101,7 +101,7 @@ def run(case):
 def main():
     MG.install_shims()
     torch.set_num_threads(8)
-    cases = sys.argv[1:] or ["full_b1_f100_p100", "full_peaky_b2_f100_p100"]
+    cases = sys.argv[1:] or ["full_b1_f100_p100", "full_peaky_b2_f100_p100", "full_peaky_s29_b2_f100_p100"]
     path = os.path.join(HERE, "bf16_floor.json")
     res = json.load(open(path)) if os.path.exists(path) else {}
     for case in cases:
