@@ -347,7 +347,7 @@ def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_
     so (out 0.2 x scale, LSE 0.3, gradients 8 % relative L2; measured 0.12 / 0.19 / 5.3 %).  "prescaled_q": Q arrives multiplied by
     scale log2 e (rounded once) and scale = 1 / log2 e, so the kernels' own pre-scaling is exact and forward and backward see identical
     scores: every element within the usual 3e-2, LSE 2e-5, gradients ~1 % (measured).  Folding the factor into the query projection was
-    built and measured (tools/ablate/variants/fold_qscale_into_projection.patch): at the model level it did NOT bring the bf16 mode closer to
+    built and measured (since late round 6 an opt-in of vitxt_gqa_amd/functional.py: T2S_FOLD_QSCALE=1): at the model level it did NOT bring the bf16 mode closer to
     the reference's fp32 gradients (HISTORY.md, round 6), so the product keeps the raw-Q call."""
     _need_gpu()
     from vitxt_gqa_amd import ops
