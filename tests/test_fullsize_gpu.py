@@ -347,8 +347,8 @@ def test_attention_peaky_unequal_chains_with_repair_at_full_length_against_fp64_
     so (out 0.2 x scale, LSE 0.3, gradients 8 % relative L2; measured 0.12 / 0.19 / 5.3 %).  "prescaled_q": Q arrives multiplied by
     scale log2 e (rounded once) and scale = 1 / log2 e, so the kernels' own pre-scaling is exact and forward and backward see identical
     scores: every element within the usual 3e-2, LSE 2e-5, gradients ~1 % (measured).  Folding the factor into the query projection was
-    built and measured (since late round 6 an opt-in of vitxt_gqa_amd/functional.py: T2S_FOLD_QSCALE=1): at the model level it did NOT bring the bf16 mode closer to
-    the reference's fp32 gradients (HISTORY.md, round 6), so the product keeps the raw-Q call."""
+    built, measured, held back on a norm-count metric and then shipped on an element-wise one (vitxt_gqa_amd/functional.py, FOLD_QSCALE: HISTORY.md,
+    "Round 6, late additions"): the model's long sequences run in the "prescaled_q" regime of this test, TextBert (L = 20) in the raw one."""
     _need_gpu()
     from vitxt_gqa_amd import ops
     ops.reset_fused_status()
